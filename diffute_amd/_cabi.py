@@ -1,0 +1,133 @@
+"""ctypes binding of the gfx950 C-ABI library (include/diffute_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  Nothing under oracle/ is ever imported from here.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffute_hip.so")
+_lib = None
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("x0", c_void_p), ("x1", c_void_p), ("ldx0", c_int), ("ldx1", c_int), ("cx0", c_int),
+        ("direct", c_int), ("IH", c_int), ("IW", c_int), ("OH", c_int), ("OW", c_int),
+        ("stride", c_int), ("pad", c_int), ("ups", c_int), ("ksize", c_int), ("Cin", c_int), ("Ktaps", c_int),
+        ("s0", c_void_p), ("s1", c_void_p), ("lds0", c_int), ("lds1", c_int), ("cs0", c_int),
+        ("w", c_void_p), ("ldw", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
+        ("bias", c_void_p), ("rowbias", c_void_p), ("rows_per_group", c_int), ("ldrb", c_int),
+        ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("geglu", c_int),
+    ]
+
+
+class UNetConfig(ctypes.Structure):
+    _fields_ = [("in_channels", c_int), ("out_channels", c_int), ("block_out_channels", c_int * 4),
+                ("layers_per_block", c_int), ("heads", c_int * 4), ("cross_attention_dim", c_int),
+                ("norm_num_groups", c_int), ("down_has_attn", c_int * 4), ("up_has_attn", c_int * 4)]
+
+
+class VAEConfig(ctypes.Structure):
+    _fields_ = [("in_channels", c_int), ("out_channels", c_int), ("latent_channels", c_int),
+                ("block_out_channels", c_int * 4), ("layers_per_block", c_int), ("norm_num_groups", c_int)]
+
+
+_P = c_void_p
+_PROTOS = {
+    "dmx_version": (c_int, []),
+    "dmx_last_error": (c_char_p, []),
+    "dmx_conv_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
+    "dmx_conv_gemm": (c_int, [POINTER(GemmDesc), _P, c_size_t, _P]),
+    "dmx_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dmx_groupnorm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, c_int, _P, c_size_t, _P]),
+    "dmx_layernorm": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P]),
+    "dmx_attention_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "dmx_timestep_embedding": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
+    "dmx_linear_small": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dmx_im2col_small": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "dmx_pack_conv_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dmx_pack_linear_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dmx_pack_geglu_bias": (c_int, [_P, _P, c_int, _P]),
+    "dmx_cast_f32_to_bf16": (c_int, [_P, _P, c_size_t, _P]),
+    "dmx_nhwc_bf16_to_nchw_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
+    "dmx_nhwc_f32_to_nchw_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
+    "dmx_nchw_f32_to_nhwc_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dmx_sched_step_ddim": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "dmx_sched_step_ddpm": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "dmx_sched_add_noise": (c_int, [_P, _P, _P, _P, _P, c_int, c_size_t, _P]),
+    "dmx_sched_get_velocity": (c_int, [_P, _P, _P, _P, _P, c_int, c_size_t, _P]),
+    "dmx_gaussian_sample": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "dmx_unet_create": (_P, [POINTER(UNetConfig)]),
+    "dmx_unet_destroy": (None, [_P]),
+    "dmx_unet_param_count": (c_int, [_P]),
+    "dmx_unet_param_info": (c_int, [_P, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
+    "dmx_unet_arena_bytes": (c_size_t, [_P]),
+    "dmx_unet_bind_arena": (c_int, [_P, _P, c_size_t]),
+    "dmx_unet_load_param": (c_int, [_P, c_char_p, _P, _P]),
+    "dmx_unet_finalize": (c_int, [_P, _P, _P]),
+    "dmx_unet_context_bytes": (c_size_t, [_P, c_int, c_int]),
+    "dmx_unet_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
+    "dmx_unet_set_context": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_size_t, _P, c_size_t, _P]),
+    "dmx_unet_forward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_vae_create": (_P, [POINTER(VAEConfig)]),
+    "dmx_vae_destroy": (None, [_P]),
+    "dmx_vae_param_count": (c_int, [_P]),
+    "dmx_vae_param_info": (c_int, [_P, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
+    "dmx_vae_arena_bytes": (c_size_t, [_P]),
+    "dmx_vae_bind_arena": (c_int, [_P, _P, c_size_t]),
+    "dmx_vae_load_param": (c_int, [_P, c_char_p, _P, _P]),
+    "dmx_vae_finalize": (c_int, [_P, _P]),
+    "dmx_vae_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
+    "dmx_vae_encode": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_vae_decode": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"diffute_amd: HIP extension not built ({_LIB_PATH} missing). "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C diffute_amd/csrc`. "
+                "There is no CPU fallback.")
+        l = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS.keys())
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dmx_last_error()
+        raise RuntimeError(f"diffute_amd: {what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("diffute_amd: tensors must live on the GPU (cuda / ROCm device); there is no CPU path")

@@ -1,0 +1,126 @@
+// extern "C" operator-level entry points declared in include/diffute_hip.h.
+#include "kernels.h"
+#include "../../include/diffute_hip.h"
+
+const char* dmx_get_error();
+
+extern "C" int dmx_version(void) { return 100; }
+extern "C" const char* dmx_last_error(void) { return dmx_get_error(); }
+
+static GemmArgs to_args(const dmx_gemm_desc* d) {
+  GemmArgs a{};
+  a.x0 = (const bf16*)d->x0; a.x1 = d->x1 ? (const bf16*)d->x1 : (const bf16*)d->x0;
+  a.ldx0 = d->ldx0; a.ldx1 = d->x1 ? d->ldx1 : d->ldx0; a.cx0 = d->cx0; a.direct = d->direct;
+  a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW;
+  a.stride = d->stride; a.pad = d->pad; a.ups = d->ups; a.ksize = d->ksize; a.Cin = d->Cin; a.Ktaps = d->Ktaps;
+  a.s0 = (const bf16*)d->s0; a.s1 = d->s1 ? (const bf16*)d->s1 : (const bf16*)d->s0;
+  a.lds0 = d->lds0; a.lds1 = d->s1 ? d->lds1 : d->lds0; a.cs0 = d->cs0;
+  a.w = (const bf16*)d->w; a.ldw = d->ldw; a.M = d->M; a.N = d->N; a.K = d->K;
+  a.bias = d->bias; a.rowbias = d->rowbias; a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1; a.ldrb = d->ldrb;
+  a.res = (const bf16*)d->res; a.ldres = d->ldres; a.out = d->out; a.ldo = d->ldo; a.out_f32 = d->out_f32; a.geglu = d->geglu;
+  return a;
+}
+extern "C" size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d) { return d ? dmx_gemm_workspace_bytes(to_args(d)) : 0; }
+extern "C" int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(d && d->x0 && d->w && d->out, "conv_gemm: null argument");
+  return dmx_gemm_launch(to_args(d), workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int dmx_groupnorm(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
+                             int B, int HW, const float* gamma, const float* beta, float eps, int silu,
+                             void* y, int ldy, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(x0 && y && gamma && beta, "groupnorm: null argument");
+  DMX_REQUIRE(workspace && workspace_bytes >= dmx_gn_workspace_bytes(B, HW, groups), "groupnorm: workspace too small");
+  GroupNormArgs a{};
+  a.x0 = (const bf16*)x0; a.ldx0 = ldx0; a.x1 = (const bf16*)x1; a.ldx1 = ldx1; a.c0 = x1 ? c0 : C;
+  a.C = C; a.groups = groups; a.B = B; a.HW = HW; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
+  a.y = (bf16*)y; a.ldy = ldy; a.partial = (float*)workspace;
+  return dmx_groupnorm_launch(a, (hipStream_t)stream);
+}
+extern "C" int dmx_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                             int rows, int C, float eps, dmx_stream_t stream) {
+  DMX_REQUIRE(x && y && gamma && beta, "layernorm: null argument");
+  return dmx_layernorm_launch((const bf16*)x, ldx, (bf16*)y, ldy, gamma, beta, rows, C, eps, (hipStream_t)stream);
+}
+extern "C" int dmx_attention_fwd(const void* q, int ldq, const void* k, int ldk, int kv_rows, const void* vt, int ldvt, int skv_stride,
+                                 void* o, int ldo, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream) {
+  DMX_REQUIRE(q && k && vt && o, "attention: null argument");
+  AttnArgs a{};
+  a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.kv_rows = kv_rows;
+  a.vt = (const bf16*)vt; a.ldvt = ldvt; a.skv_stride = skv_stride; a.o = (bf16*)o; a.ldo = ldo;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  return dmx_attention_launch(a, (hipStream_t)stream);
+}
+extern "C" int dmx_timestep_embedding(const int64_t* t, int t_count, const float* freq, int B, int dim, float* out, dmx_stream_t stream) {
+  DMX_REQUIRE(t && freq && out, "timestep_embedding: null argument");
+  return dmx_timestep_embedding_launch((const long long*)t, t_count, freq, B, dim, out, (hipStream_t)stream);
+}
+extern "C" int dmx_linear_small(const float* x, int ldx, const void* w, int ldw, const float* bias, float* y, int ldy,
+                                int B, int N, int K, int silu_in, dmx_stream_t stream) {
+  DMX_REQUIRE(x && w && y, "linear_small: null argument");
+  return dmx_linear_small_launch(x, ldx, (const bf16*)w, ldw, bias, y, ldy, B, N, K, silu_in, (hipStream_t)stream);
+}
+extern "C" int dmx_im2col_small(const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                                const void* h_nhwc, int ldh, int C, int B, int IH, int IW, int OH, int OW,
+                                int ksize, int stride, int pad, void* out, int Kpad, dmx_stream_t stream) {
+  DMX_REQUIRE(out != nullptr, "im2col_small: null output");
+  Im2colArgs a{};
+  a.f0 = f0; a.c0 = c0; a.f1 = f1; a.c1 = c1; a.f2 = f2; a.c2 = c2; a.h = (const bf16*)h_nhwc; a.ldh = ldh; a.C = C;
+  a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.ksize = ksize; a.stride = stride; a.pad = pad; a.out = (bf16*)out; a.Kpad = Kpad;
+  return dmx_im2col_small_launch(a, (hipStream_t)stream);
+}
+extern "C" int dmx_pack_conv_weight(const float* w, void* out, int Cout, int Cin, int ksize, int ldk, int koff, dmx_stream_t stream) {
+  DMX_REQUIRE(w && out, "pack_conv_weight: null argument");
+  return dmx_pack_conv_weight_launch(w, (bf16*)out, Cout, Cin, ksize, ldk, koff, (hipStream_t)stream);
+}
+extern "C" int dmx_pack_linear_weight(const float* w, void* out, int rows, int cols, int ldo, int geglu, dmx_stream_t stream) {
+  DMX_REQUIRE(w && out, "pack_linear_weight: null argument");
+  return dmx_pack_rows_launch(w, (bf16*)out, rows, cols, ldo, geglu, (hipStream_t)stream);
+}
+extern "C" int dmx_pack_geglu_bias(const float* b, float* out, int n, dmx_stream_t stream) {
+  DMX_REQUIRE(b && out, "pack_geglu_bias: null argument");
+  return dmx_pack_geglu_bias_launch(b, out, n, (hipStream_t)stream);
+}
+extern "C" int dmx_cast_f32_to_bf16(const float* in, void* out, size_t n, dmx_stream_t stream) {
+  DMX_REQUIRE(in && out, "cast: null argument");
+  return dmx_cast_f32_to_bf16_launch(in, (bf16*)out, n, (hipStream_t)stream);
+}
+extern "C" int dmx_nhwc_bf16_to_nchw_f32(const void* in, int ldin, float* out, int B, int C, int HW, dmx_stream_t stream) {
+  DMX_REQUIRE(in && out, "nhwc_bf16_to_nchw_f32: null argument");
+  return dmx_nhwc_bf16_to_nchw_f32_launch((const bf16*)in, ldin, out, B, C, HW, (hipStream_t)stream);
+}
+extern "C" int dmx_nhwc_f32_to_nchw_f32(const float* in, int ldin, float* out, int B, int C, int HW, dmx_stream_t stream) {
+  DMX_REQUIRE(in && out, "nhwc_f32_to_nchw_f32: null argument");
+  return dmx_nhwc_to_nchw_f32_launch(in, ldin, out, B, C, HW, (hipStream_t)stream);
+}
+extern "C" int dmx_nchw_f32_to_nhwc_bf16(const float* in, void* out, int ldo, int B, int C, int HW, dmx_stream_t stream) {
+  DMX_REQUIRE(in && out, "nchw_f32_to_nhwc_bf16: null argument");
+  return dmx_nchw_f32_to_nhwc_bf16_launch(in, (bf16*)out, ldo, B, C, HW, (hipStream_t)stream);
+}
+extern "C" int dmx_sched_step_ddim(const float* sample, const float* model_output, const float* noise, float* prev_sample, size_t n,
+                                   float sqrt_beta_prod_t, float sqrt_alpha_prod_t, float sqrt_alpha_prod_prev,
+                                   float dir_coef, float std_dev, int v_prediction, dmx_stream_t stream) {
+  DMX_REQUIRE(sample && model_output && prev_sample, "sched_step_ddim: null argument");
+  return dmx_sched_ddim_launch(sample, model_output, noise, prev_sample, n, sqrt_beta_prod_t, sqrt_alpha_prod_t, sqrt_alpha_prod_prev,
+                               dir_coef, std_dev, v_prediction, (hipStream_t)stream);
+}
+extern "C" int dmx_sched_step_ddpm(const float* sample, const float* model_output, const float* noise, float* prev_sample, size_t n,
+                                   float sqrt_beta_prod_t, float sqrt_alpha_prod_t, float coef_x0, float coef_xt,
+                                   float sigma, int v_prediction, dmx_stream_t stream) {
+  DMX_REQUIRE(sample && model_output && prev_sample, "sched_step_ddpm: null argument");
+  return dmx_sched_ddpm_launch(sample, model_output, noise, prev_sample, n, sqrt_beta_prod_t, sqrt_alpha_prod_t, coef_x0, coef_xt,
+                               sigma, v_prediction, (hipStream_t)stream);
+}
+extern "C" int dmx_sched_add_noise(const float* x0, const float* noise, const float* sa, const float* sb, float* out, int B, size_t per, dmx_stream_t stream) {
+  DMX_REQUIRE(x0 && noise && sa && sb && out, "sched_add_noise: null argument");
+  return dmx_add_noise_launch(x0, noise, sa, sb, out, B, per, 0, (hipStream_t)stream);
+}
+extern "C" int dmx_sched_get_velocity(const float* x0, const float* noise, const float* sa, const float* sb, float* out, int B, size_t per, dmx_stream_t stream) {
+  DMX_REQUIRE(x0 && noise && sa && sb && out, "sched_get_velocity: null argument");
+  return dmx_add_noise_launch(x0, noise, sa, sb, out, B, per, 1, (hipStream_t)stream);
+}
+extern "C" int dmx_gaussian_sample(const float* moments, const float* noise, float* out, int B, int C, int HW, float scale, dmx_stream_t stream) {
+  DMX_REQUIRE(moments && out, "gaussian_sample: null argument");
+  return dmx_gaussian_sample_launch(moments, noise, out, B, C, HW, scale, (hipStream_t)stream);
+}
+extern "C" size_t dmx_groupnorm_workspace_bytes(int B, int HW, int groups) { return dmx_gn_workspace_bytes(B, HW, groups); }

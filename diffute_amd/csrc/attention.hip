@@ -1,0 +1,176 @@
+// Flash-style fused attention forward, head dim 64, bf16 MFMA (SURVEY.md 8a K5 self, K6 cross).
+//
+//   O[b, q, h, :] = softmax(Q K^T * scale) V        (no mask; Skv = 577 tail handled)
+//
+// grid (ceil(Sq/128), H, B), 256 threads = 4 waves; each wave owns 32 query rows, the
+// block streams 64-key K / V^T tiles through LDS (register-staged, double buffered: the
+// next tile's global loads are issued before the current tile is multiplied and written
+// to LDS after it).  Scores are computed TRANSPOSED (S^T = K Q^T, K rows as the MFMA A
+// operand) so that every lane holds 32 scores of ONE query: the row max / row sum are
+// in-register plus one lane^32 exchange, and the bf16 P fragment that feeds P·V is
+// exactly 8 consecutive accumulator registers - no LDS round trip for P.  V arrives
+// transposed (V^T[d][key], produced by the projection GEMM with swapped operand roles),
+// so the P·V A-operand is two ds_read_b64 per MFMA.  Online softmax in fp32 (exp2 domain).
+#include "common.h"
+#include "kernels.h"
+
+#define KROW 72      // K tile row stride in elements (144 B: conflict-free ds_read_b128)
+#define VROW 68      // V^T tile row stride in elements (136 B: conflict-free ds_read_b64)
+#define KT_BYTES (64 * KROW * 2)
+#define VT_BYTES (64 * VROW * 2)
+
+__global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KT_BYTES + VT_BYTES)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  // ---- Q fragment (MFMA B operand): query lr, d = 16*kk + 8*lh .. +8
+  bf16x8 qf[4];
+  {
+    int qrow = q0 + lr; if (qrow >= p.Sq) qrow = p.Sq - 1;
+    const bf16* qp = p.q + ((size_t)b * p.Sq + qrow) * p.ldq + h * 64 + 8 * lh;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
+  }
+
+  // ---- staging assignment: chunk c = t + 256*i -> row c>>3, 16-byte piece c&7
+  const int srow0 = t >> 3, spc = t & 7;
+  const bf16* kbase = p.k + (size_t)b * p.kv_rows * p.ldk + h * 64 + spc * 8;
+  const bf16* vbase = p.vt + (size_t)(h * 64) * p.ldvt + (size_t)b * p.skv_stride + spc * 8;
+  u32x4 kreg[2], vreg[2];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = kv0 + srow0 + 32 * i; if (key >= p.Skv) key = p.Skv - 1;
+      kreg[i] = *(const u32x4*)(kbase + (size_t)key * p.ldk);
+      const int d = srow0 + 32 * i;
+      if (kv0 + spc * 8 < p.Skv) vreg[i] = *(const u32x4*)(vbase + (size_t)d * p.ldvt + kv0);
+      else vreg[i] = (u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+  auto write_tile = [&](int buf) {
+    char* ks = smem + buf * (KT_BYTES + VT_BYTES);
+    char* vs = ks + KT_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = srow0 + 32 * i;
+      *(u32x4*)(ks + r * (KROW * 2) + spc * 16) = kreg[i];
+      u32x2 lo = {vreg[i][0], vreg[i][1]}, hi = {vreg[i][2], vreg[i][3]};
+      *(u32x2*)(vs + r * (VROW * 2) + spc * 16) = lo;
+      *(u32x2*)(vs + r * (VROW * 2) + spc * 16 + 8) = hi;
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (p.Skv + 63) / 64;
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+  for (int it = 0; it < ntiles; ++it) {
+    const int kv0 = it * 64;
+    if (it + 1 < ntiles) load_tile(kv0 + 64);
+    const char* ks = smem + (it & 1) * (KT_BYTES + VT_BYTES);
+    const char* vs = ks + KT_BYTES;
+
+    // ---- S^T = K Q^T : s[kt][r] = score(query lr, key kv0 + 32kt + (r&3) + 8(r>>2) + 4lh)
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 kf = *(const bf16x8*)(ks + (32 * kt + lr) * (KROW * 2) + (2 * kk + lh) * 16);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt], 0, 0, 0);
+      }
+    }
+    // ---- scale to log2 domain, mask the tail, row max
+    float mx = -INFINITY;
+    const bool tail = kv0 + 64 > p.Skv;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[kt][r] * sl2;
+        if (tail) {
+          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= p.Skv) v = -INFINITY;
+        }
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        unsigned int w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p0 = __builtin_amdgcn_exp2f(s[kt][8 * u + 2 * e] - m_new);
+          const float p1 = __builtin_amdgcn_exp2f(s[kt][8 * u + 2 * e + 1] - m_new);
+          psum += p0 + p1;
+          w[e] = pack_bf2(p0, p1);
+        }
+        u32x4 wv = {w[0], w[1], w[2], w[3]};
+        pf[2 * kt + u] = __builtin_bit_cast(bf16x8, wv);
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+
+    // ---- O^T += V^T P^T : k-slot e of step s4 <-> key 16*s4 + 4lh + (e&3) + 8(e>>2)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const char* vp = vs + (32 * dt + lr) * (VROW * 2) + (16 * s4 + 4 * lh) * 2;
+        const u32x2 lo = *(const u32x2*)vp;
+        const u32x2 hi = *(const u32x2*)(vp + 16);
+        const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s4], o[dt], 0, 0, 0);
+      }
+
+    if (it + 1 < ntiles) write_tile((it + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds query lr, d = 32dt + 8g + 4lh + e
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + lr;
+  if (qrow < p.Sq) {
+    bf16* op = p.o + ((size_t)b * p.Sq + qrow) * p.ldo + h * 64 + 4 * lh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 pk = {pack_bf2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv),
+                    pack_bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv)};
+        *(u32x2*)(op + 32 * dt + 8 * g) = pk;
+      }
+  }
+}
+
+int dmx_attention_launch(const AttnArgs& a, hipStream_t stream) {
+  DMX_REQUIRE(a.B > 0 && a.H > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
+  DMX_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.skv_stride % 8 == 0 && a.ldo % 4 == 0,
+              "attention: strides must be multiples of 8 (ldq=%d ldk=%d ldvt=%d skv_stride=%d)", a.ldq, a.ldk, a.ldvt, a.skv_stride);
+  DMX_REQUIRE(a.kv_rows >= a.Skv, "attention: kv_rows=%d < Skv=%d", a.kv_rows, a.Skv);
+  DMX_REQUIRE(a.skv_stride >= (a.Skv + 7) / 8 * 8, "attention: skv_stride=%d < Skv=%d rounded to 8", a.skv_stride, a.Skv);
+  dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
+  hipLaunchKernelGGL(dmx_attn_d64_kernel, grid, dim3(256), 0, stream, a);
+  return dmx_check_launch("dmx_attn_d64_kernel");
+}

@@ -1,0 +1,70 @@
+// Common device/host helpers for the DiffUTE gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define DMX_OK 0
+#define DMX_ERR_ARG (-1)
+#define DMX_ERR_HIP (-2)
+#define DMX_ERR_UNSUPPORTED (-3)
+#define DMX_ERR_WORKSPACE (-4)
+
+void dmx_set_error(const char* fmt, ...);
+int dmx_check_launch(const char* what);
+
+#define DMX_REQUIRE(cond, ...)                \
+  do {                                        \
+    if (!(cond)) {                            \
+      dmx_set_error(__VA_ARGS__);             \
+      return DMX_ERR_ARG;                     \
+    }                                         \
+  } while (0)
+
+#define DMX_HIP(expr)                                                        \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      dmx_set_error("%s failed: %s", #expr, hipGetErrorString(_e));          \
+      return DMX_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)
+
+// round-to-nearest-even fp32 -> bf16 (NaN-safe enough for activations)
+__device__ __forceinline__ unsigned short f2bf_bits(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf_bits2f(unsigned short b) {
+  return __uint_as_float(((unsigned int)b) << 16);
+}
+__device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
+  return (unsigned int)f2bf_bits(lo) | ((unsigned int)f2bf_bits(hi) << 16);
+}
+__device__ __forceinline__ void unpack_bf8(const u32x4 v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack_bf8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -1,0 +1,137 @@
+// Host-side executor infrastructure shared by the UNet and VAE graphs:
+//   ParamTable  - diffusers state-dict key -> packed location in the caller's weights arena
+//   Workspace   - first-fit sub-allocator over the caller's activation workspace; a dry run
+//                 of the same alloc/free sequence gives the exact peak (workspace_bytes query)
+//   Exec        - op wrappers that launch (or, in a dry run, only account for) the kernels
+#pragma once
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "kernels.h"
+
+struct PackRule {
+  enum Kind { COPY_F32, CONV, LINEAR, GEGLU_W, GEGLU_B } kind = COPY_F32;
+  size_t dst = 0;          // byte offset into the arena
+  int rows = 0, cols = 0;  // LINEAR/GEGLU: [rows][cols] -> ld ; CONV: Cout, Cin
+  int ks = 0, ld = 0, koff = 0;
+};
+struct ParamEntry { std::string name; int shape[4]; PackRule rule; };
+
+class ParamTable {
+ public:
+  size_t reserve(size_t bytes) { size_t o = total_; total_ += align_up(bytes, 256); return o; }
+  void add(const std::string& name, std::initializer_list<int> shape, const PackRule& r) {
+    ParamEntry e; e.name = name; int i = 0; for (int k = 0; k < 4; ++k) e.shape[k] = 0;
+    for (int s : shape) e.shape[i++] = s;
+    e.rule = r; index_[name] = (int)entries_.size(); entries_.push_back(e);
+  }
+  // helpers returning the destination offset
+  size_t f32(const std::string& name, int n) {
+    PackRule r; r.kind = PackRule::COPY_F32; r.dst = reserve((size_t)n * 4); r.rows = n; add(name, {n}, r); return r.dst;
+  }
+  void f32_at(const std::string& name, int n, size_t dst) {
+    PackRule r; r.kind = PackRule::COPY_F32; r.dst = dst; r.rows = n; add(name, {n}, r);
+  }
+  size_t linear(const std::string& name, int rows, int cols) {
+    PackRule r; r.kind = PackRule::LINEAR; r.dst = reserve((size_t)rows * cols * 2); r.rows = rows; r.cols = cols; r.ld = cols;
+    add(name, {rows, cols}, r); return r.dst;
+  }
+  void linear_at(const std::string& name, int rows, int cols, size_t dst, int ld) {
+    PackRule r; r.kind = PackRule::LINEAR; r.dst = dst; r.rows = rows; r.cols = cols; r.ld = ld; add(name, {rows, cols}, r);
+  }
+  void conv_at(const std::string& name, int cout, int cin, int ks, size_t dst, int ldk, int koff) {
+    PackRule r; r.kind = PackRule::CONV; r.dst = dst; r.rows = cout; r.cols = cin; r.ks = ks; r.ld = ldk; r.koff = koff;
+    add(name, {cout, cin, ks, ks}, r);
+  }
+  const std::vector<ParamEntry>& entries() const { return entries_; }
+  const ParamEntry* find(const std::string& name) const {
+    auto it = index_.find(name); return it == index_.end() ? nullptr : &entries_[it->second];
+  }
+  size_t total() const { return total_; }
+  int load(char* arena, const char* name, const float* src, hipStream_t stream) const;
+ private:
+  std::vector<ParamEntry> entries_;
+  std::unordered_map<std::string, int> index_;
+  size_t total_ = 0;
+};
+
+class Workspace {
+ public:
+  void reset(void* base, size_t cap, bool dry) {
+    base_ = dry ? (char*)4096 : (char*)base; cap_ = dry ? ((size_t)1 << 46) : cap; dry_ = dry;
+    free_.clear(); live_.clear(); free_[0] = cap_; used_ = 0; peak_ = 0; failed_ = false;
+  }
+  void* alloc(size_t bytes);
+  void release(const void* p);
+  size_t peak() const { return peak_; }
+  bool failed() const { return failed_; }
+ private:
+  char* base_ = nullptr; size_t cap_ = 0; bool dry_ = false;
+  std::map<size_t, size_t> free_;                 // offset -> size
+  std::unordered_map<size_t, size_t> live_;       // offset -> size
+  size_t used_ = 0, peak_ = 0; bool failed_ = false;
+};
+
+struct Tn {                 // NHWC bf16 activation [B*H*W][C] with row stride ld
+  bf16* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0;
+  int rows() const { return B * H * W; }
+};
+
+struct ConvOpts {
+  int ksize = 3, stride = 1, pad = 1, ups = 0;
+  const float* bias = nullptr;
+  const float* rowbias = nullptr; int ldrb = 0;
+  const Tn* res = nullptr;
+  const Tn* sc0 = nullptr; const Tn* sc1 = nullptr;   // fused 1x1 shortcut sources
+  int out_f32 = 0;
+};
+
+class Exec {
+ public:
+  hipStream_t stream = nullptr;
+  bool dry = false;
+  int rc = 0;
+  Workspace ws;
+
+  Tn make(int B, int H, int W, int C) {
+    Tn t; t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
+    t.p = (bf16*)ws.alloc((size_t)B * H * W * C * 2);
+    if (ws.failed() && !rc) { dmx_set_error("workspace too small"); rc = DMX_ERR_WORKSPACE; }
+    return t;
+  }
+  void* raw(size_t bytes) {
+    void* p = ws.alloc(bytes);
+    if (ws.failed() && !rc) { dmx_set_error("workspace too small"); rc = DMX_ERR_WORKSPACE; }
+    return p;
+  }
+  void drop(const Tn& t) { ws.release(t.p); }
+  void drop(const void* p) { ws.release(p); }
+
+  // y = GroupNorm(x0|x1) [SiLU]
+  Tn groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, bool silu);
+  // conv (3x3 / 1x1, optional stride-2, upsample, concat input, fused shortcut/residual/temb)
+  Tn conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpts& o, void* f32_out = nullptr);
+  // y[rows][N] = x[rows][K] W[N][K]^T (+bias)(+res) ; geglu -> N/2 columns
+  Tn linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu);
+  // generic gemm on raw pointers (swapped-role V^T projection etc.)
+  void gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N, int K, const float* bias,
+                void* out, int ldo, int out_f32);
+  Tn layernorm(const Tn& x, const float* gamma, const float* beta, float eps);
+  void attention(const bf16* q, int ldq, const bf16* k, int ldk, int kv_rows, const bf16* vt, int ldvt, int skv_stride,
+                 bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale);
+ private:
+  void run_gemm(GemmArgs& a);
+};
+
+// ResnetBlock2D weights (offsets into the arena) shared by the UNet and VAE graphs
+struct ResW {
+  int cin = 0, cout = 0, temb_off = -1; bool shortcut = false;
+  size_t n1g = 0, n1b = 0, n2g = 0, n2b = 0, w1 = 0, b1 = 0, w2 = 0, b2 = 0, b2raw = 0, bscraw = 0;
+};
+// registers norm1/conv1/norm2/conv2/conv_shortcut keys under prefix p; the 1x1 shortcut is packed
+// as extra K columns of conv2 and its bias is folded into conv2's by resnet_finalize.
+void resnet_build(ParamTable& pt, ResW& r, const std::string& p, int cin, int cout);
+int resnet_finalize(const ResW& r, char* arena, hipStream_t stream);
+Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn* x1, int groups, float eps,
+              const float* tproj, int tproj_total);

@@ -1,0 +1,219 @@
+// Executor infrastructure: error state, parameter packing, workspace allocator, op wrappers.
+#include <stdarg.h>
+#include <stdio.h>
+#include "exec.h"
+
+static thread_local char g_err[512] = "";
+void dmx_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+const char* dmx_get_error() { return g_err; }
+int dmx_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { dmx_set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return DMX_ERR_HIP; }
+  return DMX_OK;
+}
+
+// --------------------------------------------------------------------------- ParamTable
+int ParamTable::load(char* arena, const char* name, const float* src, hipStream_t stream) const {
+  const ParamEntry* e = find(name);
+  DMX_REQUIRE(e != nullptr, "load_param: unknown parameter '%s'", name);
+  DMX_REQUIRE(arena != nullptr, "load_param: arena not bound");
+  DMX_REQUIRE(src != nullptr, "load_param: null source for '%s'", name);
+  const PackRule& r = e->rule;
+  switch (r.kind) {
+    case PackRule::COPY_F32:
+      DMX_HIP(hipMemcpyAsync(arena + r.dst, src, (size_t)r.rows * 4, hipMemcpyDeviceToDevice, stream));
+      return DMX_OK;
+    case PackRule::CONV:
+      return dmx_pack_conv_weight_launch(src, (bf16*)(arena + r.dst), r.rows, r.cols, r.ks, r.ld, r.koff, stream);
+    case PackRule::LINEAR:
+      return dmx_pack_rows_launch(src, (bf16*)(arena + r.dst), r.rows, r.cols, r.ld, 0, stream);
+    case PackRule::GEGLU_W:
+      return dmx_pack_rows_launch(src, (bf16*)(arena + r.dst), r.rows, r.cols, r.ld, 1, stream);
+    case PackRule::GEGLU_B:
+      return dmx_pack_geglu_bias_launch(src, (float*)(arena + r.dst), r.rows, stream);
+  }
+  return DMX_ERR_ARG;
+}
+
+// --------------------------------------------------------------------------- Workspace
+void* Workspace::alloc(size_t bytes) {
+  bytes = align_up(bytes ? bytes : 1, 256);
+  for (auto it = free_.begin(); it != free_.end(); ++it) {
+    if (it->second >= bytes) {
+      const size_t off = it->first, sz = it->second;
+      free_.erase(it);
+      if (sz > bytes) free_[off + bytes] = sz - bytes;
+      live_[off] = bytes;
+      used_ += bytes;
+      if (off + bytes > peak_) peak_ = off + bytes;
+      return base_ + off;
+    }
+  }
+  failed_ = true;
+  return nullptr;
+}
+void Workspace::release(const void* p) {
+  if (!p) return;
+  const size_t off = (size_t)((const char*)p - base_);
+  auto it = live_.find(off);
+  if (it == live_.end()) return;
+  size_t sz = it->second;
+  live_.erase(it);
+  used_ -= sz;
+  size_t o = off;
+  auto nxt = free_.lower_bound(o);
+  if (nxt != free_.end() && o + sz == nxt->first) { sz += nxt->second; nxt = free_.erase(nxt); }
+  if (nxt != free_.begin()) {
+    auto prv = std::prev(nxt);
+    if (prv->first + prv->second == o) { o = prv->first; sz += prv->second; free_.erase(prv); }
+  }
+  free_[o] = sz;
+}
+
+// --------------------------------------------------------------------------- Exec ops
+void Exec::run_gemm(GemmArgs& a) {
+  if (rc) return;
+  const size_t wsb = dmx_gemm_workspace_bytes(a);
+  void* w = wsb ? raw(wsb) : nullptr;
+  if (!dry && !rc) rc = dmx_gemm_launch(a, w, wsb, stream);
+  if (w) ws.release(w);
+}
+
+Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, bool silu) {
+  const int C = x0.C + (x1 ? x1->C : 0);
+  Tn y = make(x0.B, x0.H, x0.W, C);
+  const size_t pb = dmx_gn_workspace_bytes(x0.B, x0.H * x0.W, groups);
+  void* part = raw(pb);
+  if (!dry && !rc) {
+    GroupNormArgs a{};
+    a.x0 = x0.p; a.ldx0 = x0.ld; a.c0 = x0.C;
+    a.x1 = x1 ? x1->p : nullptr; a.ldx1 = x1 ? x1->ld : 0;
+    a.C = C; a.groups = groups; a.B = x0.B; a.HW = x0.H * x0.W;
+    a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu ? 1 : 0;
+    a.y = y.p; a.ldy = y.ld; a.partial = (float*)part;
+    rc = dmx_groupnorm_launch(a, stream);
+  }
+  ws.release(part);
+  return y;
+}
+
+Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpts& o, void* f32_out) {
+  int OH = x0.H, OW = x0.W;
+  if (o.ups) { OH *= 2; OW *= 2; }
+  if (o.stride == 2) { OH /= 2; OW /= 2; }
+  Tn y; y.B = x0.B; y.H = OH; y.W = OW; y.C = Cout; y.ld = Cout;
+  if (!o.out_f32) y = make(x0.B, OH, OW, Cout);
+  GemmArgs a{};
+  a.x0 = x0.p; a.ldx0 = x0.ld; a.cx0 = x0.C;
+  a.x1 = x1 ? x1->p : x0.p; a.ldx1 = x1 ? x1->ld : x0.ld;
+  a.Cin = x0.C + (x1 ? x1->C : 0);
+  a.ksize = o.ksize; a.stride = o.stride; a.pad = o.pad; a.ups = o.ups;
+  a.direct = (o.ksize == 1 && o.stride == 1 && !o.ups) ? 1 : 0;
+  a.IH = x0.H; a.IW = x0.W; a.OH = OH; a.OW = OW;
+  a.Ktaps = o.ksize * o.ksize * a.Cin;
+  a.K = a.Ktaps;
+  if (o.sc0) {
+    a.s0 = o.sc0->p; a.lds0 = o.sc0->ld; a.cs0 = o.sc0->C;
+    a.s1 = o.sc1 ? o.sc1->p : o.sc0->p; a.lds1 = o.sc1 ? o.sc1->ld : o.sc0->ld;
+    a.K += o.sc0->C + (o.sc1 ? o.sc1->C : 0);
+  }
+  a.w = w; a.ldw = a.K;
+  a.M = x0.B * OH * OW; a.N = Cout;
+  a.bias = o.bias; a.rowbias = o.rowbias; a.rows_per_group = OH * OW; a.ldrb = o.ldrb;
+  if (o.res) { a.res = o.res->p; a.ldres = o.res->ld; }
+  a.out = o.out_f32 ? f32_out : (void*)y.p; a.ldo = Cout; a.out_f32 = o.out_f32;
+  run_gemm(a);
+  return y;
+}
+
+Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu) {
+  const int Nout = geglu ? N / 2 : N;
+  Tn y = make(x.B, x.H, x.W, Nout);
+  GemmArgs a{};
+  a.x0 = x.p; a.x1 = x.p; a.ldx0 = x.ld; a.ldx1 = x.ld; a.cx0 = x.C; a.Cin = x.C;
+  a.direct = 1; a.ksize = 1; a.stride = 1; a.IH = a.OH = x.H; a.IW = a.OW = x.W;
+  a.Ktaps = x.C; a.K = x.C;
+  a.w = w; a.ldw = x.C; a.M = x.rows(); a.N = N;
+  a.bias = bias; a.rows_per_group = 1;
+  if (res) { a.res = res->p; a.ldres = res->ld; }
+  a.out = y.p; a.ldo = Nout; a.geglu = geglu ? 1 : 0;
+  run_gemm(a);
+  return y;
+}
+
+void Exec::gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N, int K, const float* bias,
+                    void* out, int ldo, int out_f32) {
+  GemmArgs a{};
+  a.x0 = x; a.x1 = x; a.ldx0 = ldx; a.ldx1 = ldx; a.cx0 = K; a.Cin = K;
+  a.direct = 1; a.ksize = 1; a.stride = 1; a.IH = a.OH = 1; a.IW = a.OW = M;
+  a.Ktaps = K; a.K = K; a.w = w; a.ldw = ldw; a.M = M; a.N = N;
+  a.bias = bias; a.rows_per_group = 1; a.out = out; a.ldo = ldo; a.out_f32 = out_f32;
+  run_gemm(a);
+}
+
+Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps) {
+  Tn y = make(x.B, x.H, x.W, x.C);
+  if (!dry && !rc) rc = dmx_layernorm_launch(x.p, x.ld, y.p, y.ld, gamma, beta, x.rows(), x.C, eps, stream);
+  return y;
+}
+
+void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, int kv_rows, const bf16* vt, int ldvt, int skv_stride,
+                     bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale) {
+  if (dry || rc) return;
+  AttnArgs a{};
+  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.vt = vt; a.ldvt = ldvt; a.skv_stride = skv_stride;
+  a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  rc = dmx_attention_launch(a, stream);
+}
+
+// --------------------------------------------------------------------------- ResnetBlock2D
+void resnet_build(ParamTable& pt, ResW& r, const std::string& p, int cin, int cout) {
+  r.cin = cin; r.cout = cout; r.shortcut = (cin != cout);
+  r.n1g = pt.f32(p + "norm1.weight", cin); r.n1b = pt.f32(p + "norm1.bias", cin);
+  r.w1 = pt.reserve((size_t)cout * 9 * cin * 2);
+  pt.conv_at(p + "conv1.weight", cout, cin, 3, r.w1, 9 * cin, 0);
+  r.b1 = pt.f32(p + "conv1.bias", cout);
+  r.n2g = pt.f32(p + "norm2.weight", cout); r.n2b = pt.f32(p + "norm2.bias", cout);
+  const int k2 = 9 * cout + (r.shortcut ? cin : 0);
+  r.w2 = pt.reserve((size_t)cout * k2 * 2);
+  pt.conv_at(p + "conv2.weight", cout, cout, 3, r.w2, k2, 0);
+  if (r.shortcut) {
+    r.b2raw = pt.f32(p + "conv2.bias", cout);
+    pt.conv_at(p + "conv_shortcut.weight", cout, cin, 1, r.w2, k2, 9 * cout);
+    r.bscraw = pt.f32(p + "conv_shortcut.bias", cout);
+    r.b2 = pt.reserve((size_t)cout * 4);
+  } else {
+    r.b2 = pt.f32(p + "conv2.bias", cout); r.b2raw = r.b2; r.bscraw = 0;
+  }
+}
+
+__global__ void dmx_add_vec_kernel(const float* a, const float* b, float* o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+int resnet_finalize(const ResW& r, char* arena, hipStream_t stream) {
+  if (!r.shortcut) return DMX_OK;
+  hipLaunchKernelGGL(dmx_add_vec_kernel, dim3(cdiv(r.cout, 256)), dim3(256), 0, stream,
+                     (const float*)(arena + r.b2raw), (const float*)(arena + r.bscraw), (float*)(arena + r.b2), r.cout);
+  return dmx_check_launch("dmx_add_vec_kernel");
+}
+
+Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn* x1, int groups, float eps,
+              const float* tproj, int tproj_total) {
+  auto F = [&](size_t off) { return (const float*)(arena + off); };
+  auto H = [&](size_t off) { return (const bf16*)(arena + off); };
+  Tn t1 = ex.groupnorm(x0, x1, F(r.n1g), F(r.n1b), groups, eps, true);
+  ConvOpts o1; o1.bias = F(r.b1);
+  if (r.temb_off >= 0 && tproj) { o1.rowbias = tproj + r.temb_off; o1.ldrb = tproj_total; }
+  Tn t2 = ex.conv(t1, nullptr, H(r.w1), r.cout, o1);
+  ex.drop(t1);
+  Tn t3 = ex.groupnorm(t2, nullptr, F(r.n2g), F(r.n2b), groups, eps, true);
+  ex.drop(t2);
+  ConvOpts o2; o2.bias = F(r.b2);
+  if (r.shortcut) { o2.sc0 = &x0; o2.sc1 = x1; } else { o2.res = &x0; }
+  Tn y = ex.conv(t3, nullptr, H(r.w2), r.cout, o2);
+  ex.drop(t3);
+  return y;
+}

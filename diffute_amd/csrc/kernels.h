@@ -1,0 +1,93 @@
+// Internal (C++) launch interfaces shared by the C-ABI wrappers and the model executors.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------ gemm.hip
+struct GemmArgs {
+  // activation operand (rows m): up to two sources split on the channel axis
+  const bf16* x0; const bf16* x1;
+  int ldx0, ldx1;          // row strides, elements
+  int cx0;                 // channels [0,cx0) of a tap come from x0, [cx0,Cin) from x1
+  int direct;              // 1: row m of X is row m of x0/x1 (linear / 1x1 s1); 0: conv gather
+  int IH, IW, OH, OW;      // source grid (before the optional x2 nearest upsample), output grid
+  int stride, pad, ups, ksize;
+  int Cin;                 // channels per tap
+  int Ktaps;               // ksize*ksize*Cin ; K - Ktaps = shortcut channels
+  const bf16* s0; const bf16* s1; int lds0, lds1, cs0;   // fused 1x1 shortcut segment
+  const bf16* w; int ldw;  // weights [N][K]
+  int M, N, K;
+  const float* bias;       // [N] fp32 or null
+  const float* rowbias;    // [M/rows_per_group][ldrb] fp32 or null (time-embedding projection)
+  int rows_per_group, ldrb;
+  const bf16* res; int ldres;   // residual or null
+  void* out; int ldo; int out_f32; int geglu;
+  float* partial; int splitk, kt_per_split;   // filled by the launcher
+  const bf16* zeros;                           // filled by the launcher
+};
+int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
+size_t dmx_gemm_workspace_bytes(const GemmArgs& a);
+void dmx_gemm_plan(const GemmArgs& a, int* tn, int* splitk, int* ktps);
+int dmx_zero_page(const bf16** out);
+
+// ------------------------------------------------------------------ norm.hip
+struct GroupNormArgs {
+  const bf16* x0; const bf16* x1; int ldx0, ldx1; int c0;   // two-source concat on channels
+  int C, groups; int B, HW;
+  const float* gamma; const float* beta; float eps; int silu;
+  bf16* y; int ldy;
+  float* partial;     // [B][nchunk][groups][2]
+  int nchunk, rows_per_chunk;
+};
+int dmx_groupnorm_chunks(int HW);
+size_t dmx_gn_workspace_bytes(int B, int HW, int groups);
+int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream);
+int dmx_layernorm_launch(const bf16* x, int ldx, bf16* y, int ldy, const float* gamma, const float* beta,
+                         int rows, int C, float eps, hipStream_t stream);
+
+int dmx_softmax_rows_launch(const float* s, int lds_, bf16* p, int ldp, int rows, int n, float scale, hipStream_t stream);
+
+// ------------------------------------------------------------------ attention.hip
+struct AttnArgs {
+  const bf16* q; int ldq;        // row (b*Sq + s), head h at column h*D
+  const bf16* k; int ldk;        // row (b*kv_rows + s)
+  int kv_rows;                   // rows per batch in k (>= Skv; Skv unless padded)
+  const bf16* vt; int ldvt;      // V^T: row (h*D + d), column (b*skv_stride + s)
+  int skv_stride;                // column offset between batches in vt
+  bf16* o; int ldo;
+  int B, H, Sq, Skv;
+  float scale;
+};
+int dmx_attention_launch(const AttnArgs& a, hipStream_t stream);
+
+// ------------------------------------------------------------------ elementwise.hip
+struct Im2colArgs {
+  // sources: up to 3 NCHW fp32 tensors concatenated on channels, or one NHWC bf16 tensor
+  const float* f0; const float* f1; const float* f2; int c0, c1, c2;
+  const bf16* h; int ldh;
+  int C;                    // total channels
+  int B, IH, IW, OH, OW, ksize, stride, pad;
+  bf16* out; int Kpad;      // [B*OH*OW][Kpad], k = tap*C + c, zero padded
+};
+int dmx_im2col_small_launch(const Im2colArgs& a, hipStream_t stream);
+int dmx_nhwc_to_nchw_f32_launch(const float* in, int ldin, float* out, int B, int C, int HW, hipStream_t stream);
+int dmx_nhwc_bf16_to_nchw_f32_launch(const bf16* in, int ldin, float* out, int B, int C, int HW, hipStream_t stream);
+int dmx_nchw_f32_to_nhwc_bf16_launch(const float* in, bf16* out, int ldo, int B, int C, int HW, hipStream_t stream);
+int dmx_cast_f32_to_bf16_launch(const float* in, bf16* out, size_t n, hipStream_t stream);
+int dmx_pack_conv_weight_launch(const float* w, bf16* out, int Cout, int Cin, int ks, int ldk, int koff, hipStream_t stream);
+int dmx_pack_rows_launch(const float* w, bf16* out, int rows, int cols, int ldo, int geglu, hipStream_t stream);
+int dmx_pack_geglu_bias_launch(const float* b, float* out, int n, hipStream_t stream);
+int dmx_cast_pad_rows_launch(const void* in, int in_is_bf16, bf16* out, int B, int S, int Spad, int C, hipStream_t stream);
+
+// ------------------------------------------------------------------ temb.hip
+int dmx_timestep_embedding_launch(const long long* t, int t_count, const float* freq, int B, int dim, float* out, hipStream_t stream);
+int dmx_linear_small_launch(const float* x, int ldx, const bf16* w, int ldw, const float* bias, float* y, int ldy,
+                            int B, int N, int K, int silu_in, hipStream_t stream);
+
+// ------------------------------------------------------------------ sched.hip
+int dmx_sched_ddim_launch(const float* x, const float* eps, const float* noise, float* out, size_t n,
+                          float sqrt_bt, float sqrt_at, float sqrt_ap, float dir_coef, float std, int vpred, hipStream_t stream);
+int dmx_sched_ddpm_launch(const float* x, const float* eps, const float* noise, float* out, size_t n,
+                          float sqrt_bt, float sqrt_at, float c0, float c1, float sigma, int vpred, hipStream_t stream);
+int dmx_add_noise_launch(const float* x0, const float* noise, const float* sa, const float* sb, float* out,
+                         int B, size_t per, int velocity, hipStream_t stream);
+int dmx_gaussian_sample_launch(const float* moments, const float* noise, float* out, int B, int C, int HW, float scale, hipStream_t stream);

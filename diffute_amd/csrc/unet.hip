@@ -1,0 +1,389 @@
+// UNet2DConditionModel executor (SD2-inpainting layout): the graph behind
+// `unet(sample, timestep, encoder_hidden_states).sample` (reference call sites
+// app.ipynb:814, train_diffute_v1.py:913; module structure SURVEY.md Appendix A.1).
+//
+// The graph is walked on the host and every op is one of the hand-written gfx950 kernels.
+// Fusions relative to the eager diffusers graph:
+//   - torch.cat([latents, mask, masked_latents]) + NCHW->NHWC + fp32->bf16 + conv_in im2col: one kernel
+//   - skip-connection torch.cat: never materialised (GroupNorm and the shortcut read two sources)
+//   - conv1 + bias + time-embedding broadcast add: one launch
+//   - conv2 + 1x1 conv_shortcut + residual add: one launch (shortcut appended as extra K)
+//   - nearest x2 upsample: folded into the following conv's gather
+//   - to_q|to_k one GEMM; to_v as a role-swapped GEMM that emits V^T for the attention kernel
+//   - GEGLU: Linear(C,8C) + a*gelu(b) in one launch; every Linear bias / residual in the GEMM epilogue
+//   - all 22 time_emb_proj Linear layers: one GEMV launch
+//   - cross-attention K / V^T of the glyph context computed once per image (set_context)
+#include <math.h>
+#include <memory>
+#include "exec.h"
+#include "../../include/diffute_hip.h"
+
+namespace {
+
+struct XfW {
+  int C = 0, heads = 0, ctx_slot = -1;
+  size_t ng, nb, wpi, bpi, l1g, l1b, l2g, l2b, l3g, l3b;
+  size_t wqk, wv, wo1, bo1, wq2, wk2, wv2, wo2, bo2, wf1, bf1, wf2, bf2, wpo, bpo;
+};
+struct ConvW { size_t w, b; int c; };
+
+}  // namespace
+
+struct dmx_unet {
+  dmx_unet_config cfg;
+  ParamTable pt;
+  char* arena = nullptr;
+  int temb_dim = 0, tproj_total = 0;
+  size_t te_w1, te_b1, te_w2, te_b2, tp_w, tp_b, freq;
+  size_t ci_w, ci_b; int ci_kpad = 0;
+  size_t co_w, co_b, cno_g, cno_b;
+  std::vector<ResW> down_res[4], up_res[4]; std::vector<XfW> down_xf[4], up_xf[4];
+  ConvW down_ds[4], up_us[4];
+  ResW mid_res[2]; XfW mid_xf;
+  std::vector<XfW*> xf_all;          // cross-attention layers in graph order (context cache slots)
+  bool finalized = false;
+
+  template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
+};
+
+namespace {
+
+void build_resnet(dmx_unet* u, ResW& r, const std::string& p, int cin, int cout, bool temb) {
+  resnet_build(u->pt, r, p, cin, cout);
+  if (temb) { r.temb_off = u->tproj_total; u->tproj_total += cout; }   // rows of the batched time_emb_proj matrix
+}
+
+void build_xf(dmx_unet* u, XfW& x, const std::string& p, int C, int heads) {
+  ParamTable& pt = u->pt;
+  const int ctx = u->cfg.cross_attention_dim;
+  x.C = C; x.heads = heads;
+  x.ng = pt.f32(p + "norm.weight", C); x.nb = pt.f32(p + "norm.bias", C);
+  x.wpi = pt.linear(p + "proj_in.weight", C, C); x.bpi = pt.f32(p + "proj_in.bias", C);
+  const std::string t = p + "transformer_blocks.0.";
+  x.l1g = pt.f32(t + "norm1.weight", C); x.l1b = pt.f32(t + "norm1.bias", C);
+  x.wqk = pt.reserve((size_t)2 * C * C * 2);
+  pt.linear_at(t + "attn1.to_q.weight", C, C, x.wqk, C);
+  pt.linear_at(t + "attn1.to_k.weight", C, C, x.wqk + (size_t)C * C * 2, C);
+  x.wv = pt.linear(t + "attn1.to_v.weight", C, C);
+  x.wo1 = pt.linear(t + "attn1.to_out.0.weight", C, C); x.bo1 = pt.f32(t + "attn1.to_out.0.bias", C);
+  x.l2g = pt.f32(t + "norm2.weight", C); x.l2b = pt.f32(t + "norm2.bias", C);
+  x.wq2 = pt.linear(t + "attn2.to_q.weight", C, C);
+  x.wk2 = pt.linear(t + "attn2.to_k.weight", C, ctx);
+  x.wv2 = pt.linear(t + "attn2.to_v.weight", C, ctx);
+  x.wo2 = pt.linear(t + "attn2.to_out.0.weight", C, C); x.bo2 = pt.f32(t + "attn2.to_out.0.bias", C);
+  x.l3g = pt.f32(t + "norm3.weight", C); x.l3b = pt.f32(t + "norm3.bias", C);
+  { PackRule r; r.kind = PackRule::GEGLU_W; r.dst = pt.reserve((size_t)8 * C * C * 2); r.rows = 8 * C; r.cols = C; r.ld = C;
+    pt.add(t + "ff.net.0.proj.weight", {8 * C, C}, r); x.wf1 = r.dst; }
+  { PackRule r; r.kind = PackRule::GEGLU_B; r.dst = pt.reserve((size_t)8 * C * 4); r.rows = 8 * C;
+    pt.add(t + "ff.net.0.proj.bias", {8 * C}, r); x.bf1 = r.dst; }
+  x.wf2 = pt.linear(t + "ff.net.2.weight", C, 4 * C); x.bf2 = pt.f32(t + "ff.net.2.bias", C);
+  x.wpo = pt.linear(p + "proj_out.weight", C, C); x.bpo = pt.f32(p + "proj_out.bias", C);
+}
+
+}  // namespace
+
+extern "C" dmx_unet* dmx_unet_create(const dmx_unet_config* cfg) {
+  if (!cfg) { dmx_set_error("unet_create: null config"); return nullptr; }
+  for (int i = 0; i < 4; ++i) {
+    const int c = cfg->block_out_channels[i];
+    if (c % 64 != 0 || c % cfg->norm_num_groups != 0 || (cfg->heads[i] > 0 && c / cfg->heads[i] != 64)) {
+      dmx_set_error("unet_create: block_out_channels[%d]=%d must be a multiple of 64 with head dim 64", i, c);
+      return nullptr;
+    }
+  }
+  if (cfg->cross_attention_dim % 64 != 0) { dmx_set_error("unet_create: cross_attention_dim must be a multiple of 64"); return nullptr; }
+  auto u = std::make_unique<dmx_unet>();
+  u->cfg = *cfg;
+  ParamTable& pt = u->pt;
+  const int* boc = cfg->block_out_channels; const int L = cfg->layers_per_block;
+  const int temb = boc[0] * 4; u->temb_dim = temb;
+  u->te_w1 = pt.linear("time_embedding.linear_1.weight", temb, boc[0]); u->te_b1 = pt.f32("time_embedding.linear_1.bias", temb);
+  u->te_w2 = pt.linear("time_embedding.linear_2.weight", temb, temb); u->te_b2 = pt.f32("time_embedding.linear_2.bias", temb);
+  u->freq = pt.reserve((size_t)(boc[0] / 2) * 4);
+  u->ci_kpad = (int)align_up((size_t)9 * cfg->in_channels, 64);
+  u->ci_w = pt.reserve((size_t)boc[0] * u->ci_kpad * 2);
+  pt.conv_at("conv_in.weight", boc[0], cfg->in_channels, 3, u->ci_w, u->ci_kpad, 0);
+  u->ci_b = pt.f32("conv_in.bias", boc[0]);
+  std::vector<int> skips; skips.push_back(boc[0]);
+  int cprev = boc[0];
+  for (int i = 0; i < 4; ++i) {
+    const int c = boc[i];
+    u->down_res[i].resize(L); if (cfg->down_has_attn[i]) u->down_xf[i].resize(L);
+    for (int j = 0; j < L; ++j) {
+      const std::string p = "down_blocks." + std::to_string(i);
+      build_resnet(u.get(), u->down_res[i][j], p + ".resnets." + std::to_string(j) + ".", cprev, c, true);
+      if (cfg->down_has_attn[i]) build_xf(u.get(), u->down_xf[i][j], p + ".attentions." + std::to_string(j) + ".", c, cfg->heads[i]);
+      cprev = c; skips.push_back(c);
+    }
+    if (i < 3) {
+      const std::string p = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv.";
+      u->down_ds[i].c = c; u->down_ds[i].w = pt.reserve((size_t)c * 9 * c * 2);
+      pt.conv_at(p + "weight", c, c, 3, u->down_ds[i].w, 9 * c, 0);
+      u->down_ds[i].b = pt.f32(p + "bias", c);
+      skips.push_back(c);
+    }
+  }
+  build_resnet(u.get(), u->mid_res[0], "mid_block.resnets.0.", cprev, cprev, true);
+  build_xf(u.get(), u->mid_xf, "mid_block.attentions.0.", cprev, cfg->heads[3]);
+  build_resnet(u.get(), u->mid_res[1], "mid_block.resnets.1.", cprev, cprev, true);
+  for (int i = 0; i < 4; ++i) {
+    const int c = boc[3 - i];
+    u->up_res[i].resize(L + 1); if (cfg->up_has_attn[i]) u->up_xf[i].resize(L + 1);
+    for (int j = 0; j < L + 1; ++j) {
+      const int cs = skips.back(); skips.pop_back();
+      const std::string p = "up_blocks." + std::to_string(i);
+      build_resnet(u.get(), u->up_res[i][j], p + ".resnets." + std::to_string(j) + ".", cprev + cs, c, true);
+      if (cfg->up_has_attn[i]) build_xf(u.get(), u->up_xf[i][j], p + ".attentions." + std::to_string(j) + ".", c, cfg->heads[3 - i]);
+      cprev = c;
+    }
+    if (i < 3) {
+      const std::string p = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
+      u->up_us[i].c = c; u->up_us[i].w = pt.reserve((size_t)c * 9 * c * 2);
+      pt.conv_at(p + "weight", c, c, 3, u->up_us[i].w, 9 * c, 0);
+      u->up_us[i].b = pt.f32(p + "bias", c);
+    }
+  }
+  u->cno_g = pt.f32("conv_norm_out.weight", boc[0]); u->cno_b = pt.f32("conv_norm_out.bias", boc[0]);
+  u->co_w = pt.reserve((size_t)cfg->out_channels * 9 * boc[0] * 2);
+  pt.conv_at("conv_out.weight", cfg->out_channels, boc[0], 3, u->co_w, 9 * boc[0], 0);
+  u->co_b = pt.f32("conv_out.bias", cfg->out_channels);
+
+  // time_emb_proj of every resnet: rows of one [tproj_total][temb] matrix (+ bias vector)
+  u->tp_w = pt.reserve((size_t)u->tproj_total * temb * 2);
+  u->tp_b = pt.reserve((size_t)u->tproj_total * 4);
+  auto reg_tp = [&](const ResW& r, const std::string& p) {
+    pt.linear_at(p + "time_emb_proj.weight", r.cout, temb, u->tp_w + (size_t)r.temb_off * temb * 2, temb);
+    pt.f32_at(p + "time_emb_proj.bias", r.cout, u->tp_b + (size_t)r.temb_off * 4);
+  };
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < L; ++j) reg_tp(u->down_res[i][j], "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".");
+  reg_tp(u->mid_res[0], "mid_block.resnets.0."); reg_tp(u->mid_res[1], "mid_block.resnets.1.");
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < L + 1; ++j) reg_tp(u->up_res[i][j], "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".");
+
+  // cross-attention context slots in graph order
+  for (int i = 0; i < 4; ++i) for (auto& x : u->down_xf[i]) u->xf_all.push_back(&x);
+  u->xf_all.push_back(&u->mid_xf);
+  for (int i = 0; i < 4; ++i) for (auto& x : u->up_xf[i]) u->xf_all.push_back(&x);
+  for (size_t s = 0; s < u->xf_all.size(); ++s) u->xf_all[s]->ctx_slot = (int)s;
+  return u.release();
+}
+
+extern "C" void dmx_unet_destroy(dmx_unet* u) { delete u; }
+extern "C" int dmx_unet_param_count(const dmx_unet* u) { return u ? (int)u->pt.entries().size() : 0; }
+extern "C" int dmx_unet_param_info(const dmx_unet* u, int index, const char** name, int shape[4]) {
+  DMX_REQUIRE(u && index >= 0 && index < (int)u->pt.entries().size(), "unet_param_info: bad index %d", index);
+  const ParamEntry& e = u->pt.entries()[index];
+  if (name) *name = e.name.c_str();
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = e.shape[k];
+  return DMX_OK;
+}
+extern "C" size_t dmx_unet_arena_bytes(const dmx_unet* u) { return u ? u->pt.total() : 0; }
+extern "C" int dmx_unet_bind_arena(dmx_unet* u, void* arena, size_t bytes) {
+  DMX_REQUIRE(u && arena && bytes >= u->pt.total(), "unet_bind_arena: need %zu bytes", u ? u->pt.total() : (size_t)0);
+  u->arena = (char*)arena; u->finalized = false;
+  DMX_HIP(hipMemset(arena, 0, u->pt.total()));      // zero the K padding of conv_in
+  return DMX_OK;
+}
+extern "C" int dmx_unet_load_param(dmx_unet* u, const char* name, const float* src, dmx_stream_t stream) {
+  DMX_REQUIRE(u != nullptr, "unet_load_param: null handle");
+  u->finalized = false;
+  return u->pt.load(u->arena, name, src, (hipStream_t)stream);
+}
+
+extern "C" int dmx_unet_finalize(dmx_unet* u, const float* h_freq, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->arena, "unet_finalize: arena not bound");
+  DMX_REQUIRE(h_freq != nullptr, "unet_finalize: null frequency table");
+  hipStream_t s = (hipStream_t)stream;
+  DMX_HIP(hipMemcpyAsync(u->arena + u->freq, h_freq, (size_t)(u->cfg.block_out_channels[0] / 2) * 4, hipMemcpyHostToDevice, s));
+  auto fuse = [&](const ResW& r) -> int { return resnet_finalize(r, u->arena, s); };
+  int rc = 0;
+  for (int i = 0; i < 4 && !rc; ++i) { for (auto& r : u->down_res[i]) if (!rc) rc = fuse(r); for (auto& r : u->up_res[i]) if (!rc) rc = fuse(r); }
+  if (!rc) rc = fuse(u->mid_res[0]); if (!rc) rc = fuse(u->mid_res[1]);
+  DMX_HIP(hipStreamSynchronize(s));
+  u->finalized = (rc == 0);
+  return rc;
+}
+
+// ----------------------------------------------------------------------------- context
+static int ctx_pad(int ctx_len) { return (int)align_up((size_t)ctx_len, 64); }
+
+extern "C" size_t dmx_unet_context_bytes(const dmx_unet* u, int B, int ctx_len) {
+  if (!u) return 0;
+  size_t tot = 0;
+  const int sp = ctx_pad(ctx_len);
+  for (const XfW* x : u->xf_all) tot += 2 * align_up((size_t)B * sp * x->C * 2, 256);
+  return tot;
+}
+static void ctx_slot_ptrs(const dmx_unet* u, const void* cache, int B, int ctx_len, int slot, const bf16** k, const bf16** vt) {
+  size_t off = 0; const int sp = ctx_pad(ctx_len);
+  for (int s = 0; s < slot; ++s) off += 2 * align_up((size_t)B * sp * u->xf_all[s]->C * 2, 256);
+  const size_t one = align_up((size_t)B * sp * u->xf_all[slot]->C * 2, 256);
+  *k = (const bf16*)((const char*)cache + off); *vt = (const bf16*)((const char*)cache + off + one);
+}
+
+extern "C" int dmx_unet_set_context(dmx_unet* u, const void* ctx, int ctx_is_bf16, int B, int ctx_len,
+                                    void* cache, size_t cache_bytes, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->finalized, "unet_set_context: weights not finalized");
+  DMX_REQUIRE(ctx && cache && cache_bytes >= dmx_unet_context_bytes(u, B, ctx_len), "unet_set_context: context cache too small");
+  Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
+  const int D = u->cfg.cross_attention_dim, sp = ctx_pad(ctx_len);
+  bf16* cp = (bf16*)ex.raw((size_t)B * sp * D * 2);
+  if (ex.rc) return ex.rc;
+  int rc = dmx_cast_pad_rows_launch(ctx, ctx_is_bf16, cp, B, ctx_len, sp, D, ex.stream);
+  if (rc) return rc;
+  for (const XfW* x : u->xf_all) {
+    const bf16 *k, *vt; ctx_slot_ptrs(u, cache, B, ctx_len, x->ctx_slot, &k, &vt);
+    // K[b*sp + s][C] = ctx W_k^T ; V^T[C][b*sp + s] = W_v ctx^T (role-swapped GEMM)
+    ex.gemm_raw(cp, D, B * sp, u->at<bf16>(x->wk2), D, x->C, D, nullptr, (void*)k, x->C, 0);
+    ex.gemm_raw(u->at<bf16>(x->wv2), D, x->C, cp, D, B * sp, D, nullptr, (void*)vt, B * sp, 0);
+    if (ex.rc) return ex.rc;
+  }
+  return ex.rc;
+}
+
+// ----------------------------------------------------------------------------- forward
+namespace {
+
+struct Fwd {
+  dmx_unet* u; Exec& ex; int B; const float* tproj; const void* cache; int ctx_len;
+
+  Tn resnet(const ResW& r, const Tn& x0, const Tn* x1) {
+    return resnet_run(ex, u->arena, r, x0, x1, u->cfg.norm_num_groups, 1e-5f, tproj, u->tproj_total);
+  }
+
+  Tn xformer(const XfW& w, const Tn& x) {
+    const int G = u->cfg.norm_num_groups, C = w.C, S = x.H * x.W, M = x.rows();
+    Tn t = ex.groupnorm(x, nullptr, u->at<float>(w.ng), u->at<float>(w.nb), G, 1e-6f, false);
+    Tn h = ex.linear(t, u->at<bf16>(w.wpi), C, u->at<float>(w.bpi), nullptr, false);
+    ex.drop(t);
+    // ---- self attention
+    Tn n = ex.layernorm(h, u->at<float>(w.l1g), u->at<float>(w.l1b), 1e-5f);
+    Tn qk = ex.linear(n, u->at<bf16>(w.wqk), 2 * C, nullptr, nullptr, false);
+    bf16* vt = (bf16*)ex.raw((size_t)C * M * 2);
+    ex.gemm_raw(u->at<bf16>(w.wv), C, C, n.p, n.ld, M, C, nullptr, vt, M, 0);
+    ex.drop(n);
+    Tn a = ex.make(x.B, x.H, x.W, C);
+    ex.attention(qk.p, 2 * C, qk.p + C, 2 * C, S, vt, M, S, a.p, C, x.B, w.heads, S, S, 0.125f);
+    ex.drop(qk); ex.drop(vt);
+    Tn h2 = ex.linear(a, u->at<bf16>(w.wo1), C, u->at<float>(w.bo1), &h, false);
+    ex.drop(a); ex.drop(h);
+    // ---- cross attention over the cached glyph-context K / V^T
+    n = ex.layernorm(h2, u->at<float>(w.l2g), u->at<float>(w.l2b), 1e-5f);
+    Tn q = ex.linear(n, u->at<bf16>(w.wq2), C, nullptr, nullptr, false);
+    ex.drop(n);
+    const bf16 *kc = nullptr, *vtc = nullptr; const int sp = ctx_pad(ctx_len);
+    ctx_slot_ptrs(u, cache, x.B, ctx_len, w.ctx_slot, &kc, &vtc);
+    a = ex.make(x.B, x.H, x.W, C);
+    ex.attention(q.p, C, kc, C, sp, vtc, x.B * sp, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
+    ex.drop(q);
+    Tn h3 = ex.linear(a, u->at<bf16>(w.wo2), C, u->at<float>(w.bo2), &h2, false);
+    ex.drop(a); ex.drop(h2);
+    // ---- GEGLU feed-forward
+    n = ex.layernorm(h3, u->at<float>(w.l3g), u->at<float>(w.l3b), 1e-5f);
+    Tn g = ex.linear(n, u->at<bf16>(w.wf1), 8 * C, u->at<float>(w.bf1), nullptr, true);
+    ex.drop(n);
+    Tn h4 = ex.linear(g, u->at<bf16>(w.wf2), C, u->at<float>(w.bf2), &h3, false);
+    ex.drop(g); ex.drop(h3);
+    Tn y = ex.linear(h4, u->at<bf16>(w.wpo), C, u->at<float>(w.bpo), &x, false);
+    ex.drop(h4);
+    return y;
+  }
+};
+
+int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+             const long long* timesteps, int t_count, const void* cache, int ctx_len, float* out, int B, int H, int W) {
+  const dmx_unet_config& cfg = u->cfg;
+  const int* boc = cfg.block_out_channels; const int L = cfg.layers_per_block; const int temb = u->temb_dim;
+  // ---- time embedding (fp32, bf16 weights)
+  float* sinus = (float*)ex.raw((size_t)B * boc[0] * 4);
+  float* e1 = (float*)ex.raw((size_t)B * temb * 4);
+  float* emb = (float*)ex.raw((size_t)B * temb * 4);
+  float* tproj = (float*)ex.raw((size_t)B * u->tproj_total * 4);
+  if (!ex.dry && !ex.rc) {
+    ex.rc = dmx_timestep_embedding_launch(timesteps, t_count, u->at<float>(u->freq), B, boc[0], sinus, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(sinus, boc[0], u->at<bf16>(u->te_w1), boc[0], u->at<float>(u->te_b1), e1, temb, B, temb, boc[0], 0, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(e1, temb, u->at<bf16>(u->te_w2), temb, u->at<float>(u->te_b2), emb, temb, B, temb, temb, 1, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(emb, temb, u->at<bf16>(u->tp_w), temb, u->at<float>(u->tp_b), tproj, u->tproj_total, B, u->tproj_total, temb, 1, ex.stream);
+  }
+  ex.drop(sinus); ex.drop(e1); ex.drop(emb);
+  // ---- conv_in: cat + layout + im2col, then GEMM
+  Tn col = ex.make(B, H, W, u->ci_kpad);
+  if (!ex.dry && !ex.rc) {
+    Im2colArgs a{}; a.f0 = f0; a.c0 = c0; a.f1 = f1; a.c1 = c1; a.f2 = f2; a.c2 = c2; a.C = cfg.in_channels;
+    a.B = B; a.IH = a.OH = H; a.IW = a.OW = W; a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = u->ci_kpad;
+    ex.rc = dmx_im2col_small_launch(a, ex.stream);
+  }
+  Tn h = ex.linear(col, u->at<bf16>(u->ci_w), boc[0], u->at<float>(u->ci_b), nullptr, false);
+  ex.drop(col);
+  Fwd f{u, ex, B, tproj, cache, ctx_len};
+  std::vector<Tn> skips; skips.push_back(h);
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < L; ++j) {
+      Tn y = f.resnet(u->down_res[i][j], h, nullptr);
+      if (cfg.down_has_attn[i]) { Tn z = f.xformer(u->down_xf[i][j], y); ex.drop(y); y = z; }
+      h = y; skips.push_back(h);                      // previous h stays alive as a skip
+    }
+    if (i < 3) {
+      ConvOpts o; o.stride = 2; o.pad = 1; o.bias = u->at<float>(u->down_ds[i].b);
+      h = ex.conv(h, nullptr, u->at<bf16>(u->down_ds[i].w), boc[i], o);
+      skips.push_back(h);
+    }
+  }
+  { Tn y = f.resnet(u->mid_res[0], h, nullptr);          // h is also skips.back(): keep it
+    Tn z = f.xformer(u->mid_xf, y); ex.drop(y);
+    h = f.resnet(u->mid_res[1], z, nullptr); ex.drop(z); }
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < L + 1; ++j) {
+      Tn s = skips.back(); skips.pop_back();
+      Tn y = f.resnet(u->up_res[i][j], h, &s);
+      ex.drop(h); ex.drop(s);
+      if (cfg.up_has_attn[i]) { Tn z = f.xformer(u->up_xf[i][j], y); ex.drop(y); y = z; }
+      h = y;
+    }
+    if (i < 3) {
+      ConvOpts o; o.ups = 1; o.bias = u->at<float>(u->up_us[i].b);
+      Tn y = ex.conv(h, nullptr, u->at<bf16>(u->up_us[i].w), boc[3 - i], o);
+      ex.drop(h); h = y;
+    }
+  }
+  Tn t = ex.groupnorm(h, nullptr, u->at<float>(u->cno_g), u->at<float>(u->cno_b), cfg.norm_num_groups, 1e-5f, true);
+  ex.drop(h);
+  float* eps_nhwc = (float*)ex.raw((size_t)B * H * W * cfg.out_channels * 4);
+  ConvOpts oo; oo.bias = u->at<float>(u->co_b); oo.out_f32 = 1;
+  ex.conv(t, nullptr, u->at<bf16>(u->co_w), cfg.out_channels, oo, eps_nhwc);
+  ex.drop(t);
+  if (!ex.dry && !ex.rc) ex.rc = dmx_nhwc_to_nchw_f32_launch(eps_nhwc, cfg.out_channels, out, B, cfg.out_channels, H * W, ex.stream);
+  ex.drop(eps_nhwc); ex.drop(tproj);
+  return ex.rc;
+}
+
+}  // namespace
+
+extern "C" size_t dmx_unet_workspace_bytes(dmx_unet* u, int B, int H, int W, int ctx_len) {
+  if (!u) return 0;
+  Exec ex; ex.dry = true; ex.ws.reset(nullptr, 0, true);
+  unet_run(u, ex, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, nullptr, ctx_len, nullptr, B, H, W);
+  size_t need = ex.ws.peak();
+  // set_context needs the padded context + split-K scratch
+  Exec e2; e2.dry = true; e2.ws.reset(nullptr, 0, true);
+  const int D = u->cfg.cross_attention_dim, sp = ctx_pad(ctx_len);
+  void* cp = e2.raw((size_t)B * sp * D * 2);
+  for (const XfW* x : u->xf_all) {
+    e2.gemm_raw((const bf16*)cp, D, B * sp, nullptr, D, x->C, D, nullptr, nullptr, x->C, 0);
+    e2.gemm_raw(nullptr, D, x->C, (const bf16*)cp, D, B * sp, D, nullptr, nullptr, B * sp, 0);
+  }
+  if (e2.ws.peak() > need) need = e2.ws.peak();
+  return need + 4096;
+}
+
+extern "C" int dmx_unet_forward(dmx_unet* u, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                                const int64_t* timesteps, int t_count, const void* cache, int ctx_len,
+                                float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->finalized, "unet_forward: weights not finalized (bind_arena, load_param*, finalize)");
+  DMX_REQUIRE(f0 && out && timesteps && cache && workspace, "unet_forward: null argument");
+  DMX_REQUIRE(c0 + c1 + c2 == u->cfg.in_channels, "unet_forward: c0+c1+c2=%d != in_channels=%d", c0 + c1 + c2, u->cfg.in_channels);
+  DMX_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "unet_forward: H=%d W=%d must be positive multiples of 8", H, W);
+  Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
+  return unet_run(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
+}

@@ -1,0 +1,270 @@
+// AutoencoderKL executor (SD VAE layout): the graphs behind `vae.encode(x)` (reference call
+// sites app.ipynb:781,793; train_diffute_v1.py:875,886) and `vae.decode(z).sample`
+// (app.ipynb:819); module structure SURVEY.md Appendix A.2.  Same kernels as the UNet:
+// >95% of the FLOPs are the 3x3 convolutions (implicit GEMM on MFMA), GroupNorm+SiLU is the
+// HBM-bound remainder.  The asymmetric (0,1,0,1) pad of the encoder's stride-2 convs and the
+// decoder's nearest x2 upsamples are folded into the conv gather.  The single-head d=512
+// mid-block attention runs as QK^T GEMM -> fp32 row softmax -> PV GEMM per sample.
+#include <math.h>
+#include <memory>
+#include "exec.h"
+#include "../../include/diffute_hip.h"
+
+namespace {
+struct AttnW { int C = 0; size_t gg, gb, wq, bq, wk, bk, wv, bv, wo, bo; };
+struct CW { size_t w = 0, b = 0; int cin = 0, cout = 0, kpad = 0; };
+}  // namespace
+
+struct dmx_vae {
+  dmx_vae_config cfg;
+  ParamTable pt;
+  char* arena = nullptr;
+  bool finalized = false;
+  // encoder
+  CW e_in, e_out, quant; std::vector<ResW> e_res[4]; CW e_ds[4]; ResW e_mid[2]; AttnW e_attn; size_t e_ng, e_nb;
+  // decoder
+  CW pquant, d_in, d_out; ResW d_mid[2]; AttnW d_attn; std::vector<ResW> d_res[4]; CW d_us[4]; size_t d_ng, d_nb;
+  template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
+};
+
+namespace {
+
+void small_conv(ParamTable& pt, CW& c, const std::string& p, int cout, int cin, int ks) {
+  c.cin = cin; c.cout = cout; c.kpad = (int)align_up((size_t)ks * ks * cin, 64);
+  c.w = pt.reserve((size_t)cout * c.kpad * 2);
+  pt.conv_at(p + "weight", cout, cin, ks, c.w, c.kpad, 0);
+  c.b = pt.f32(p + "bias", cout);
+}
+void big_conv(ParamTable& pt, CW& c, const std::string& p, int cout, int cin) {
+  c.cin = cin; c.cout = cout; c.kpad = 9 * cin;
+  c.w = pt.reserve((size_t)cout * 9 * cin * 2);
+  pt.conv_at(p + "weight", cout, cin, 3, c.w, 9 * cin, 0);
+  c.b = pt.f32(p + "bias", cout);
+}
+void attn_build(ParamTable& pt, AttnW& a, const std::string& p, int C) {
+  a.C = C;
+  a.gg = pt.f32(p + "group_norm.weight", C); a.gb = pt.f32(p + "group_norm.bias", C);
+  a.wq = pt.linear(p + "to_q.weight", C, C); a.bq = pt.f32(p + "to_q.bias", C);
+  a.wk = pt.linear(p + "to_k.weight", C, C); a.bk = pt.f32(p + "to_k.bias", C);
+  a.wv = pt.linear(p + "to_v.weight", C, C); a.bv = pt.f32(p + "to_v.bias", C);
+  a.wo = pt.linear(p + "to_out.0.weight", C, C); a.bo = pt.f32(p + "to_out.0.bias", C);
+}
+
+// single-head attention over H*W tokens with d = C (softmax in fp32)
+Tn attn_run(Exec& ex, const dmx_vae* v, const AttnW& w, const Tn& x, int G) {
+  const int C = w.C, S = x.H * x.W, M = x.rows();
+  Tn n = ex.groupnorm(x, nullptr, v->at<float>(w.gg), v->at<float>(w.gb), G, 1e-6f, false);
+  Tn q = ex.linear(n, v->at<bf16>(w.wq), C, v->at<float>(w.bq), nullptr, false);
+  Tn k = ex.linear(n, v->at<bf16>(w.wk), C, v->at<float>(w.bk), nullptr, false);
+  bf16* vt = (bf16*)ex.raw((size_t)C * M * 2);                     // V^T (bias added after P.V: rows of P sum to 1)
+  ex.gemm_raw(v->at<bf16>(w.wv), C, C, n.p, n.ld, M, C, nullptr, vt, M, 0);
+  ex.drop(n);
+  Tn a = ex.make(x.B, x.H, x.W, C);
+  float* sc = (float*)ex.raw((size_t)S * S * 4);
+  bf16* pr = (bf16*)ex.raw((size_t)S * S * 2);
+  const float scale = 1.0f / sqrtf((float)C);
+  for (int b = 0; b < x.B; ++b) {
+    ex.gemm_raw(q.p + (size_t)b * S * C, C, S, k.p + (size_t)b * S * C, C, S, C, nullptr, sc, S, 1);
+    if (!ex.dry && !ex.rc) ex.rc = dmx_softmax_rows_launch(sc, S, pr, S, S, S, scale, ex.stream);
+    ex.gemm_raw(pr, S, S, vt + (size_t)b * S, M, C, S, v->at<float>(w.bv), a.p + (size_t)b * S * C, C, 0);
+  }
+  ex.drop(sc); ex.drop(pr); ex.drop(q); ex.drop(k); ex.drop(vt);
+  Tn y = ex.linear(a, v->at<bf16>(w.wo), C, v->at<float>(w.bo), &x, false);
+  ex.drop(a);
+  return y;
+}
+
+int vae_encode_run(dmx_vae* v, Exec& ex, const float* x, float* moments, int B, int H, int W) {
+  const dmx_vae_config& c = v->cfg; const int G = c.norm_num_groups; const int L = c.layers_per_block;
+  Tn col = ex.make(B, H, W, v->e_in.kpad);
+  if (!ex.dry && !ex.rc) {
+    Im2colArgs a{}; a.f0 = x; a.c0 = c.in_channels; a.C = c.in_channels; a.B = B; a.IH = a.OH = H; a.IW = a.OW = W;
+    a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = v->e_in.kpad;
+    ex.rc = dmx_im2col_small_launch(a, ex.stream);
+  }
+  Tn h = ex.linear(col, v->at<bf16>(v->e_in.w), c.block_out_channels[0], v->at<float>(v->e_in.b), nullptr, false);
+  ex.drop(col);
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < L; ++j) {
+      Tn y = resnet_run(ex, v->arena, v->e_res[i][j], h, nullptr, G, 1e-6f, nullptr, 0);
+      ex.drop(h); h = y;
+    }
+    if (i < 3) {                       // F.pad(h,(0,1,0,1)) + conv s2 p0: the gather's range check is the pad
+      ConvOpts o; o.stride = 2; o.pad = 0; o.bias = v->at<float>(v->e_ds[i].b);
+      Tn y = ex.conv(h, nullptr, v->at<bf16>(v->e_ds[i].w), c.block_out_channels[i], o);
+      ex.drop(h); h = y;
+    }
+  }
+  { Tn y = resnet_run(ex, v->arena, v->e_mid[0], h, nullptr, G, 1e-6f, nullptr, 0); ex.drop(h);
+    Tn z = attn_run(ex, v, v->e_attn, y, G); ex.drop(y);
+    h = resnet_run(ex, v->arena, v->e_mid[1], z, nullptr, G, 1e-6f, nullptr, 0); ex.drop(z); }
+  Tn t = ex.groupnorm(h, nullptr, v->at<float>(v->e_ng), v->at<float>(v->e_nb), G, 1e-6f, true);
+  ex.drop(h);
+  ConvOpts oo; oo.bias = v->at<float>(v->e_out.b);
+  Tn m8 = ex.conv(t, nullptr, v->at<bf16>(v->e_out.w), 2 * c.latent_channels, oo);   // [M][8] bf16
+  ex.drop(t);
+  // quant_conv 1x1 (8 -> 8): pad K to 64 and reuse the GEMM; fp32 out, then NCHW
+  Tn qc = ex.make(B, m8.H, m8.W, v->quant.kpad);
+  if (!ex.dry && !ex.rc) {
+    Im2colArgs a{}; a.h = m8.p; a.ldh = m8.ld; a.C = m8.C; a.B = B; a.IH = a.OH = m8.H; a.IW = a.OW = m8.W;
+    a.ksize = 1; a.stride = 1; a.pad = 0; a.out = qc.p; a.Kpad = v->quant.kpad;
+    ex.rc = dmx_im2col_small_launch(a, ex.stream);
+  }
+  const int Mo = B * m8.H * m8.W, C2 = 2 * c.latent_channels;
+  float* mo = (float*)ex.raw((size_t)Mo * C2 * 4);
+  ex.gemm_raw(qc.p, qc.ld, Mo, v->at<bf16>(v->quant.w), v->quant.kpad, C2, v->quant.kpad, v->at<float>(v->quant.b), mo, C2, 1);
+  if (!ex.dry && !ex.rc) ex.rc = dmx_nhwc_to_nchw_f32_launch(mo, C2, moments, B, C2, m8.H * m8.W, ex.stream);
+  ex.drop(qc); ex.drop(m8); ex.drop(mo);
+  return ex.rc;
+}
+
+int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, int h0, int w0) {
+  const dmx_vae_config& c = v->cfg; const int G = c.norm_num_groups; const int L = c.layers_per_block;
+  const int lc = c.latent_channels;
+  // post_quant_conv 1x1 on the NCHW fp32 latents
+  Tn pc = ex.make(B, h0, w0, v->pquant.kpad);
+  if (!ex.dry && !ex.rc) {
+    Im2colArgs a{}; a.f0 = z; a.c0 = lc; a.C = lc; a.B = B; a.IH = a.OH = h0; a.IW = a.OW = w0;
+    a.ksize = 1; a.stride = 1; a.pad = 0; a.out = pc.p; a.Kpad = v->pquant.kpad;
+    ex.rc = dmx_im2col_small_launch(a, ex.stream);
+  }
+  Tn z2 = ex.make(B, h0, w0, lc);
+  ex.gemm_raw(pc.p, pc.ld, B * h0 * w0, v->at<bf16>(v->pquant.w), v->pquant.kpad, lc, v->pquant.kpad, v->at<float>(v->pquant.b), z2.p, lc, 0);
+  ex.drop(pc);
+  Tn col = ex.make(B, h0, w0, v->d_in.kpad);
+  if (!ex.dry && !ex.rc) {
+    Im2colArgs a{}; a.h = z2.p; a.ldh = z2.ld; a.C = lc; a.B = B; a.IH = a.OH = h0; a.IW = a.OW = w0;
+    a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = v->d_in.kpad;
+    ex.rc = dmx_im2col_small_launch(a, ex.stream);
+  }
+  ex.drop(z2);
+  Tn h = ex.linear(col, v->at<bf16>(v->d_in.w), c.block_out_channels[3], v->at<float>(v->d_in.b), nullptr, false);
+  ex.drop(col);
+  { Tn y = resnet_run(ex, v->arena, v->d_mid[0], h, nullptr, G, 1e-6f, nullptr, 0); ex.drop(h);
+    Tn zz = attn_run(ex, v, v->d_attn, y, G); ex.drop(y);
+    h = resnet_run(ex, v->arena, v->d_mid[1], zz, nullptr, G, 1e-6f, nullptr, 0); ex.drop(zz); }
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < L + 1; ++j) {
+      Tn y = resnet_run(ex, v->arena, v->d_res[i][j], h, nullptr, G, 1e-6f, nullptr, 0);
+      ex.drop(h); h = y;
+    }
+    if (i < 3) {
+      ConvOpts o; o.ups = 1; o.bias = v->at<float>(v->d_us[i].b);
+      Tn y = ex.conv(h, nullptr, v->at<bf16>(v->d_us[i].w), c.block_out_channels[3 - i], o);
+      ex.drop(h); h = y;
+    }
+  }
+  Tn t = ex.groupnorm(h, nullptr, v->at<float>(v->d_ng), v->at<float>(v->d_nb), G, 1e-6f, true);
+  ex.drop(h);
+  const int Mo = B * t.H * t.W;
+  float* im = (float*)ex.raw((size_t)Mo * c.out_channels * 4);
+  ConvOpts oo; oo.bias = v->at<float>(v->d_out.b); oo.out_f32 = 1;
+  ex.conv(t, nullptr, v->at<bf16>(v->d_out.w), c.out_channels, oo, im);
+  if (!ex.dry && !ex.rc) ex.rc = dmx_nhwc_to_nchw_f32_launch(im, c.out_channels, image, B, c.out_channels, t.H * t.W, ex.stream);
+  ex.drop(t); ex.drop(im);
+  return ex.rc;
+}
+
+}  // namespace
+
+extern "C" dmx_vae* dmx_vae_create(const dmx_vae_config* cfg) {
+  if (!cfg) { dmx_set_error("vae_create: null config"); return nullptr; }
+  for (int i = 0; i < 4; ++i)
+    if (cfg->block_out_channels[i] % 64 != 0) { dmx_set_error("vae_create: block_out_channels must be multiples of 64"); return nullptr; }
+  auto v = std::make_unique<dmx_vae>();
+  v->cfg = *cfg;
+  ParamTable& pt = v->pt;
+  const int* boc = cfg->block_out_channels; const int L = cfg->layers_per_block; const int lc = cfg->latent_channels;
+  const std::string e = "encoder.", d = "decoder.";
+  small_conv(pt, v->e_in, e + "conv_in.", boc[0], cfg->in_channels, 3);
+  int cprev = boc[0];
+  for (int i = 0; i < 4; ++i) {
+    v->e_res[i].resize(L);
+    for (int j = 0; j < L; ++j) {
+      resnet_build(pt, v->e_res[i][j], e + "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", cprev, boc[i]);
+      cprev = boc[i];
+    }
+    if (i < 3) big_conv(pt, v->e_ds[i], e + "down_blocks." + std::to_string(i) + ".downsamplers.0.conv.", boc[i], boc[i]);
+  }
+  resnet_build(pt, v->e_mid[0], e + "mid_block.resnets.0.", cprev, cprev);
+  attn_build(pt, v->e_attn, e + "mid_block.attentions.0.", cprev);
+  resnet_build(pt, v->e_mid[1], e + "mid_block.resnets.1.", cprev, cprev);
+  v->e_ng = pt.f32(e + "conv_norm_out.weight", cprev); v->e_nb = pt.f32(e + "conv_norm_out.bias", cprev);
+  big_conv(pt, v->e_out, e + "conv_out.", 2 * lc, cprev);
+  small_conv(pt, v->quant, "quant_conv.", 2 * lc, 2 * lc, 1);
+  small_conv(pt, v->pquant, "post_quant_conv.", lc, lc, 1);
+  cprev = boc[3];
+  small_conv(pt, v->d_in, d + "conv_in.", cprev, lc, 3);
+  resnet_build(pt, v->d_mid[0], d + "mid_block.resnets.0.", cprev, cprev);
+  attn_build(pt, v->d_attn, d + "mid_block.attentions.0.", cprev);
+  resnet_build(pt, v->d_mid[1], d + "mid_block.resnets.1.", cprev, cprev);
+  for (int i = 0; i < 4; ++i) {
+    const int c = boc[3 - i];
+    v->d_res[i].resize(L + 1);
+    for (int j = 0; j < L + 1; ++j) {
+      resnet_build(pt, v->d_res[i][j], d + "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", cprev, c);
+      cprev = c;
+    }
+    if (i < 3) big_conv(pt, v->d_us[i], d + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.", c, c);
+  }
+  v->d_ng = pt.f32(d + "conv_norm_out.weight", cprev); v->d_nb = pt.f32(d + "conv_norm_out.bias", cprev);
+  big_conv(pt, v->d_out, d + "conv_out.", cfg->out_channels, cprev);
+  return v.release();
+}
+
+extern "C" void dmx_vae_destroy(dmx_vae* v) { delete v; }
+extern "C" int dmx_vae_param_count(const dmx_vae* v) { return v ? (int)v->pt.entries().size() : 0; }
+extern "C" int dmx_vae_param_info(const dmx_vae* v, int index, const char** name, int shape[4]) {
+  DMX_REQUIRE(v && index >= 0 && index < (int)v->pt.entries().size(), "vae_param_info: bad index %d", index);
+  const ParamEntry& e = v->pt.entries()[index];
+  if (name) *name = e.name.c_str();
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = e.shape[k];
+  return DMX_OK;
+}
+extern "C" size_t dmx_vae_arena_bytes(const dmx_vae* v) { return v ? v->pt.total() : 0; }
+extern "C" int dmx_vae_bind_arena(dmx_vae* v, void* arena, size_t bytes) {
+  DMX_REQUIRE(v && arena && bytes >= v->pt.total(), "vae_bind_arena: need %zu bytes", v ? v->pt.total() : (size_t)0);
+  v->arena = (char*)arena; v->finalized = false;
+  DMX_HIP(hipMemset(arena, 0, v->pt.total()));
+  return DMX_OK;
+}
+extern "C" int dmx_vae_load_param(dmx_vae* v, const char* name, const float* src, dmx_stream_t stream) {
+  DMX_REQUIRE(v != nullptr, "vae_load_param: null handle");
+  v->finalized = false;
+  return v->pt.load(v->arena, name, src, (hipStream_t)stream);
+}
+extern "C" int dmx_vae_finalize(dmx_vae* v, dmx_stream_t stream) {
+  DMX_REQUIRE(v && v->arena, "vae_finalize: arena not bound");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = 0;
+  for (int i = 0; i < 4 && !rc; ++i) {
+    for (auto& r : v->e_res[i]) if (!rc) rc = resnet_finalize(r, v->arena, s);
+    for (auto& r : v->d_res[i]) if (!rc) rc = resnet_finalize(r, v->arena, s);
+  }
+  for (int k = 0; k < 2 && !rc; ++k) { rc = resnet_finalize(v->e_mid[k], v->arena, s); if (!rc) rc = resnet_finalize(v->d_mid[k], v->arena, s); }
+  DMX_HIP(hipStreamSynchronize(s));
+  v->finalized = (rc == 0);
+  return rc;
+}
+extern "C" size_t dmx_vae_workspace_bytes(dmx_vae* v, int B, int H, int W, int decode) {
+  if (!v) return 0;
+  Exec ex; ex.dry = true; ex.ws.reset(nullptr, 0, true);
+  if (decode) vae_decode_run(v, ex, nullptr, nullptr, B, H, W); else vae_encode_run(v, ex, nullptr, nullptr, B, H, W);
+  return ex.ws.peak() + 4096;
+}
+extern "C" int dmx_vae_encode(dmx_vae* v, const float* x, float* moments, int B, int H, int W,
+                              void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(v && v->finalized, "vae_encode: weights not finalized");
+  DMX_REQUIRE(x && moments && workspace, "vae_encode: null argument");
+  DMX_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0 && H > 0 && W > 0, "vae_encode: H=%d W=%d must be positive multiples of 8", H, W);
+  Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
+  return vae_encode_run(v, ex, x, moments, B, H, W);
+}
+extern "C" int dmx_vae_decode(dmx_vae* v, const float* z, float* image, int B, int h, int w,
+                              void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(v && v->finalized, "vae_decode: weights not finalized");
+  DMX_REQUIRE(z && image && workspace, "vae_decode: null argument");
+  DMX_REQUIRE(B > 0 && h > 0 && w > 0, "vae_decode: empty problem");
+  Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
+  return vae_decode_run(v, ex, z, image, B, h, w);
+}

@@ -1,0 +1,408 @@
+"""Host-side mirror of the diffusers classes the reference drives.
+
+`UNet2DConditionModel` and `AutoencoderKL` keep the call surface train_diffute_v1.py / app.ipynb
+use - `unet(sample, timestep, encoder_hidden_states).sample`, `vae.encode(x).latent_dist.sample()`,
+`vae.decode(z).sample`, `vae(x)["sample"]`, `.config`, `.parameters()`, `state_dict()` with
+diffusers keys, `from_pretrained / save_pretrained` - while every FLOP runs in the gfx950 C-ABI
+library (diffute_amd/lib/libdiffute_hip.so).  torch is plumbing only: it owns device memory and
+the stream.  There is no CPU or eager fallback.
+"""
+import ctypes
+import json
+import math
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import _cabi
+from .init import init_param
+
+SD2_INPAINT_UNET_CONFIG = dict(
+    in_channels=9, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+    attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024, norm_num_groups=32,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    use_linear_projection=True, flip_sin_to_cos=True, freq_shift=0, norm_eps=1e-5, act_fn="silu",
+    sample_size=64)
+
+SD_VAE_CONFIG = dict(
+    in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
+    layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215, act_fn="silu", sample_size=512)
+
+
+class _Config(SimpleNamespace):
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def to_dict(self):
+        return {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self).items()}
+
+
+class UNet2DConditionOutput(SimpleNamespace):
+    """`.sample` (train_diffute_v1.py:913, app.ipynb:814)."""
+
+
+class DecoderOutput(SimpleNamespace):
+    """`.sample` (app.ipynb:819)."""
+
+
+class DiagonalGaussianDistribution:
+    """`vae.encode(x).latent_dist` (app.ipynb:781,793): sample() / mode() run dmx_gaussian_sample."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters                     # moments NCHW fp32 [B, 2C, h, w]
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+
+    def _run(self, noise):
+        lib = _cabi.lib()
+        B, C2, h, w = self.parameters.shape
+        out = torch.empty(B, C2 // 2, h, w, dtype=torch.float32, device=self.parameters.device)
+        _cabi.check(lib.dmx_gaussian_sample(_cabi.ptr(self.parameters), _cabi.ptr(noise), _cabi.ptr(out),
+                                            B, C2 // 2, h * w, 1.0, _cabi.current_stream()), "gaussian_sample")
+        return out
+
+    def sample(self, generator=None, noise=None):
+        if noise is None:
+            B, C2, h, w = self.parameters.shape
+            noise = torch.randn(B, C2 // 2, h, w, generator=generator, device=self.parameters.device, dtype=torch.float32)
+        return self._run(noise.to(torch.float32).contiguous())
+
+    def mode(self):
+        return self._run(None)
+
+
+class AutoencoderKLOutput(SimpleNamespace):
+    """`.latent_dist`."""
+
+
+class _Node(nn.Module):
+    """Plain container; children / parameters are attached by dotted state-dict key."""
+
+
+def _attach(root: nn.Module, key: str, param: nn.Parameter):
+    parts = key.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+class _HipModel(nn.Module):
+    """Shared plumbing: parameter tree from the C library's table, packed-weights arena, workspace."""
+    _kind = None         # "unet" | "vae"
+
+    def _setup(self, handle, seed, device):
+        self._h = handle
+        self._dtype = torch.float32
+        self._arena = None
+        self._packed_sig = None
+        self._ws = None
+        lib = _cabi.lib()
+        n = getattr(lib, f"dmx_{self._kind}_param_count")(self._h)
+        self._keys = []
+        name = ctypes.c_char_p()
+        shape = (ctypes.c_int * 4)()
+        for i in range(n):
+            _cabi.check(getattr(lib, f"dmx_{self._kind}_param_info")(self._h, i, ctypes.byref(name), ctypes.byref(shape)), "param_info")
+            key = name.value.decode()
+            shp = tuple(int(s) for s in shape if s > 0)
+            self._keys.append(key)
+            _attach(self, key, nn.Parameter(init_param(key, shp, seed=seed, device=device), requires_grad=True))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                getattr(_cabi.lib(), f"dmx_{self._kind}_destroy")(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- reference-visible knobs that are no-ops here
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        """train_diffute_v1.py:657 - attention is always the fused flash-style HIP kernel."""
+
+    def enable_gradient_checkpointing(self):
+        """train_diffute_v1.py:696 - unnecessary with 288 GB of HBM; accepted for compatibility."""
+
+    def register_to_config(self, **kw):
+        for k, v in kw.items():
+            setattr(self.config, k, v)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def to(self, *args, **kwargs):
+        """`.to(device, dtype=weight_dtype)` (train_diffute_v1.py:796): device moves are honoured; the
+        dtype is recorded as the I/O dtype only - master parameters stay fp32, compute is bf16 MFMA
+        with fp32 accumulation whatever the requested low-precision dtype."""
+        dtype = kwargs.pop("dtype", None)
+        args = list(args)
+        for a in list(args):
+            if isinstance(a, torch.dtype):
+                dtype = a; args.remove(a)
+        if dtype is not None:
+            self._dtype = dtype
+        if args or kwargs:
+            super().to(*args, **kwargs)
+            self._packed_sig = None
+        return self
+
+    # ---- packed weights
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _ensure_packed(self):
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("diffute_amd: model parameters must be on the GPU (call .cuda()); there is no CPU path")
+        sig = self._signature()
+        if self._packed_sig == sig and self._arena is not None:
+            return
+        lib = _cabi.lib()
+        k = self._kind
+        nbytes = getattr(lib, f"dmx_{k}_arena_bytes")(self._h)
+        if self._arena is None or self._arena.device != dev:
+            self._arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        _cabi.check(getattr(lib, f"dmx_{k}_bind_arena")(self._h, _cabi.ptr(self._arena), nbytes), "bind_arena")
+        st = _cabi.current_stream()
+        sd = dict(self.named_parameters())
+        for key in self._keys:
+            src = sd[key].detach().to(torch.float32).contiguous()
+            _cabi.check(getattr(lib, f"dmx_{k}_load_param")(self._h, key.encode(), _cabi.ptr(src), st), f"load_param({key})")
+        self._finalize(st)
+        self._packed_sig = sig
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---- (de)serialisation in the diffusers directory layout (train_diffute_v1.py:664-690)
+    def save_pretrained(self, save_directory):
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(dict(self.config.to_dict(), _class_name=type(self).__name__), f, indent=2)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(save_directory, "diffusion_pytorch_model.safetensors"))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, revision=None, **kw):
+        d = pretrained_model_name_or_path if subfolder is None else os.path.join(pretrained_model_name_or_path, subfolder)
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = json.load(f)
+        cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+        model = cls(**cfg)
+        st = os.path.join(d, "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(d, "diffusion_pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict(cls._convert_legacy_keys(sd))
+        return model
+
+    @staticmethod
+    def _convert_legacy_keys(sd):
+        return sd
+
+
+class UNet2DConditionModel(_HipModel):
+    """SD2-inpainting UNet (reference: train_diffute_v1.py:633-635, app.ipynb:551-553)."""
+    _kind = "unet"
+
+    def __init__(self, seed=1234, device="cpu", **config):
+        super().__init__()
+        cfg = dict(SD2_INPAINT_UNET_CONFIG); cfg.update(config)
+        for k in ("block_out_channels", "attention_head_dim", "down_block_types", "up_block_types"):
+            cfg[k] = tuple(cfg[k])
+        if isinstance(cfg["attention_head_dim"], int):
+            cfg["attention_head_dim"] = (cfg["attention_head_dim"],) * 4
+        self.config = _Config(**cfg)
+        if len(cfg["block_out_channels"]) != 4:
+            raise ValueError("UNet2DConditionModel: exactly 4 resolution levels are supported")
+        c = _cabi.UNetConfig()
+        c.in_channels = cfg["in_channels"]; c.out_channels = cfg["out_channels"]
+        c.layers_per_block = cfg["layers_per_block"]; c.cross_attention_dim = cfg["cross_attention_dim"]
+        c.norm_num_groups = cfg["norm_num_groups"]
+        for i in range(4):
+            c.block_out_channels[i] = cfg["block_out_channels"][i]
+            c.heads[i] = cfg["attention_head_dim"][i]
+            c.down_has_attn[i] = int(cfg["down_block_types"][i].startswith("CrossAttn"))
+            c.up_has_attn[i] = int(cfg["up_block_types"][i].startswith("CrossAttn"))
+        h = _cabi.lib().dmx_unet_create(ctypes.byref(c))
+        if not h:
+            raise ValueError("UNet2DConditionModel: " + _cabi.lib().dmx_last_error().decode())
+        self._ctx_cache = None
+        self._ctx_key = None
+        self._setup(h, seed, device)
+
+    def _finalize(self, st):
+        half = self.config.block_out_channels[0] // 2
+        # diffusers get_timestep_embedding: exp(-ln(10000) * arange(half) / (half - freq_shift))
+        exponent = -math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32)
+        freq = torch.exp(exponent / (half - self.config.freq_shift)).contiguous()
+        self._freq_host = freq
+        _cabi.check(_cabi.lib().dmx_unet_finalize(self._h, ctypes.c_void_p(freq.data_ptr()), st), "unet_finalize")
+        self._ctx_key = None
+
+    # ---- glyph-context K/V cache (constant across denoise steps, app.ipynb:776,814)
+    def set_context(self, encoder_hidden_states):
+        self._ensure_packed()
+        ctx = encoder_hidden_states
+        _cabi.require_cuda(ctx)
+        if ctx.dtype not in (torch.float32, torch.bfloat16):
+            ctx = ctx.to(torch.float32)
+        ctx = ctx.contiguous()
+        B, S, D = ctx.shape
+        if D != self.config.cross_attention_dim:
+            raise ValueError(f"encoder_hidden_states last dim {D} != cross_attention_dim {self.config.cross_attention_dim}")
+        lib = _cabi.lib()
+        nb = lib.dmx_unet_context_bytes(self._h, B, S)
+        if self._ctx_cache is None or self._ctx_cache.numel() < nb or self._ctx_cache.device != ctx.device:
+            self._ctx_cache = torch.empty(nb, dtype=torch.uint8, device=ctx.device)
+        wsb = lib.dmx_unet_workspace_bytes(self._h, B, 8, 8, S)
+        ws = self._workspace(wsb)
+        _cabi.check(lib.dmx_unet_set_context(self._h, _cabi.ptr(ctx), int(ctx.dtype == torch.bfloat16), B, S,
+                                             _cabi.ptr(self._ctx_cache), self._ctx_cache.numel(),
+                                             _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_set_context")
+        self._ctx_key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
+                         encoder_hidden_states.dtype)
+        self._ctx_shape = (B, S)
+
+    def forward_parts(self, parts, timesteps_dev, out=None):
+        """Hot-loop entry: `parts` = list of (NCHW fp32 cuda tensor) whose channels sum to in_channels
+        (fuses the torch.cat of app.ipynb:811); timesteps_dev = int64 cuda tensor [1] or [B];
+        context must have been set with set_context()."""
+        lib = _cabi.lib()
+        x0 = parts[0]
+        B, _, H, W = x0.shape
+        if self._ctx_key is None or self._ctx_shape[0] != B:
+            raise RuntimeError("UNet2DConditionModel: set_context() must be called with a batch-matching context first")
+        ps = [(p, p.shape[1]) for p in parts] + [(None, 0)] * (3 - len(parts))
+        if out is None:
+            out = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=x0.device)
+        wsb = getattr(self, "_ws_need", None)
+        key = (B, H, W, self._ctx_shape[1])
+        if wsb is None or wsb[0] != key:
+            self._ws_need = wsb = (key, lib.dmx_unet_workspace_bytes(self._h, B, H, W, self._ctx_shape[1]))
+        ws = self._workspace(wsb[1])
+        _cabi.check(lib.dmx_unet_forward(self._h, _cabi.ptr(ps[0][0]), ps[0][1], _cabi.ptr(ps[1][0]), ps[1][1],
+                                         _cabi.ptr(ps[2][0]), ps[2][1], _cabi.ptr(timesteps_dev), timesteps_dev.numel(),
+                                         _cabi.ptr(self._ctx_cache), self._ctx_shape[1], _cabi.ptr(out), B, H, W,
+                                         _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_forward")
+        return out
+
+    def forward(self, sample, timestep, encoder_hidden_states, return_dict=True, **unused):
+        """unet(sample[B,9,h,w], timestep (int / 0-d / [B] tensor), encoder_hidden_states[B,S,1024])."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "diffute_amd: the HIP UNet is forward-only in this build (no backward kernels yet); "
+                "call it under torch.no_grad() / after requires_grad_(False)")
+        _cabi.require_cuda(sample, encoder_hidden_states)
+        self._ensure_packed()
+        key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
+               encoder_hidden_states.dtype)
+        if key != self._ctx_key:
+            self.set_context(encoder_hidden_states)
+        B = sample.shape[0]
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([int(timestep)], dtype=torch.int64)
+        t = timestep.reshape(-1).to(device=sample.device, dtype=torch.int64)
+        if t.numel() not in (1, B):
+            raise ValueError(f"timestep must have 1 or {B} elements, got {t.numel()}")
+        x = sample.to(torch.float32).contiguous()
+        out = self.forward_parts([x], t)
+        if self._dtype != torch.float32 and sample.dtype != torch.float32:
+            out = out.to(sample.dtype)
+        return UNet2DConditionOutput(sample=out) if return_dict else (out,)
+
+
+class AutoencoderKL(_HipModel):
+    """SD VAE (reference: train_diffute_v1.py:632, app.ipynb:550, train_vae.py:516)."""
+    _kind = "vae"
+
+    def __init__(self, seed=4321, device="cpu", **config):
+        super().__init__()
+        cfg = dict(SD_VAE_CONFIG); cfg.update(config)
+        cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
+        self.config = _Config(**cfg)
+        c = _cabi.VAEConfig()
+        c.in_channels = cfg["in_channels"]; c.out_channels = cfg["out_channels"]; c.latent_channels = cfg["latent_channels"]
+        c.layers_per_block = cfg["layers_per_block"]; c.norm_num_groups = cfg["norm_num_groups"]
+        for i in range(4):
+            c.block_out_channels[i] = cfg["block_out_channels"][i]
+        h = _cabi.lib().dmx_vae_create(ctypes.byref(c))
+        if not h:
+            raise ValueError("AutoencoderKL: " + _cabi.lib().dmx_last_error().decode())
+        self._setup(h, seed, device)
+
+    def _finalize(self, st):
+        _cabi.check(_cabi.lib().dmx_vae_finalize(self._h, st), "vae_finalize")
+
+    @staticmethod
+    def _convert_legacy_keys(sd):
+        """Old SD VAE checkpoints name the mid-block attention query/key/value/proj_attn."""
+        ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+        out = OrderedDict()
+        for k, v in sd.items():
+            parts = k.split(".")
+            if "attentions" in parts and len(parts) >= 2 and parts[-2] in ren:
+                parts[-2] = ren[parts[-2]]
+                k = ".".join(parts)
+                if v.ndim == 4:
+                    v = v[:, :, 0, 0]
+            out[k] = v
+        return out
+
+    def _no_grad_check(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("diffute_amd: the HIP VAE is forward-only in this build; use torch.no_grad() / requires_grad_(False)")
+
+    def encode(self, x, return_dict=True):
+        self._no_grad_check()
+        _cabi.require_cuda(x)
+        self._ensure_packed()
+        lib = _cabi.lib()
+        x = x.to(torch.float32).contiguous()
+        B, C, H, W = x.shape
+        f = 2 ** (len(self.config.block_out_channels) - 1)
+        moments = torch.empty(B, 2 * self.config.latent_channels, H // f, W // f, dtype=torch.float32, device=x.device)
+        ws = self._workspace(lib.dmx_vae_workspace_bytes(self._h, B, H, W, 0))
+        _cabi.check(lib.dmx_vae_encode(self._h, _cabi.ptr(x), _cabi.ptr(moments), B, H, W, _cabi.ptr(ws), ws.numel(),
+                                       _cabi.current_stream()), "vae_encode")
+        dist = DiagonalGaussianDistribution(moments)
+        return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
+
+    def decode(self, z, return_dict=True):
+        self._no_grad_check()
+        _cabi.require_cuda(z)
+        self._ensure_packed()
+        lib = _cabi.lib()
+        z = z.to(torch.float32).contiguous()
+        B, C, h, w = z.shape
+        f = 2 ** (len(self.config.block_out_channels) - 1)
+        img = torch.empty(B, self.config.out_channels, h * f, w * f, dtype=torch.float32, device=z.device)
+        ws = self._workspace(lib.dmx_vae_workspace_bytes(self._h, B, h, w, 1))
+        _cabi.check(lib.dmx_vae_decode(self._h, _cabi.ptr(z), _cabi.ptr(img), B, h, w, _cabi.ptr(ws), ws.numel(),
+                                       _cabi.current_stream()), "vae_decode")
+        return DecoderOutput(sample=img) if return_dict else (img,)
+
+    def forward(self, sample, sample_posterior=False, return_dict=True, generator=None):
+        """`vae(x)["sample"]` (train_vae.py:721-722): decode(encode(x).latent_dist.mode())."""
+        post = self.encode(sample).latent_dist
+        z = post.sample(generator=generator) if sample_posterior else post.mode()
+        dec = self.decode(z).sample
+        return {"sample": dec} if return_dict else (dec,)

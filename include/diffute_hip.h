@@ -1,0 +1,204 @@
+/*
+ * diffute_hip.h - C-ABI of the MI355X-native (gfx950) DiffUTE hot path.
+ *
+ * The reference (chenhaoxing/DiffUTE) has no FFI of its own: its hot path is reached
+ * through three Python classes of the un-vendored `diffusers` library.  Each entry point
+ * below names the reference call site (file:line under /root/reference) whose arithmetic
+ * it replaces; INTEGRATION.md shows the Python-side binding (ctypes) a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it is named
+ *     `h_...` or is a `const char*` / descriptor struct (host memory);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - activations between kernels are NHWC ("pixel-major") bf16; model inputs / outputs at
+ *     the Python boundary stay NCHW fp32 exactly as the reference passes them
+ *     (app.ipynb:762, train_diffute_v1.py:731), converted inside the library;
+ *   - functions return 0 on success, a negative DMX_ERR_* code otherwise; the message of
+ *     the last failure on the calling thread is `dmx_last_error()`;
+ *   - the library never allocates model memory: weights arena, context cache and workspace
+ *     are caller-provided (sizes from the *_bytes queries).  The only internal allocation
+ *     is one 4 KiB zero page used for convolution padding.
+ */
+#ifndef DIFFUTE_HIP_H
+#define DIFFUTE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMX_OK 0
+#define DMX_ERR_ARG (-1)
+#define DMX_ERR_HIP (-2)
+#define DMX_ERR_UNSUPPORTED (-3)
+#define DMX_ERR_WORKSPACE (-4)
+
+typedef void* dmx_stream_t;
+typedef struct dmx_unet dmx_unet;
+typedef struct dmx_vae dmx_vae;
+
+int dmx_version(void);
+const char* dmx_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Operator level.  Used by the parity tests and by the executors.
+ * ---------------------------------------------------------------------------------- */
+
+/* K1/K1s/K2/K7/K8/K10: fused implicit-GEMM convolution / linear layer.
+ * Replaces torch conv2d / linear / F.interpolate(nearest x2) / torch.cat(dim=1) inside
+ * diffusers ResnetBlock2D, Downsample2D, Upsample2D, Attention and FeedForward, reached from
+ * unet(...) app.ipynb:814, train_diffute_v1.py:913 and vae.encode/decode app.ipynb:793,819. */
+typedef struct dmx_gemm_desc {
+  const void* x0; const void* x1;   /* bf16 activations; x1 = second channel range or NULL   */
+  int ldx0, ldx1, cx0;              /* row strides (elements); channels taken from x0        */
+  int direct;                       /* 1: X row m = activation row m (linear / 1x1 stride 1) */
+  int IH, IW, OH, OW;               /* source grid (before x2 upsample) and output grid      */
+  int stride, pad, ups, ksize;      /* ksize 1 or 3; pad = top/left pad; ups = nearest x2    */
+  int Cin;                          /* channels per tap (cx0 + channels of x1)               */
+  int Ktaps;                        /* ksize*ksize*Cin                                       */
+  const void* s0; const void* s1;   /* optional fused 1x1 shortcut sources (K - Ktaps chans) */
+  int lds0, lds1, cs0;
+  const void* w; int ldw;           /* bf16 weights [N][K], K = (tap, channel) contiguous    */
+  int M, N, K;
+  const float* bias;                /* [N] or NULL                                           */
+  const float* rowbias;             /* [M/rows_per_group][ldrb] or NULL (time embedding)     */
+  int rows_per_group, ldrb;
+  const void* res; int ldres;       /* bf16 residual or NULL                                 */
+  void* out; int ldo; int out_f32;  /* bf16 (default) or fp32 output                         */
+  int geglu;                        /* 1: weights/bias GEGLU-packed, out[m][j] = a*gelu(b)   */
+} dmx_gemm_desc;
+size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d);
+int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
+/* K3: GroupNorm (+SiLU) over NHWC bf16; optional virtual channel concat of (x0 | x1).
+ * Replaces torch.nn.GroupNorm + SiLU in ResnetBlock2D / Transformer2DModel / VAE blocks. */
+size_t dmx_groupnorm_workspace_bytes(int B, int HW, int groups);
+int dmx_groupnorm(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
+                  int B, int HW, const float* gamma, const float* beta, float eps, int silu,
+                  void* y, int ldy, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
+/* K4: LayerNorm over the channel axis of [rows][C] bf16 (BasicTransformerBlock norm1/2/3). */
+int dmx_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                  int rows, int C, float eps, dmx_stream_t stream);
+
+/* K5/K6: fused attention core softmax(Q K^T * scale) V, head dim 64, no mask.
+ * q: row (b*Sq+s), head h at column 64h.  k: row (b*kv_rows+s).  vt: V transposed,
+ * row (64h+d), column (b*skv_stride+s); columns [Skv, round_up(Skv,8)) must be finite.
+ * Replaces diffusers Attention (optionally xformers, train_diffute_v1.py:648-659). */
+int dmx_attention_fwd(const void* q, int ldq, const void* k, int ldk, int kv_rows,
+                      const void* vt, int ldvt, int skv_stride, void* o, int ldo,
+                      int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream);
+
+/* K9: sinusoidal timestep embedding (flip_sin_to_cos) and the small-M fp32 linear used by the
+ * time-embedding MLP.  t: int64 [t_count] (t_count 1 or B); freq: fp32 [dim/2] table. */
+int dmx_timestep_embedding(const int64_t* t, int t_count, const float* freq, int B, int dim, float* out, dmx_stream_t stream);
+int dmx_linear_small(const float* x, int ldx, const void* w_bf16, int ldw, const float* bias, float* y, int ldy,
+                     int B, int N, int K, int silu_in, dmx_stream_t stream);
+
+/* small-channel im2col (conv_in 9->320, VAE 3->128 / 4->512, quant convs): NCHW fp32 sources
+ * (f0|f1|f2 concatenated on channels = torch.cat([latents, mask, masked_latents], 1),
+ * app.ipynb:811) or one NHWC bf16 source -> bf16 [B*OH*OW][Kpad]. */
+int dmx_im2col_small(const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                     const void* h_nhwc, int ldh, int C, int B, int IH, int IW, int OH, int OW,
+                     int ksize, int stride, int pad, void* out, int Kpad, dmx_stream_t stream);
+
+/* weight packing: fp32 torch layouts -> bf16 GEMM rows */
+int dmx_pack_conv_weight(const float* w, void* out, int Cout, int Cin, int ksize, int ldk, int koff, dmx_stream_t stream);
+int dmx_pack_linear_weight(const float* w, void* out, int rows, int cols, int ldo, int geglu, dmx_stream_t stream);
+int dmx_pack_geglu_bias(const float* b, float* out, int n, dmx_stream_t stream);
+
+/* layout helpers */
+int dmx_cast_f32_to_bf16(const float* in, void* out, size_t n, dmx_stream_t stream);
+int dmx_nhwc_bf16_to_nchw_f32(const void* in, int ldin, float* out, int B, int C, int HW, dmx_stream_t stream);
+int dmx_nhwc_f32_to_nchw_f32(const float* in, int ldin, float* out, int B, int C, int HW, dmx_stream_t stream);
+int dmx_nchw_f32_to_nhwc_bf16(const float* in, void* out, int ldo, int B, int C, int HW, dmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Scheduler.  Scalar coefficients are computed by the host-side
+ * scheduler classes; these are the elementwise updates over [B,4,h,w] fp32 latents.
+ * ---------------------------------------------------------------------------------- */
+/* DDIMScheduler.step(...).prev_sample  (north_star; same call shape as app.ipynb:816) */
+int dmx_sched_step_ddim(const float* sample, const float* model_output, const float* noise, float* prev_sample, size_t n,
+                        float sqrt_beta_prod_t, float sqrt_alpha_prod_t, float sqrt_alpha_prod_prev,
+                        float dir_coef, float std_dev, int v_prediction, dmx_stream_t stream);
+/* DDPMScheduler.step(...).prev_sample  (app.ipynb:816); noise = NULL when t == 0 */
+int dmx_sched_step_ddpm(const float* sample, const float* model_output, const float* noise, float* prev_sample, size_t n,
+                        float sqrt_beta_prod_t, float sqrt_alpha_prod_t, float coef_x0, float coef_xt,
+                        float sigma, int v_prediction, dmx_stream_t stream);
+/* scheduler.add_noise / get_velocity (train_diffute_v1.py:897,907): per-sample coefficients */
+int dmx_sched_add_noise(const float* x0, const float* noise, const float* sqrt_alpha_prod, const float* sqrt_one_minus,
+                        float* out, int B, size_t per_sample, dmx_stream_t stream);
+int dmx_sched_get_velocity(const float* x0, const float* noise, const float* sqrt_alpha_prod, const float* sqrt_one_minus,
+                           float* out, int B, size_t per_sample, dmx_stream_t stream);
+/* latent_dist.sample() * scaling_factor (app.ipynb:793-794; train_diffute_v1.py:875-876);
+ * noise = NULL gives latent_dist.mode() (train_vae.py:721). moments NCHW fp32 [B][2C][HW]. */
+int dmx_gaussian_sample(const float* moments, const float* noise, float* out, int B, int C, int HW, float scale, dmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whole-model executors.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dmx_unet_config {
+  int in_channels, out_channels;
+  int block_out_channels[4];
+  int layers_per_block;
+  int heads[4];                 /* diffusers `attention_head_dim` (= head counts)            */
+  int cross_attention_dim;
+  int norm_num_groups;
+  int down_has_attn[4], up_has_attn[4];
+} dmx_unet_config;
+
+/* UNet2DConditionModel  (from_pretrained: train_diffute_v1.py:633-635, app.ipynb:551-553) */
+dmx_unet* dmx_unet_create(const dmx_unet_config* cfg);
+void dmx_unet_destroy(dmx_unet* u);
+int dmx_unet_param_count(const dmx_unet* u);
+/* name = diffusers state-dict key; shape up to 4 dims (unused = 0) */
+int dmx_unet_param_info(const dmx_unet* u, int index, const char** name, int shape[4]);
+size_t dmx_unet_arena_bytes(const dmx_unet* u);
+int dmx_unet_bind_arena(dmx_unet* u, void* arena, size_t bytes);
+int dmx_unet_load_param(dmx_unet* u, const char* name, const float* src_f32, dmx_stream_t stream);
+int dmx_unet_finalize(dmx_unet* u, const float* h_freq_table, dmx_stream_t stream);
+size_t dmx_unet_context_bytes(const dmx_unet* u, int B, int ctx_len);
+size_t dmx_unet_workspace_bytes(dmx_unet* u, int B, int H, int W, int ctx_len);
+/* cross-attention K / V^T of the glyph context, constant across denoise steps (app.ipynb:776,814) */
+int dmx_unet_set_context(dmx_unet* u, const void* ctx, int ctx_is_bf16, int B, int ctx_len,
+                         void* context_cache, size_t context_bytes, void* workspace, size_t workspace_bytes,
+                         dmx_stream_t stream);
+/* unet(sample, timestep, encoder_hidden_states).sample  (app.ipynb:814, train_diffute_v1.py:913).
+ * The 9-channel sample is given as up to three NCHW fp32 tensors (c0+c1+c2 = in_channels):
+ * pass the concatenated tensor as f0 with c0 = 9, or latents/mask/masked latents separately
+ * (fuses torch.cat of app.ipynb:811).  timesteps: device int64 [t_count], t_count 1 or B.
+ * out: NCHW fp32 [B][out_channels][H][W]. */
+int dmx_unet_forward(dmx_unet* u, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                     const int64_t* timesteps, int t_count, const void* context_cache, int ctx_len,
+                     float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
+typedef struct dmx_vae_config {
+  int in_channels, out_channels, latent_channels;
+  int block_out_channels[4];
+  int layers_per_block;
+  int norm_num_groups;
+} dmx_vae_config;
+
+/* AutoencoderKL (from_pretrained: train_diffute_v1.py:632, app.ipynb:550, train_vae.py:516) */
+dmx_vae* dmx_vae_create(const dmx_vae_config* cfg);
+void dmx_vae_destroy(dmx_vae* v);
+int dmx_vae_param_count(const dmx_vae* v);
+int dmx_vae_param_info(const dmx_vae* v, int index, const char** name, int shape[4]);
+size_t dmx_vae_arena_bytes(const dmx_vae* v);
+int dmx_vae_bind_arena(dmx_vae* v, void* arena, size_t bytes);
+int dmx_vae_load_param(dmx_vae* v, const char* name, const float* src_f32, dmx_stream_t stream);
+int dmx_vae_finalize(dmx_vae* v, dmx_stream_t stream);
+size_t dmx_vae_workspace_bytes(dmx_vae* v, int B, int H, int W, int decode);
+/* vae.encode(x) -> moments NCHW fp32 [B][2*latent][H/8][W/8]  (app.ipynb:781,793) */
+int dmx_vae_encode(dmx_vae* v, const float* x, float* moments, int B, int H, int W,
+                   void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+/* vae.decode(z).sample: z NCHW fp32 [B][latent][h][w] -> image [B][3][8h][8w]  (app.ipynb:819) */
+int dmx_vae_decode(dmx_vae* v, const float* z, float* image, int B, int h, int w,
+                   void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFUTE_HIP_H */

@@ -1,0 +1,64 @@
+"""Oracle: the denoise loop and the training-step forward that drive the models.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+  * denoise()      restates app.ipynb:796-816 (no CFG, one UNet call per step,
+                   9-channel cat([latents, mask, masked_latents]) input).
+  * mask_to_latent restates F.interpolate(mask, size=(h/8, w/8)) default nearest
+                   (app.ipynb:787-791, train_diffute_v1.py:880-884): src = floor(dst*8).
+  * train_forward  restates train_diffute_v1.py:875-918 with every random draw injected.
+"""
+import numpy as np
+import torch
+
+from . import schedulers as S
+from .unet import unet_forward
+from .vae import vae_encode_moments, gaussian_sample
+
+
+def mask_to_latent(mask, factor=8):
+    """mask [B,1,H,W] -> [B,1,H/f,W/f] nearest: out[y,x] = in[floor(y*f), floor(x*f)]."""
+    return mask[:, :, ::factor, ::factor].to(torch.float32).contiguous()
+
+
+@torch.no_grad()
+def denoise(P, cfg, latents, mask, masked_latents, ctx, steps, scheduler="ddim",
+            noise=None, emulate_bf16=False, ac=None, N=1000, trace=None):
+    """Returns final latents [B,4,h,w] fp32.  noise: [steps,B,4,h,w] for DDPM (injected
+    in place of the device RNG draw inside DDPMScheduler.step, app.ipynb:816)."""
+    if ac is None:
+        ac = S.make_tables(N)[2]
+    ts = S.timesteps_ddim(steps, N) if scheduler == "ddim" else S.timesteps_ddpm(steps, N)
+    x = latents.to(torch.float32).clone()          # init_noise_sigma == 1.0 (app.ipynb:800)
+    for i, t in enumerate(ts):
+        inp = torch.cat([x, mask.to(torch.float32), masked_latents.to(torch.float32)], dim=1)
+        eps = unet_forward(P, cfg, inp, torch.tensor(int(t)), ctx, emulate_bf16=emulate_bf16)
+        if scheduler == "ddim":
+            xn = S.ddim_step(ac, eps.numpy(), int(t), x.numpy(), steps, N)
+        else:
+            nz = None if noise is None else noise[i].numpy()
+            xn = S.ddpm_step(ac, eps.numpy(), int(t), x.numpy(), steps, N, noise=nz)
+        x = torch.from_numpy(xn)
+        if trace is not None:
+            trace.append((int(t), eps.clone(), x.clone()))
+    return x
+
+
+@torch.no_grad()
+def train_forward(Pu, ucfg, Pv, vcfg, pixel_values, masked_images, masks, ctx, timesteps,
+                  noise, enc_noise, enc_noise_masked, ac=None, prediction_type="epsilon"):
+    """Loss of one training step (train_diffute_v1.py:875-918), all randomness injected."""
+    if ac is None:
+        ac = S.make_tables()[2]
+    sf = vcfg["scaling_factor"]
+    lat = gaussian_sample(vae_encode_moments(Pv, vcfg, pixel_values), enc_noise) * sf
+    m = mask_to_latent(masks, 2 ** (len(vcfg["block_out_channels"]) - 1))
+    mlat = gaussian_sample(vae_encode_moments(Pv, vcfg, masked_images), enc_noise_masked) * sf
+    noisy = torch.from_numpy(S.add_noise(ac, lat.numpy(), noise.numpy(), timesteps.numpy()))
+    if prediction_type == "epsilon":
+        target = noise
+    elif prediction_type == "v_prediction":
+        target = torch.from_numpy(S.get_velocity(ac, lat.numpy(), noise.numpy(), timesteps.numpy()))
+    else:
+        raise ValueError(f"Unknown prediction type {prediction_type}")
+    pred = unet_forward(Pu, ucfg, torch.cat([noisy, m, mlat], dim=1), timesteps, ctx)
+    return torch.mean((pred.float() - target.float()) ** 2), pred
