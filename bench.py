@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json metric: 512x512 50-step denoise images/sec (whole job), MI355X.
+
+One "step" = one pass of the hot path over one batch: the full 50-step DDIM denoise loop
+(app.ipynb:796-816: per step cat([latents, mask, masked_latents]) -> UNet -> scheduler.step) for a
+batch of 4 synthetic 512x512 masked-text crops (latents 4x64x64, glyph context [4,577,1024]) with
+random-init SD2-inpainting-shaped weights, bf16 MFMA compute, inputs resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+N>1: launched by torch.distributed.run, one rank per GPU; images are independent so the batch is
+replicated per rank (weak scaling, no data-path collective); RCCL is used only for the barrier and
+the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PROF_CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other"]
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512 px)")
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import diffute_amd as D
+    from diffute_amd import _cabi
+    from diffute_amd.flops import context_kv_flops, unet_flops
+    from diffute_amd.synthetic import synth_inputs
+
+    B, hw, T = args.batch, args.latent, args.denoise_steps
+    unet = D.UNet2DConditionModel(device=dev).requires_grad_(False)
+    sched = D.DDIMScheduler()
+    lat, mask, mlat, ctx = synth_inputs(B, hw, hw, 577, 1024, seed=100 * rank, device=dev)
+    unet._ensure_packed()
+
+    def one_pass():
+        return D.denoise(unet, sched, lat, mask, mlat, ctx, T)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = one_pass()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all(), "non-finite latents"
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    loop_flops = T * unet_flops(unet.config, B, hw, hw, 577, True) + context_kv_flops(unet.config, B, 577)
+    result = {
+        "metric": "512x512 50-step denoise images/sec", "value": round(value, 3), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SD2-inpaint UNet {T}-step DDIM denoise loop, {hw * 8}x{hw * 8} px, batch {B} per GPU, "
+                               "glyph context [B,577,1024], ctx K/V cached per image (BASELINE configs[1]); "
+                               "VAE encode/decode not in the timed region",
+                   "global_batch": world * B, "denoise_steps": T, "parallelism": f"replicas x{world} (no collective)",
+                   "weights": "random-init SD2-inpainting shapes (865,925,124 params), bf16 packed"},
+        "loop_tflops_per_gpu": round(loop_flops * args.steps / elapsed / 1e12, 2),
+        "loop_mfma_frac": round(loop_flops * args.steps / elapsed / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+    }
+
+    if rank == 0 and not args.no_profile:
+        # ---- roofline leg: one more pass with every launch bracketed by hipEvents on its stream
+        lib = _cabi.lib()
+        torch.cuda.synchronize(dev)
+        lib.dmx_profile_begin()
+        one_pass()
+        buf = (ctypes.c_double * (4 * len(PROF_CLASSES)))()
+        _cabi.check(lib.dmx_profile_end(buf, len(buf)), "profile_end")
+        classes = {}
+        for i, name in enumerate(PROF_CLASSES):
+            n, ms, fl, by = buf[4 * i:4 * i + 4]
+            if n > 0:
+                classes[name] = {"launches": int(n), "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / n, 2),
+                                 "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if fl > 0 and ms > 0 else None,
+                                 "gbps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+        dom = max((k for k in classes if k.startswith("gemm")), key=lambda k: classes[k]["total_ms"])
+        n, ms, fl, by = buf[4 * PROF_CLASSES.index(dom):4 * PROF_CLASSES.index(dom) + 4]
+        ach = fl / (ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                              "kernel": "dmx_gemm_kernel<%d>" % (2 if dom == "gemm_128x128" else 1),
+                              "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
+                              "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+                              "note": "hipEvent-bracketed launches over one 50-step pass; traffic (PMC) in profiles/"}
+        result["kernel_classes"] = classes
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the torch-CPU fp32 oracle (a port; the reference itself cannot be imported)
+        from oracle import unet as OU
+        torch.set_num_threads(os.cpu_count())
+        P = {k: v.detach().cpu() for k, v in unet.state_dict().items()}
+        l1, m1, ml1, c1 = [x[:1].cpu() for x in (lat, mask, mlat, ctx)]
+        inp = torch.cat([l1, m1, ml1], 1)
+        tt = torch.tensor(981)
+        OU.unet_forward(P, OU.SD2_INPAINT_UNET, inp[:, :, :16, :16], tt, c1)        # warm-up (small)
+        c0 = time.perf_counter()
+        eps_cpu = OU.unet_forward(P, OU.SD2_INPAINT_UNET, inp, tt, c1)
+        t_fwd = time.perf_counter() - c0
+        unet.set_context(ctx[:1].contiguous())
+        eps_gpu = unet.forward_parts([lat[:1].contiguous(), mask[:1].contiguous(), mlat[:1].contiguous()],
+                                     torch.tensor([981], device=dev))
+        rel = float((eps_gpu.cpu() - eps_cpu).norm() / eps_cpu.norm())
+        result["cpu_baseline"] = {"value": round(1.0 / (T * t_fwd), 5), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                                  "sample": f"1 UNet forward (B=1, {hw * 8} px, fp32 torch-CPU oracle, {os.cpu_count()} threads) = "
+                                            f"{t_fwd:.2f} s, x{T} steps extrapolated linearly",
+                                  "gpu_vs_cpu_eps_rel_l2": round(rel, 5)}
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

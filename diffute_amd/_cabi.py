@@ -71,6 +71,8 @@ _PROTOS = {
     "dmx_unet_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dmx_unet_set_context": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_size_t, _P, c_size_t, _P]),
     "dmx_unet_forward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_profile_begin": (c_int, []),
+    "dmx_profile_end": (c_int, [POINTER(ctypes.c_double), c_int]),
     "dmx_vae_create": (_P, [POINTER(VAEConfig)]),
     "dmx_vae_destroy": (None, [_P]),
     "dmx_vae_param_count": (c_int, [_P]),

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "exec.h"
+#include <vector>
 
 static thread_local char g_err[512] = "";
 void dmx_set_error(const char* fmt, ...) {
@@ -11,6 +12,40 @@ const char* dmx_get_error() { return g_err; }
 int dmx_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dmx_set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return DMX_ERR_HIP; }
+  return DMX_OK;
+}
+
+// --------------------------------------------------------------------------- profiler
+namespace {
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}
+ProfScope::ProfScope(ProfClass c, hipStream_t s, double flops, double bytes) {
+  if (!g_prof_on) return;
+  ProfRec r; r.cls = c; r.flops = flops; r.bytes = bytes;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, s);
+  slot = (int)g_prof.size(); g_prof.push_back(r);
+  stream_ = s;
+}
+ProfScope::~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream_); }
+
+extern "C" int dmx_profile_begin(void) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear(); g_prof_on = true; return DMX_OK;
+}
+// out[cls*4 + {0,1,2,3}] = launches, total ms, algorithmic flops, algorithmic bytes ; cls in ProfClass order
+extern "C" int dmx_profile_end(double* out, int n_out) {
+  g_prof_on = false;
+  DMX_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < n_out; ++i) out[i] = 0.0;
+  for (auto& r : g_prof) {
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, r.a, r.b);
+    if (r.cls * 4 + 3 < n_out) { out[r.cls * 4] += 1; out[r.cls * 4 + 1] += ms; out[r.cls * 4 + 2] += r.flops; out[r.cls * 4 + 3] += r.bytes; }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
   return DMX_OK;
 }
 
@@ -93,6 +128,7 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
     a.C = C; a.groups = groups; a.B = x0.B; a.HW = x0.H * x0.W;
     a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu ? 1 : 0;
     a.y = y.p; a.ldy = y.ld; a.partial = (float*)part;
+    ProfScope ps(PROF_GNORM, stream, 0.0, 6.0 * (double)x0.rows() * C);     // read x twice (stats, apply) + write y, bf16
     rc = dmx_groupnorm_launch(a, stream);
   }
   ws.release(part);
@@ -155,7 +191,10 @@ void Exec::gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N
 
 Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps) {
   Tn y = make(x.B, x.H, x.W, x.C);
-  if (!dry && !rc) rc = dmx_layernorm_launch(x.p, x.ld, y.p, y.ld, gamma, beta, x.rows(), x.C, eps, stream);
+  if (!dry && !rc) {
+    ProfScope ps(PROF_LNORM, stream, 0.0, 4.0 * (double)x.rows() * x.C);
+    rc = dmx_layernorm_launch(x.p, x.ld, y.p, y.ld, gamma, beta, x.rows(), x.C, eps, stream);
+  }
   return y;
 }
 
@@ -165,6 +204,7 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, int kv_rows
   AttnArgs a{};
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.vt = vt; a.ldvt = ldvt; a.skv_stride = skv_stride;
   a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv));
   rc = dmx_attention_launch(a, stream);
 }
 

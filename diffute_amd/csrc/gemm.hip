@@ -394,11 +394,16 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   const int bn = 64 * tn;
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, bn), sk, 1);
   const size_t lds = 2 * (size_t)(BM * BK * 2 + bn * BK * 2);
+  // algorithmic work of this launch: 2*M*N*K flops; bytes = activations read once + weights + output
+  const double flops = 2.0 * a.M * (double)a.N * a.K;
+  const double bytes = 2.0 * ((double)a.M * (a.K / (a.direct ? 1 : (a.ksize * a.ksize))) + (double)a.N * a.K + (double)a.M * (a.geglu ? a.N / 2 : a.N));
   if (tn == 2) {
+    ProfScope ps(PROF_GEMM128, stream, flops, bytes);
     static bool attr2 = false;
     if (!attr2) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
     hipLaunchKernelGGL(dmx_gemm_kernel<2>, grid, dim3(256), lds, stream, a);
   } else {
+    ProfScope ps(PROF_GEMM64, stream, flops, bytes);
     static bool attr1 = false;
     if (!attr1) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
     hipLaunchKernelGGL(dmx_gemm_kernel<1>, grid, dim3(256), lds, stream, a);
@@ -409,6 +414,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     const size_t total4 = (size_t)a.M * a.N / 4;
     int blocks = (int)((total4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
+    ProfScope ps(PROF_SPLITK, stream, 0.0, 4.0 * sk * (double)a.M * a.N);
     hipLaunchKernelGGL(dmx_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
     rc = dmx_check_launch("dmx_splitk_reduce_kernel");
   }

@@ -1,0 +1,174 @@
+"""Operator-level Python wrappers over the C-ABI (include/diffute_hip.h).
+
+Activations are NHWC bf16 torch tensors [B,H,W,C] (last dim contiguous; a row stride larger than C is
+allowed, e.g. a channel slice of a wider tensor).  These wrappers exist for the parity tests and for
+users who want single kernels; the model executors call the same kernels from C++.
+"""
+import ctypes
+
+import torch
+
+from . import _cabi
+from ._cabi import GemmDesc, check, current_stream, lib, ptr
+
+
+def _ld(x):
+    assert x.stride(-1) == 1, "channel dim must be contiguous"
+    return x.stride(-2)
+
+
+def nchw_to_nhwc_bf16(x):
+    """fp32 NCHW -> bf16 NHWC through dmx_nchw_f32_to_nhwc_bf16."""
+    x = x.to(torch.float32).contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x.device)
+    check(lib().dmx_nchw_f32_to_nhwc_bf16(ptr(x), ptr(out), C, B, C, H * W, current_stream()), "nchw_f32_to_nhwc_bf16")
+    return out
+
+
+def nhwc_bf16_to_nchw(x):
+    B, H, W, C = x.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    check(lib().dmx_nhwc_bf16_to_nchw_f32(ptr(x), _ld(x), ptr(out), B, C, H * W, current_stream()), "nhwc_bf16_to_nchw_f32")
+    return out
+
+
+def pack_conv_weight(w, shortcut_w=None):
+    """[Cout,Cin,k,k] fp32 -> bf16 [Cout][k*k*Cin (+ Csc)] ; optional 1x1 shortcut appended as extra K."""
+    w = w.to(torch.float32).contiguous()
+    Cout, Cin, k, _ = w.shape
+    K = k * k * Cin + (shortcut_w.shape[1] if shortcut_w is not None else 0)
+    Kp = (K + 63) // 64 * 64
+    out = torch.zeros(Cout, Kp, dtype=torch.bfloat16, device=w.device)
+    check(lib().dmx_pack_conv_weight(ptr(w), ptr(out), Cout, Cin, k, Kp, 0, current_stream()), "pack_conv_weight")
+    if shortcut_w is not None:
+        s = shortcut_w.to(torch.float32).contiguous()
+        check(lib().dmx_pack_conv_weight(ptr(s), ptr(out), Cout, s.shape[1], 1, Kp, k * k * Cin, current_stream()), "pack_conv_weight(sc)")
+    return out
+
+
+def pack_linear_weight(w, geglu=False):
+    w = w.to(torch.float32).contiguous()
+    out = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    check(lib().dmx_pack_linear_weight(ptr(w), ptr(out), w.shape[0], w.shape[1], w.shape[1], int(geglu), current_stream()), "pack_linear_weight")
+    return out
+
+
+def pack_geglu_bias(b):
+    b = b.to(torch.float32).contiguous()
+    out = torch.empty_like(b)
+    check(lib().dmx_pack_geglu_bias(ptr(b), ptr(out), b.numel(), current_stream()), "pack_geglu_bias")
+    return out
+
+
+def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=None, rowbias=None,
+              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None):
+    """Fused conv / linear.  x0 (and x1) NHWC bf16; w packed bf16 [N][K].  Returns NHWC (bf16 or fp32)."""
+    B, H, W, C0 = x0.shape
+    Cin = C0 + (x1.shape[-1] if x1 is not None else 0)
+    OH, OW = H, W
+    if ups:
+        OH, OW = 2 * OH, 2 * OW
+    if stride == 2:
+        OH, OW = OH // 2, OW // 2
+    d = GemmDesc()
+    d.x0 = x0.data_ptr(); d.ldx0 = _ld(x0); d.cx0 = C0
+    if x1 is not None:
+        d.x1 = x1.data_ptr(); d.ldx1 = _ld(x1)
+    d.direct = int(ksize == 1 and stride == 1 and not ups) if direct is None else int(direct)
+    d.IH, d.IW, d.OH, d.OW = H, W, OH, OW
+    d.stride, d.pad, d.ups, d.ksize, d.Cin = stride, pad, int(ups), ksize, Cin
+    d.Ktaps = ksize * ksize * Cin
+    K = d.Ktaps
+    if sc0 is not None:
+        d.s0 = sc0.data_ptr(); d.lds0 = _ld(sc0); d.cs0 = sc0.shape[-1]; K += sc0.shape[-1]
+        if sc1 is not None:
+            d.s1 = sc1.data_ptr(); d.lds1 = _ld(sc1); K += sc1.shape[-1]
+    d.w = w.data_ptr(); d.ldw = w.stride(0)
+    d.M = B * OH * OW; d.N = N; d.K = K
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    if rowbias is not None:
+        d.rowbias = rowbias.data_ptr(); d.ldrb = rowbias.stride(0)
+    d.rows_per_group = OH * OW
+    if res is not None:
+        d.res = res.data_ptr(); d.ldres = _ld(res)
+    Nout = N // 2 if geglu else N
+    out = torch.empty(B, OH, OW, Nout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x0.device)
+    d.out = out.data_ptr(); d.ldo = Nout; d.out_f32 = int(out_f32); d.geglu = int(geglu)
+    wsb = lib().dmx_conv_gemm_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x0.device)
+    check(lib().dmx_conv_gemm(ctypes.byref(d), ptr(ws), wsb, current_stream()), "conv_gemm")
+    return out
+
+
+def linear(x, w, bias=None, res=None, geglu=False, out_f32=False):
+    """x [..., K] bf16 (2-D view [rows][K]) @ w[N][K]^T."""
+    K = x.shape[-1]
+    x4 = x.reshape(1, 1, -1, K)
+    r4 = None if res is None else res.reshape(1, 1, -1, res.shape[-1])
+    y = conv_gemm(x4, w, w.shape[0], ksize=1, pad=0, bias=bias, res=r4, geglu=geglu, out_f32=out_f32)
+    return y.reshape(*x.shape[:-1], y.shape[-1])
+
+
+def groupnorm(x0, gamma, beta, groups, eps, silu, x1=None):
+    B, H, W, C0 = x0.shape
+    C = C0 + (x1.shape[-1] if x1 is not None else 0)
+    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x0.device)
+    wsb = lib().dmx_groupnorm_workspace_bytes(B, H * W, groups)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x0.device)
+    check(lib().dmx_groupnorm(ptr(x0), _ld(x0), ptr(x1), _ld(x1) if x1 is not None else 0, C0, C, groups, B, H * W,
+                              ptr(gamma), ptr(beta), float(eps), int(silu), ptr(y), C, ptr(ws), wsb, current_stream()), "groupnorm")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    check(lib().dmx_layernorm(ptr(x), C, ptr(y), C, ptr(gamma), ptr(beta), rows, C, float(eps), current_stream()), "layernorm")
+    return y
+
+
+def attention(q, k, vt, B, H, Sq, Skv, scale, kv_rows=None, skv_stride=None):
+    """q [B*Sq, >=H*64], k [B*kv_rows, >=H*64], vt [H*64, >= B*skv_stride] (2-D, row-major views)."""
+    o = torch.empty(B * Sq, H * 64, dtype=torch.bfloat16, device=q.device)
+    kv_rows = Skv if kv_rows is None else kv_rows
+    skv_stride = Skv if skv_stride is None else skv_stride
+    check(lib().dmx_attention_fwd(ptr(q), q.stride(0), ptr(k), k.stride(0), kv_rows, ptr(vt), vt.stride(0), skv_stride,
+                                  ptr(o), H * 64, B, H, Sq, Skv, float(scale), current_stream()), "attention_fwd")
+    return o
+
+
+def im2col_small(sources=None, nhwc=None, ksize=3, stride=1, pad=1, Kpad=64):
+    if nhwc is not None:
+        B, H, W, C = nhwc.shape
+        args = [None, 0, None, 0, None, 0, ptr(nhwc), _ld(nhwc)]
+    else:
+        srcs = [s.to(torch.float32).contiguous() for s in sources]
+        B, _, H, W = srcs[0].shape
+        C = sum(s.shape[1] for s in srcs)
+        args = []
+        for i in range(3):
+            args += [ptr(srcs[i]), srcs[i].shape[1]] if i < len(srcs) else [None, 0]
+        args += [None, 0]
+    OH, OW = (H // stride, W // stride)
+    dev = nhwc.device if nhwc is not None else srcs[0].device
+    out = torch.empty(B, OH, OW, Kpad, dtype=torch.bfloat16, device=dev)
+    check(lib().dmx_im2col_small(*args, C, B, H, W, OH, OW, ksize, stride, pad, ptr(out), Kpad, current_stream()), "im2col_small")
+    return out
+
+
+def timestep_embedding(t, freq, B, dim):
+    out = torch.empty(B, dim, dtype=torch.float32, device=t.device)
+    check(lib().dmx_timestep_embedding(ptr(t), t.numel(), ptr(freq), B, dim, ptr(out), current_stream()), "timestep_embedding")
+    return out
+
+
+def linear_small(x, w, bias=None, silu_in=False):
+    B, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    check(lib().dmx_linear_small(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, B, N, K, int(silu_in),
+                                 current_stream()), "linear_small")
+    return y

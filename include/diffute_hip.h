@@ -198,6 +198,15 @@ int dmx_vae_encode(dmx_vae* v, const float* x, float* moments, int B, int H, int
 int dmx_vae_decode(dmx_vae* v, const float* z, float* image, int B, int h, int w,
                    void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Measurement aid (bench.py roofline leg): while enabled, every executor launch is bracketed
+ * by hipEvents on its own stream.  dmx_profile_end synchronises and fills, per kernel class
+ * (0 conv/linear GEMM, 1 attention, 2 GroupNorm, 3 LayerNorm, 4 other), four doubles:
+ * launches, total milliseconds, algorithmic FLOPs, algorithmic bytes.
+ * ---------------------------------------------------------------------------------- */
+int dmx_profile_begin(void);
+int dmx_profile_end(double* h_out, int n_out);
+
 #ifdef __cplusplus
 }
 #endif

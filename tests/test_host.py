@@ -1,0 +1,174 @@
+"""CPU-side checks (no GPU): oracle pins, host logic of the product, C-ABI library surface."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_param_counts_match_public_models():
+    """The only external pins available: SD2-inpaint UNet 865,925,124 / SD VAE 83,653,863."""
+    from oracle import unet as OU, vae as OV
+    assert OU.count_params(OU.unet_param_spec(OU.SD2_INPAINT_UNET)) == 865_925_124
+    assert OU.count_params(OV.vae_param_spec(OV.SD_VAE)) == 83_653_863
+
+
+def test_scheduler_index_math_bit_exact():
+    """S2: integer timestep grids (known answers) - oracle, product and committed fixture agree exactly."""
+    import diffute_amd as D
+    from oracle import schedulers as OS
+    g = np.load(os.path.join(GOLD, "sched.npz"))
+    for n, first, last in ((10, 900, 0), (50, 980, 0), (150, 894, 0)):
+        p = D.DDPMScheduler(); p.set_timesteps(n)
+        assert p.timesteps.dtype == torch.int64
+        assert np.array_equal(p.timesteps.numpy(), OS.timesteps_ddpm(n)) and np.array_equal(p.timesteps.numpy(), g[f"ddpm_{n}"])
+        assert int(p.timesteps[0]) == first and int(p.timesteps[-1]) == last
+        d = D.DDIMScheduler(); d.set_timesteps(n)
+        assert np.array_equal(d.timesteps.numpy(), OS.timesteps_ddim(n)) and np.array_equal(d.timesteps.numpy(), g[f"ddim_{n}"])
+        assert int(d.timesteps[0]) == first + 1 and int(d.timesteps[-1]) == 1
+        assert all(p.previous_timestep(int(t)) == OS.prev_timestep(int(t), n) for t in p.timesteps)
+    assert D.DDPMScheduler().init_noise_sigma == 1.0 and D.DDPMScheduler().num_train_timesteps == 1000
+    assert D.DDPMScheduler().config.prediction_type == "epsilon"
+
+
+def test_scheduler_tables():
+    """alphas_cumprod: oracle's scalar restatement of torch.linspace/cumprod vs the product's torch expression
+    (<= 1 ulp apart: torch's vectorised linspace kernel is SIMD-width dependent) and vs the fixture (exact)."""
+    import diffute_amd as D
+    from oracle import schedulers as OS
+    betas, alphas, ac = OS.make_tables()
+    g = np.load(os.path.join(GOLD, "sched.npz"))
+    assert np.array_equal(ac, g["alphas_cumprod"]) and np.array_equal(betas, g["betas"])
+    s = D.DDIMScheduler()
+    assert np.abs(s.alphas_cumprod.numpy() - ac).max() <= 6e-8
+    assert abs(float(ac[0]) - 0.99915) < 1e-6 and abs(float(ac[-1]) - 0.0046602) < 1e-6
+    # step coefficients: product host math == oracle scalars when fed the same table
+    s.alphas_cumprod = torch.from_numpy(ac.copy()); s.final_alpha_cumprod = s.alphas_cumprod[0]
+    s.set_timesteps(50)
+    x, e = g["x"], g["eps"]
+    sbt, sat, sap, dirc, std = s.step_coefficients(981)
+    ref = OS.ddim_step(ac, e, 981, x, 50)
+    mine = (np.float32(sap) * ((x - np.float32(sbt) * e) / np.float32(sat)) + np.float32(dirc) * e).astype(np.float32)
+    assert np.array_equal(mine, ref) and np.array_equal(ref, g["ddim_step_981_50"])
+
+
+def test_oracle_golden_reproducible():
+    """The committed tiny goldens are what the oracle computes today."""
+    from oracle import prng, unet as OU
+    g = np.load(os.path.join(GOLD, "tiny_unet.npz"))
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from make_golden import synth_inputs
+    cfg = OU.TINY_UNET
+    P = OU.make_params(OU.unet_param_spec(cfg), seed=1234)
+    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, cfg["cross_attention_dim"])
+    y = OU.unet_forward(P, cfg, torch.cat([lat, mask, mlat], 1), torch.tensor(981), ctx)
+    assert float((y - torch.from_numpy(g["eps_fp32"])).abs().max()) < 1e-4
+
+
+def test_product_param_table_matches_oracle_spec():
+    """Two independent enumerations (C++ ParamTable vs oracle spec) agree on every key, shape and value."""
+    import diffute_amd as D
+    from oracle import unet as OU, vae as OV
+    u = D.UNet2DConditionModel(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128)
+    spec = OU.unet_param_spec(OU.TINY_UNET)
+    sd = u.state_dict()
+    assert set(sd) == set(spec) and all(tuple(sd[k].shape) == tuple(spec[k]) for k in spec)
+    P = OU.make_params(spec)
+    assert all(torch.equal(sd[k], P[k]) for k in spec)
+    v = D.AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+    vs = OV.vae_param_spec(OV.TINY_VAE)
+    assert set(v.state_dict()) == set(vs)
+    assert v.config.scaling_factor == 0.18215 and 2 ** (len(v.config.block_out_channels) - 1) == 8
+
+
+def test_full_config_param_table():
+    from diffute_amd import _cabi
+    import ctypes
+    import diffute_amd as D
+    c = _cabi.UNetConfig()
+    cfg = D.SD2_INPAINT_UNET_CONFIG
+    c.in_channels, c.out_channels, c.layers_per_block, c.cross_attention_dim, c.norm_num_groups = 9, 4, 2, 1024, 32
+    for i in range(4):
+        c.block_out_channels[i] = cfg["block_out_channels"][i]; c.heads[i] = cfg["attention_head_dim"][i]
+        c.down_has_attn[i] = int(i < 3); c.up_has_attn[i] = int(i > 0)
+    lib = _cabi.lib()
+    h = lib.dmx_unet_create(ctypes.byref(c))
+    assert h
+    n = lib.dmx_unet_param_count(h)
+    name = ctypes.c_char_p(); shape = (ctypes.c_int * 4)()
+    total = 0
+    for i in range(n):
+        assert lib.dmx_unet_param_info(h, i, ctypes.byref(name), ctypes.byref(shape)) == 0
+        total += int(np.prod([s for s in shape if s > 0]))
+    assert n == 686 and total == 865_925_124
+    assert lib.dmx_unet_arena_bytes(h) > 2 * 865_000_000 * 0.99
+    # workspace plan is a pure host computation
+    assert lib.dmx_unet_workspace_bytes(h, 4, 64, 64, 577) > 0
+    lib.dmx_unet_destroy(h)
+
+
+def test_cabi_exports_every_declared_symbol():
+    from diffute_amd import _cabi
+    hdr = open(os.path.join(ROOT, "include", "diffute_hip.h")).read()
+    declared = set(re.findall(r"\b(dmx_[a-z0-9_]+)\s*\(", hdr))
+    lib = _cabi.lib()
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/diffute_hip.h but not exported"
+    assert declared == set(_cabi.exported_symbols())
+
+
+def test_error_paths_without_gpu():
+    """Loud failures: CPU tensors are rejected, bad configs are rejected, errors carry a message."""
+    import diffute_amd as D
+    from diffute_amd import _cabi
+    with pytest.raises(ValueError):
+        D.UNet2DConditionModel(block_out_channels=(48, 96, 192, 192), attention_head_dim=(1, 2, 4, 4))
+    s = D.DDIMScheduler(); s.set_timesteps(10)
+    with pytest.raises(RuntimeError):
+        s.step(torch.zeros(1, 4, 8, 8), 901, torch.zeros(1, 4, 8, 8))
+    u = D.UNet2DConditionModel(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            u(torch.zeros(1, 9, 8, 8), 10, torch.zeros(1, 7, 128))
+    with pytest.raises(ValueError):
+        D.DDPMScheduler().step_coefficients(10)        # set_timesteps not called
+    assert _cabi.lib().dmx_version() >= 100
+
+
+def test_mask_downsample_nearest():
+    """P3: F.interpolate(mask, size=(h/8,w/8)) default nearest == src index floor(dst*8)."""
+    import torch.nn.functional as F
+    import diffute_amd as D
+    m = torch.zeros(1, 1, 64, 64); m[:, :, 17:41, 9:50] = 1
+    assert torch.equal(D.mask_to_latent(m), F.interpolate(m, size=(8, 8)))
+
+
+def test_save_load_roundtrip(tmp_path):
+    import diffute_amd as D
+    v = D.AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+    v.save_pretrained(str(tmp_path / "vae"))
+    v2 = D.AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
+    assert all(torch.equal(a, b) for a, b in zip(v.state_dict().values(), v2.state_dict().values()))
+    s = D.DDPMScheduler(); s.save_pretrained(str(tmp_path / "scheduler"))
+    s2 = D.DDPMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")
+    assert torch.equal(s.alphas_cumprod, s2.alphas_cumprod)
+    # legacy VAE attention key names (query/key/value/proj_attn) are accepted
+    sd = {k.replace("to_q", "query").replace("to_k", "key").replace("to_v", "value").replace("to_out.0", "proj_attn"): t
+          for k, t in v.state_dict().items()}
+    v3 = D.AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=1, seed=1)
+    v3.load_state_dict(D.AutoencoderKL._convert_legacy_keys(sd))
+    assert all(torch.equal(a, b) for a, b in zip(v.state_dict().values(), v3.state_dict().values()))
+
+
+def test_flops_formula_matches_oracle():
+    import diffute_amd as D
+    from diffute_amd.flops import unet_flops
+    from oracle import unet as OU
+    u_cfg = D.models._Config(**{**D.SD2_INPAINT_UNET_CONFIG})
+    assert unet_flops(u_cfg, 4, 64, 64, 577, True) == OU.unet_flops(OU.SD2_INPAINT_UNET, 4, 64, 64, 577, True)
+    assert abs(unet_flops(u_cfg, 1, 64, 64, 577, False) / 1e12 - 0.853) < 0.002
