@@ -260,11 +260,22 @@ struct Fwd {
     // ---- self attention
     Tn n = ex.layernorm(h, u->at<float>(w.l1g), u->at<float>(w.l1b), 1e-5f);
     Tn qk = ex.linear(n, u->at<bf16>(w.wqk), 2 * C, nullptr, nullptr, false);
-    bf16* vt = (bf16*)ex.raw((size_t)C * M * 2);
-    ex.gemm_raw(u->at<bf16>(w.wv), C, C, n.p, n.ld, M, C, nullptr, vt, M, 0);
+    // V^T[C][b*Sp + s]: one role-swapped GEMM when S is a multiple of 8 (always at 512/768 px); otherwise
+    // per-sample GEMMs into a zeroed buffer whose per-sample column stride is padded to 8 (16-byte loads).
+    const int Sp = (S + 7) / 8 * 8, ldvt = x.B * Sp;
+    bf16* vt = (bf16*)ex.raw((size_t)C * ldvt * 2);
+    if (Sp == S) {
+      ex.gemm_raw(u->at<bf16>(w.wv), C, C, n.p, n.ld, M, C, nullptr, vt, ldvt, 0);
+    } else {
+      if (!ex.dry && !ex.rc && hipMemsetAsync(vt, 0, (size_t)C * ldvt * 2, ex.stream) != hipSuccess) {
+        dmx_set_error("hipMemsetAsync failed"); ex.rc = DMX_ERR_HIP;
+      }
+      for (int b = 0; b < x.B; ++b)
+        ex.gemm_raw(u->at<bf16>(w.wv), C, C, n.p + (size_t)b * S * n.ld, n.ld, S, C, nullptr, vt + (size_t)b * Sp, ldvt, 0);
+    }
     ex.drop(n);
     Tn a = ex.make(x.B, x.H, x.W, C);
-    ex.attention(qk.p, 2 * C, qk.p + C, 2 * C, S, vt, M, S, a.p, C, x.B, w.heads, S, S, 0.125f);
+    ex.attention(qk.p, 2 * C, qk.p + C, 2 * C, S, vt, ldvt, Sp, a.p, C, x.B, w.heads, S, S, 0.125f);
     ex.drop(qk); ex.drop(vt);
     Tn h2 = ex.linear(a, u->at<bf16>(w.wo1), C, u->at<float>(w.bo1), &h, false);
     ex.drop(a); ex.drop(h);

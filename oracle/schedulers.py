@@ -55,51 +55,76 @@ def prev_timestep(t, n, N=1000):
     return int(t) - N // n
 
 
-def ddim_step(ac, eps, t, x, n, N=1000, eta=0.0, noise=None, prediction_type="epsilon"):
-    """DDIMScheduler.step(...).prev_sample ; all arithmetic fp32, op order as diffusers."""
+def ddim_coefs(ac, t, n, N=1000, eta=0.0):
+    """Scalar coefficients of DDIMScheduler.step: (sqrt(1-abar_t), sqrt(abar_t), sqrt(abar_prev), dir, std).
+    diffusers writes `x ** 0.5` on 0-d fp32 tensors; pow(x, 0.5) and sqrt(x) differ by <= 1 ulp between
+    libm implementations, so coefficients are compared at 1 ulp and the elementwise update bit-exactly."""
     p = prev_timestep(t, n, N)
     a_t = f32(ac[t]); a_p = f32(ac[p]) if p >= 0 else f32(ac[0])
     b_t = f32(1.0) - a_t
+    var = (f32(1.0) - a_p) / (f32(1.0) - a_t) * (f32(1.0) - a_t / a_p)
+    std = f32(f32(eta) * np.sqrt(f32(var)))
+    return (f32(np.sqrt(b_t)), f32(np.sqrt(a_t)), f32(np.sqrt(a_p)), f32(np.sqrt(f32(f32(1.0) - a_p - std * std))), std)
+
+
+def ddim_apply(c, eps, x, noise=None, prediction_type="epsilon"):
+    """Elementwise part of DDIMScheduler.step in diffusers' op order, fp32."""
+    sbt, sat, sap, dirc, std = [f32(v) for v in c]
     eps = eps.astype(f32); x = x.astype(f32)
     if prediction_type == "epsilon":
-        x0 = (x - np.sqrt(b_t) * eps) / np.sqrt(a_t)
+        x0 = (x - sbt * eps) / sat
         pe = eps
     elif prediction_type == "v_prediction":
-        x0 = np.sqrt(a_t) * x - np.sqrt(b_t) * eps
-        pe = np.sqrt(a_t) * eps + np.sqrt(b_t) * x
+        x0 = sat * x - sbt * eps
+        pe = sat * eps + sbt * x
     else:
         raise ValueError(prediction_type)
-    var = (f32(1.0) - a_p) / (f32(1.0) - a_t) * (f32(1.0) - a_t / a_p)
-    std = f32(eta) * np.sqrt(f32(var))
-    direction = np.sqrt(f32(f32(1.0) - a_p - std * std)) * pe
-    prev = np.sqrt(a_p) * x0 + direction
-    if eta > 0:
+    prev = sap * x0 + dirc * pe
+    if noise is not None:
         prev = prev + std * noise.astype(f32)
     return prev.astype(f32)
 
 
-def ddpm_step(ac, eps, t, x, n, N=1000, noise=None, prediction_type="epsilon"):
-    """DDPMScheduler.step(...).prev_sample, variance_type fixed_small, strided prev_t
-    (the >=0.15 formulation; SURVEY.md Appendix A.3 version caveat)."""
+def ddim_step(ac, eps, t, x, n, N=1000, eta=0.0, noise=None, prediction_type="epsilon"):
+    """DDIMScheduler.step(...).prev_sample ; all arithmetic fp32, op order as diffusers."""
+    return ddim_apply(ddim_coefs(ac, t, n, N, eta), eps, x, noise if eta > 0 else None, prediction_type)
+
+
+def ddpm_coefs(ac, t, n, N=1000):
+    """(sqrt(1-abar_t), sqrt(abar_t), coef_x0, coef_xt, sigma) of DDPMScheduler.step, variance_type fixed_small,
+    strided prev_t (the >=0.15 formulation; SURVEY.md Appendix A.3 version caveat)."""
     p = prev_timestep(t, n, N)
     a_t = f32(ac[t]); a_p = f32(ac[p]) if p >= 0 else f32(1.0)
     b_t = f32(1.0) - a_t; b_p = f32(1.0) - a_p
     cur_a = f32(a_t / a_p); cur_b = f32(1.0) - cur_a
-    eps = eps.astype(f32); x = x.astype(f32)
-    if prediction_type == "epsilon":
-        x0 = (x - np.sqrt(b_t) * eps) / np.sqrt(a_t)
-    elif prediction_type == "v_prediction":
-        x0 = np.sqrt(a_t) * x - np.sqrt(b_t) * eps
-    else:
-        raise ValueError(prediction_type)
-    c0 = f32(np.sqrt(a_p) * cur_b) / b_t
-    c1 = f32(np.sqrt(cur_a) * b_p) / b_t
-    prev = c0 * x0 + c1 * x
+    c0 = f32(f32(np.sqrt(a_p) * cur_b) / b_t)
+    c1 = f32(f32(np.sqrt(cur_a) * b_p) / b_t)
+    sigma = f32(0.0)
     if t > 0:
         var = f32(f32(b_p / b_t) * cur_b)
         var = max(var, f32(1e-20))
-        prev = prev + np.sqrt(f32(var)) * noise.astype(f32)
+        sigma = f32(np.sqrt(f32(var)))
+    return (f32(np.sqrt(b_t)), f32(np.sqrt(a_t)), c0, c1, sigma)
+
+
+def ddpm_apply(c, eps, x, noise=None, prediction_type="epsilon"):
+    sbt, sat, c0, c1, sigma = [f32(v) for v in c]
+    eps = eps.astype(f32); x = x.astype(f32)
+    if prediction_type == "epsilon":
+        x0 = (x - sbt * eps) / sat
+    elif prediction_type == "v_prediction":
+        x0 = sat * x - sbt * eps
+    else:
+        raise ValueError(prediction_type)
+    prev = c0 * x0 + c1 * x
+    if noise is not None:
+        prev = prev + sigma * noise.astype(f32)
     return prev.astype(f32)
+
+
+def ddpm_step(ac, eps, t, x, n, N=1000, noise=None, prediction_type="epsilon"):
+    """DDPMScheduler.step(...).prev_sample; noise is added only when t > 0."""
+    return ddpm_apply(ddpm_coefs(ac, t, n, N), eps, x, noise if t > 0 else None, prediction_type)
 
 
 def add_noise(ac, x0, noise, t):
