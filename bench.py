@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile-csv", default="", help="write one row per kernel launch of the profiled pass")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +105,8 @@ def main():
         # ---- roofline leg: one more pass with every launch bracketed by hipEvents on its stream
         lib = _cabi.lib()
         torch.cuda.synchronize(dev)
+        if args.profile_csv:
+            lib.dmx_profile_dump_path(args.profile_csv.encode())
         lib.dmx_profile_begin()
         one_pass()
         buf = (ctypes.c_double * (4 * len(PROF_CLASSES)))()
@@ -129,7 +132,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the torch-CPU fp32 oracle (a port; the reference itself cannot be imported)
         from oracle import unet as OU
-        torch.set_num_threads(os.cpu_count())
+        nthreads = min(os.cpu_count() or 1, 16)          # more threads than this only adds contention for these op sizes
+        torch.set_num_threads(nthreads)
         P = {k: v.detach().cpu() for k, v in unet.state_dict().items()}
         l1, m1, ml1, c1 = [x[:1].cpu() for x in (lat, mask, mlat, ctx)]
         inp = torch.cat([l1, m1, ml1], 1)
@@ -142,8 +146,8 @@ def main():
         eps_gpu = unet.forward_parts([lat[:1].contiguous(), mask[:1].contiguous(), mlat[:1].contiguous()],
                                      torch.tensor([981], device=dev))
         rel = float((eps_gpu.cpu() - eps_cpu).norm() / eps_cpu.norm())
-        result["cpu_baseline"] = {"value": round(1.0 / (T * t_fwd), 5), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
-                                  "sample": f"1 UNet forward (B=1, {hw * 8} px, fp32 torch-CPU oracle, {os.cpu_count()} threads) = "
+        result["cpu_baseline"] = {"value": round(1.0 / (T * t_fwd), 5), "unit": "images/s", "cores": nthreads, "kind": "port",
+                                  "sample": f"1 UNet forward (B=1, {hw * 8} px, fp32 torch-CPU oracle, {nthreads} threads) = "
                                             f"{t_fwd:.2f} s, x{T} steps extrapolated linearly",
                                   "gpu_vs_cpu_eps_rel_l2": round(rel, 5)}
     if rank == 0:

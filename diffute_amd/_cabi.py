@@ -20,6 +20,7 @@ class GemmDesc(ctypes.Structure):
         ("w", c_void_p), ("ldw", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
         ("bias", c_void_p), ("rowbias", c_void_p), ("rows_per_group", c_int), ("ldrb", c_int),
         ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("geglu", c_int),
+        ("force_tn", c_int), ("force_splitk", c_int), ("timing", c_void_p),
     ]
 
 
@@ -71,8 +72,10 @@ _PROTOS = {
     "dmx_unet_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dmx_unet_set_context": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_size_t, _P, c_size_t, _P]),
     "dmx_unet_forward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_unet_forward_graph": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "dmx_profile_begin": (c_int, []),
     "dmx_profile_end": (c_int, [POINTER(ctypes.c_double), c_int]),
+    "dmx_profile_dump_path": (c_int, [c_char_p]),
     "dmx_vae_create": (_P, [POINTER(VAEConfig)]),
     "dmx_vae_destroy": (None, [_P]),
     "dmx_vae_param_count": (c_int, [_P]),

@@ -37,18 +37,19 @@ int dmx_check_launch(const char* what);
     }                                                                        \
   } while (0)
 
-// round-to-nearest-even fp32 -> bf16 (NaN-safe enough for activations)
+// fp32 -> bf16, round-to-nearest-even: native casts so hipcc emits gfx950's v_cvt_pk_bf16_f32 (one instruction per
+// pair) instead of a ~7-op integer sequence per value.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ unsigned short f2bf_bits(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
 }
 __device__ __forceinline__ float bf_bits2f(unsigned short b) {
   return __uint_as_float(((unsigned int)b) << 16);
 }
 __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
-  return (unsigned int)f2bf_bits(lo) | ((unsigned int)f2bf_bits(hi) << 16);
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned int, v);
 }
 __device__ __forceinline__ void unpack_bf8(const u32x4 v, float* f) {
 #pragma unroll

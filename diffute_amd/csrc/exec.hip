@@ -1,6 +1,7 @@
 // Executor infrastructure: error state, parameter packing, workspace allocator, op wrappers.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 #include "exec.h"
 #include <vector>
 
@@ -17,13 +18,15 @@ int dmx_check_launch(const char* what) {
 
 // --------------------------------------------------------------------------- profiler
 namespace {
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char tag[96]; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+char g_prof_path[512] = "";
 }
-ProfScope::ProfScope(ProfClass c, hipStream_t s, double flops, double bytes) {
+ProfScope::ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag) {
   if (!g_prof_on) return;
-  ProfRec r; r.cls = c; r.flops = flops; r.bytes = bytes;
+  ProfRec r; r.cls = c; r.flops = flops; r.bytes = bytes; r.tag[0] = 0;
+  if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); r.tag[sizeof(r.tag) - 1] = 0; }
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   (void)hipEventRecord(r.a, s);
   slot = (int)g_prof.size(); g_prof.push_back(r);
@@ -31,6 +34,7 @@ ProfScope::ProfScope(ProfClass c, hipStream_t s, double flops, double bytes) {
 }
 ProfScope::~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream_); }
 
+bool dmx_profile_active() { return g_prof_on; }
 extern "C" int dmx_profile_begin(void) {
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear(); g_prof_on = true; return DMX_OK;
@@ -40,12 +44,22 @@ extern "C" int dmx_profile_end(double* out, int n_out) {
   g_prof_on = false;
   DMX_HIP(hipDeviceSynchronize());
   for (int i = 0; i < n_out; ++i) out[i] = 0.0;
+  FILE* f = g_prof_path[0] ? fopen(g_prof_path, "w") : nullptr;
+  if (f) fprintf(f, "class,ms,flops,bytes,tag\n");
   for (auto& r : g_prof) {
     float ms = 0.f; (void)hipEventElapsedTime(&ms, r.a, r.b);
+    if (f) fprintf(f, "%d,%.6f,%.0f,%.0f,%s\n", r.cls, ms, r.flops, r.bytes, r.tag);
     if (r.cls * 4 + 3 < n_out) { out[r.cls * 4] += 1; out[r.cls * 4 + 1] += ms; out[r.cls * 4 + 2] += r.flops; out[r.cls * 4 + 3] += r.bytes; }
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
+  if (f) fclose(f);
   g_prof.clear();
+  return DMX_OK;
+}
+// optional: per-launch CSV written by the next dmx_profile_end (empty path disables)
+extern "C" int dmx_profile_dump_path(const char* path) {
+  g_prof_path[0] = 0;
+  if (path) { strncpy(g_prof_path, path, sizeof(g_prof_path) - 1); g_prof_path[sizeof(g_prof_path) - 1] = 0; }
   return DMX_OK;
 }
 
@@ -128,7 +142,8 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
     a.C = C; a.groups = groups; a.B = x0.B; a.HW = x0.H * x0.W;
     a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu ? 1 : 0;
     a.y = y.p; a.ldy = y.ld; a.partial = (float*)part;
-    ProfScope ps(PROF_GNORM, stream, 0.0, 6.0 * (double)x0.rows() * C);     // read x twice (stats, apply) + write y, bf16
+    char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d", x0.rows(), C);
+    ProfScope ps(PROF_GNORM, stream, 0.0, 6.0 * (double)x0.rows() * C, tag);     // read x twice (stats, apply) + write y, bf16
     rc = dmx_groupnorm_launch(a, stream);
   }
   ws.release(part);
@@ -192,7 +207,8 @@ void Exec::gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N
 Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps) {
   Tn y = make(x.B, x.H, x.W, x.C);
   if (!dry && !rc) {
-    ProfScope ps(PROF_LNORM, stream, 0.0, 4.0 * (double)x.rows() * x.C);
+    char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d", x.rows(), x.C);
+    ProfScope ps(PROF_LNORM, stream, 0.0, 4.0 * (double)x.rows() * x.C, tag);
     rc = dmx_layernorm_launch(x.p, x.ld, y.p, y.ld, gamma, beta, x.rows(), x.C, eps, stream);
   }
   return y;
@@ -204,7 +220,8 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, int kv_rows
   AttnArgs a{};
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.vt = vt; a.ldvt = ldvt; a.skv_stride = skv_stride;
   a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
-  ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv));
+  char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
+  ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv), tag);
   rc = dmx_attention_launch(a, stream);
 }
 

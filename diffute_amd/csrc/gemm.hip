@@ -14,19 +14,21 @@
 // is one launch.
 //
 // Tiling: block = 256 threads = 4 waves (2 along m x 2 along n); block tile 128(m) x
-// {128,64}(n) x 64(k); per wave 2 x TN MFMA tiles of v_mfma_f32_32x32x16_bf16.  The
+// {128,64}(n) x 32(k); per wave 2 x TN MFMA tiles of v_mfma_f32_32x32x16_bf16.  The
 // weight tile is the MFMA A operand (rows = n) and the activation tile the B operand
 // (cols = m) so each lane ends up with 4 consecutive output channels of one pixel
-// (8-byte bf16 / 16-byte fp32 stores).  LDS tiles are [rows][64] bf16 with the 16-byte
-// k-chunk XOR-swizzled by ((row>>1)&7) on the SOURCE side (glds writes lane-linear), which
-// makes the ds_read_b128 fragment reads bank-conflict free.  Two LDS stages (64 KB at
-// BN=128) -> 2 blocks per CU; the next K-tile's DMA is in flight while the current one
-// is multiplied.
+// (8-byte bf16 / 16-byte fp32 stores).  LDS tiles are [rows][32] bf16 (64-byte rows) with
+// the 16-byte k-chunk XOR-swizzled by ((row>>2)&3) on the SOURCE side (glds writes
+// lane-linear), which makes the ds_read_b128 fragment reads bank-conflict free.  A 4-deep
+// LDS ring (64 KB at BN=128 -> 2 blocks per CU) keeps three K-tiles of DMA in flight behind
+// a counted `s_waitcnt vmcnt(N)` + raw s_barrier; the queue is never drained inside the loop.
 #include "common.h"
 #include "kernels.h"
+#include <stdio.h>
 
 #define BM 128
-#define BK 64
+#define BK 32
+#define NSTAGE 4
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -43,11 +45,14 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
   constexpr int X_BYTES = BM * BK * 2;
   constexpr int W_BYTES = BN * BK * 2;
   constexpr int STAGE = X_BYTES + W_BYTES;
+  constexpr int NLOADS = 2 + TN;                       // glds per thread per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  long long tm0 = 0, tm1 = 0, tm2 = 0;
+  if (p.timing) tm0 = (long long)__builtin_amdgcn_s_memrealtime();
   const int wm = wave & 1, wn = wave >> 1;
 
   // ---- block -> tile mapping (XCD-aware: each XCD's L2 sees one n-tile at a time)
@@ -67,12 +72,15 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
     kt_end = min(kt_begin + p.kt_per_split, nkt_total);
   }
 
-  // ---- per-thread staging rows: chunk q = t + 256*i -> row q>>3, slot q&7
-  const int slot = t & 7;
-  RowSrc xr[4];
+  // ---- per-thread staging rows: 16-byte chunk q = t + 256*i -> row q>>2, slot q&3 (rows are 64 B)
+  const int slot = t & 3;
+  RowSrc xr[2];
+  int kcx[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + (t >> 3) + 32 * i;
+  for (int i = 0; i < 2; ++i) {
+    const int r = (t >> 2) + 64 * i;
+    const int m = m0 + r;
+    kcx[i] = (slot ^ ((r >> 2) & 3)) * 8;
     xr[i].valid = m < p.M;
     if (p.direct) {
       xr[i].bbase = m; xr[i].iy0 = 0; xr[i].ix0 = 0;
@@ -87,62 +95,76 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
       xr[i].ix0 = ox * p.stride - p.pad;
     }
   }
-  const bf16* wrow[2 * TN];
-  int kcw[2 * TN];
-#pragma unroll
-  for (int i = 0; i < 2 * TN; ++i) {
-    const int r = (t >> 3) + 32 * i;
-    const int n = n0 + r;
-    wrow[i] = (n < p.N) ? (p.w + (size_t)n * p.ldw) : nullptr;
-    kcw[i] = (slot ^ ((r >> 1) & 7)) * 8;
-  }
-  int kcx[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) kcx[i] = (slot ^ ((((t >> 3) + 32 * i) >> 1) & 7)) * 8;
-
   const int eh = p.ups ? 2 * p.IH : p.IH;   // extent of the (virtually upsampled) input grid
   const int ew = p.ups ? 2 * p.IW : p.IW;
 
-  auto stage = [&](int kt, int buf) {
-    char* xs = smem + buf * STAGE;
-    char* ws = xs + X_BYTES;
-    const int k0 = kt * BK;
-    // ---- activation tile
-    const bf16* src; int ld; int ci; int dy = 0, dx = 0; bool sc = false;
+  // ---- producer state.  K is walked in SEGMENTS inside which the source tensor and the filter tap are fixed
+  // (tap x {x0,x1}, then the fused shortcut {s0,s1}); inside a segment staging a K-tile is: 2+TN DMA loads from
+  // per-row pointers, then pointer += 64 bytes.  All address decoding lives in segment_setup (rare).
+  const char* xp[2]; int xinc[2];
+  const char* wp[TN]; int winc[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int r = (t >> 2) + 64 * i;
+    const int n = n0 + r;
+    const int kc = (slot ^ ((r >> 2) & 3)) * 8;
+    if (n < p.N) { wp[i] = (const char*)(p.w + (size_t)n * p.ldw + (size_t)kt_begin * BK + kc); winc[i] = BK * 2; }
+    else { wp[i] = (const char*)p.zeros; winc[i] = 0; }
+  }
+  int p_kt = kt_begin, p_left = 0;
+  auto segment_setup = [&](int k0) {
+    const bf16* src; int ld, ci, cend, dy = 0, dx = 0; bool sc = false;
     if (k0 < p.Ktaps) {
       int tap = 0; ci = k0;
       if (p.ksize == 3) { tap = k0 / p.Cin; ci = k0 - tap * p.Cin; dy = tap / 3; dx = tap - dy * 3; }
-      if (ci < p.cx0) { src = p.x0 + ci; ld = p.ldx0; } else { src = p.x1 + (ci - p.cx0); ld = p.ldx1; }
+      if (ci < p.cx0) { src = p.x0 + ci; ld = p.ldx0; cend = p.cx0; } else { src = p.x1 + (ci - p.cx0); ld = p.ldx1; cend = p.Cin; }
     } else {
-      sc = true; ci = k0 - p.Ktaps;
-      if (ci < p.cs0) { src = p.s0 + ci; ld = p.lds0; } else { src = p.s1 + (ci - p.cs0); ld = p.lds1; }
+      sc = true; ci = k0 - p.Ktaps; const int ctot = p.K - p.Ktaps;
+      if (ci < p.cs0) { src = p.s0 + ci; ld = p.lds0; cend = p.cs0; } else { src = p.s1 + (ci - p.cs0); ld = p.lds1; cend = ctot; }
     }
+    p_left = (cend - ci) / BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16* g = p.zeros;
+    for (int i = 0; i < 2; ++i) {
+      const bf16* g = nullptr;
       if (xr[i].valid) {
         if (p.direct) {
-          g = src + (size_t)xr[i].bbase * ld + kcx[i];
+          g = src + (size_t)xr[i].bbase * ld;
         } else if (sc) {       // shortcut: 1x1 at the output pixel (shortcut source has the output grid)
-          const int opix = m0 + (t >> 3) + 32 * i;
-          g = src + (size_t)opix * ld + kcx[i];
+          g = src + (size_t)(m0 + (t >> 2) + 64 * i) * ld;
         } else {
           const int iy = xr[i].iy0 + dy, ix = xr[i].ix0 + dx;
           if (iy >= 0 && iy < eh && ix >= 0 && ix < ew) {
             const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-            g = src + (size_t)(xr[i].bbase + sy * p.IW + sx) * ld + kcx[i];
+            g = src + (size_t)(xr[i].bbase + sy * p.IW + sx) * ld;
           }
         }
       }
-      char* l = xs + (wave * 64 + 256 * i) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+      if (g) { xp[i] = (const char*)(g + kcx[i]); xinc[i] = BK * 2; }
+      else { xp[i] = (const char*)p.zeros; xinc[i] = 0; }       // padding / M tail: re-read the zero page
     }
-    // ---- weight tile
+  };
+  // Issues exactly NLOADS global_load_lds per thread; past the end: dummy loads of the zero page into a buffer
+  // nobody reads, so the counted vmcnt below stays uniform through the pipeline tail.
+  auto produce = [&](int buf) {
+    char* xs = smem + buf * STAGE;
+    char* ws = xs + X_BYTES;
+    if (p_kt < kt_end) {
+      if (p_left == 0) segment_setup(p_kt * BK);
 #pragma unroll
-    for (int i = 0; i < 2 * TN; ++i) {
-      const bf16* g = wrow[i] ? (wrow[i] + k0 + kcw[i]) : p.zeros;
-      char* l = ws + (wave * 64 + 256 * i) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)xp[i], (lptr_t)(xs + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+        xp[i] += xinc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(ws + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+        wp[i] += winc[i];
+      }
+      ++p_kt; --p_left;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLOADS; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)p.zeros, (lptr_t)(xs + (wave * 64 + 256 * i) * 16), 16, 0, 0);
     }
   };
 
@@ -154,37 +176,57 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // fragment read offsets (bytes) for this lane: row part and the swizzle key
+  // fragment read addresses for this lane (stage offset is an immediate: the loop is unrolled over the ring)
   const int lr = lane & 31, lh = lane >> 5;
-  int xoff[2], xkey[2], woff[TN], wkey[TN];
+  int xad[2][2], wad[TN][2];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) { const int r = wm * 64 + b * 32 + lr; xoff[b] = r * 128; xkey[b] = (r >> 1) & 7; }
+  for (int b = 0; b < 2; ++b) {
+    const int r = wm * 64 + b * 32 + lr;
 #pragma unroll
-  for (int a = 0; a < TN; ++a) { const int r = wn * 32 * TN + a * 32 + lr; woff[a] = r * 128; wkey[a] = (r >> 1) & 7; }
-
-  if (kt_begin < kt_end) stage(kt_begin, 0);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);
-    const char* xs = smem + buf * STAGE;
-    const char* ws = xs + X_BYTES;
+    for (int kk = 0; kk < 2; ++kk) xad[b][kk] = r * 64 + (((2 * kk + lh) ^ ((r >> 2) & 3)) << 4);
+  }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int kc = 2 * kk + lh;
+  for (int a = 0; a < TN; ++a) {
+    const int r = wn * 32 * TN + a * 32 + lr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) wad[a][kk] = X_BYTES + r * 64 + (((2 * kk + lh) ^ ((r >> 2) & 3)) << 4);
+  }
+  auto compute = [&](const int J) {
+    const char* st = smem + J * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
       bf16x8 xf[2], wf[TN];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) xf[b] = *(const bf16x8*)(xs + xoff[b] + ((kc ^ xkey[b]) << 4));
+      for (int b = 0; b < 2; ++b) xf[b] = *(const bf16x8*)(st + xad[b][kk]);
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[a] = *(const bf16x8*)(ws + woff[a] + ((kc ^ wkey[a]) << 4));
+      for (int a = 0; a < TN; ++a) wf[a] = *(const bf16x8*)(st + wad[a][kk]);
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
     }
+  };
+
+  // ---- NSTAGE-deep LDS ring, NSTAGE-1 K-tiles of DMA in flight, counted vmcnt (never drained to 0 in the loop)
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s) produce(s);
+  if (p.timing) tm1 = (long long)__builtin_amdgcn_s_memrealtime();
+  int kt = kt_begin;
+#define DMX_SUBITER(J)                                                                      \
+  {                                                                                         \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLOADS) : "memory");            \
+    __builtin_amdgcn_s_barrier(); /* tile kt is in LDS for every wave; tile kt-1's buffer is free */ \
+    produce((J + NSTAGE - 1) & (NSTAGE - 1));                                               \
+    compute(J);                                                                             \
+    if (++kt >= kt_end) break;                                                              \
   }
+  for (;;) {
+    DMX_SUBITER(0) DMX_SUBITER(1) DMX_SUBITER(2) DMX_SUBITER(3)
+  }
+#undef DMX_SUBITER
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the dummy tail loads before LDS is released
+  if (p.timing) tm2 = (long long)__builtin_amdgcn_s_memrealtime();
 
   // ---------------------------------------------------------------- epilogue
   // acc[a][b][4g+e] = out[m = m0 + wm*64 + b*32 + lr][n = n0 + wn*32*TN + a*32 + 8g + 4lh + e]
@@ -209,10 +251,114 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
           }
         }
       }
-    return;
-  }
-
-  if (p.geglu) {
+  } else if (!p.out_f32 && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (p.res == nullptr || (p.ldres & 7) == 0)) {
+    // ---- coalesced epilogue: accumulators (+ time-embedding row bias) -> LDS as fp32 (the ring is free now) ->
+    // each thread finishes 8 consecutive channels of one pixel: + bias + residual (or GEGLU a*gelu(b)), one
+    // rounding to bf16, one 16-byte store; a wave writes whole 128/256-byte row segments.  Raw s_barrier +
+    // lgkmcnt only: __syncthreads() would also wait for the global stores (vmcnt counts stores on gfx950), and
+    // every global load is issued before the first store for the same reason.
+    constexpr int LDT = BN + 4;                        // padded row stride (floats): conflict-free b128 writes
+    constexpr int OCT = BM * (BN / 8) / 256;           // (row, octet) items per thread: 8 (BN=128) or 4 (BN=64)
+    float* tile = (float*)smem;
+    const bool geglu = p.geglu != 0;
+    if (p.rowbias) {                                   // uniform branch; columns past N are clamped (never stored)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        int m = m0 + wm * 64 + b * 32 + lr; if (m >= p.M) m = p.M - 1;
+        const float* rb = p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb;
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            int nn = n0 + wn * 32 * TN + a * 32 + 8 * g + 4 * lh; if (nn > p.N - 4) nn = p.N - 4;
+            const f32x4 bv = *(const f32x4*)(rb + nn);
+            acc[a][b][4 * g] += bv[0]; acc[a][b][4 * g + 1] += bv[1]; acc[a][b][4 * g + 2] += bv[2]; acc[a][b][4 * g + 3] += bv[3];
+          }
+      }
+    }
+    __builtin_amdgcn_s_barrier();                      // every wave has left the K loop: the ring can be reused
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int r = wm * 64 + b * 32 + lr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+          *(f32x4*)(tile + r * LDT + wn * 32 * TN + a * 32 + 8 * g + 4 * lh) = v;
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (geglu) {
+      if constexpr (TN == 2) {
+        // 64 output columns per tile: octet o -> packed group G = o>>2 ('a' rows 64G.., gate rows 64G+32..)
+        const int o = t & 7, G = o >> 2, jj = (o & 3) * 8;
+        const int na = n0 + 64 * G + jj;
+        float ba[8], bg[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 x0 = *(const f32x4*)(p.bias + na + 4 * q), x1 = *(const f32x4*)(p.bias + na + 32 + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ba[4 * q + e] = x0[e]; bg[4 * q + e] = x1[e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          asm volatile("" ::: "memory");
+          const int r = (t >> 3) + 32 * k;
+          const int m = m0 + r;
+          if (m >= p.M) continue;
+          const float* ta = tile + r * LDT + 64 * G + jj;
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x4 av = *(const f32x4*)(ta + 4 * q), gv = *(const f32x4*)(ta + 32 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = (av[e] + ba[4 * q + e]) * gelu_erf_f(gv[e] + bg[4 * q + e]);
+          }
+          *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + (n0 >> 1) + 32 * G + jj) = pack_bf8(v);
+        }
+      }
+    } else {
+      constexpr int OC = BN / 8;                       // octets per tile row; 256 % OC == 0 so o is fixed per thread
+      const int o = t % OC, n = n0 + o * 8;
+      if (n < p.N) {
+        float bs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+        if (p.bias) {
+          const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
+        }
+        u32x4 rv[OCT];
+        if (p.res) {
+#pragma unroll
+          for (int k = 0; k < OCT; ++k) {
+            int m = m0 + t / OC + (256 / OC) * k; if (m >= p.M) m = p.M - 1;
+            rv[k] = *(const u32x4*)(p.res + (size_t)m * p.ldres + n);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < OCT; ++k) {
+          asm volatile("" ::: "memory");               // keep each item's LDS reads in its own iteration (VGPR pressure)
+          const int r = t / OC + (256 / OC) * k;
+          const int m = m0 + r;
+          if (m >= p.M) continue;
+          const f32x4 v0 = *(const f32x4*)(tile + r * LDT + o * 8), v1 = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bs[e]; v[4 + e] = v1[e] + bs[4 + e]; }
+          if (p.res) {
+            float rf[8]; unpack_bf8(rv[k], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          }
+          *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + n) = pack_bf8(v);
+        }
+      }
+    }
+  } else if (p.geglu) {
     if constexpr (TN == 2) {
       // packed weight rows: [32 'a' rows | 32 matching 'b' rows] per 64-row group
 #pragma unroll
@@ -236,9 +382,7 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
         }
       }
     }
-    return;
-  }
-
+  } else {
   const bool vec_ok = ((p.N & 3) == 0) && ((p.ldo & 3) == 0);
 #pragma unroll
   for (int a = 0; a < TN; ++a)
@@ -287,6 +431,11 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
         }
       }
     }
+  }
+  if (p.timing && t == 0) {        // probe build aid: per-block timeline in 10 ns ticks (s_memrealtime)
+    long long* o = p.timing + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    o[0] = tm0; o[1] = tm1; o[2] = tm2; o[3] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // split-K second pass: sum partials in fixed order, then the same epilogue.
@@ -327,41 +476,48 @@ int dmx_zero_page(const bf16** out) {
   if (!g_zero_page) {
     void* z = nullptr;
     DMX_HIP(hipMalloc(&z, 4096));
-    DMX_HIP(hipMemset(z, 0, 4096));
+    DMX_HIP(hipMemset(z, 0, 4096));   // staging pointers into this page never advance (increment 0)
     g_zero_page = (const bf16*)z;
   }
   *out = g_zero_page;
   return DMX_OK;
 }
 
-static int pick_tn(const GemmArgs& a) {
-  if (a.geglu) return 2;
-  if (a.N <= 64) return 1;
-  const int r = a.N % 128;
-  if (r != 0 && r <= 64) {                       // e.g. 320, 960: 64-wide tiles waste nothing
-    return 1;
-  }
-  // occupancy: prefer 64-wide tiles when 128-wide ones cannot fill the chip
-  const long blocks128 = (long)cdiv(a.M, BM) * cdiv(a.N, 128);
-  if (blocks128 < 192 && a.K <= 1024) return 1;
-  return 2;
+// Tile / split-K plan.  The chip holds 256 CUs x 2 resident blocks; the UNet's GEMMs are small next to that
+// (M = 256..16384 rows), so the plan trades tile efficiency (128x128 does 8 MFMAs per barrier, 128x64 only 4)
+// against filling the CUs, with split-K (fp32 partials + a reduce pass) when even 64-wide tiles leave CUs idle.
+// Costs are in units of one 128x128x32 K-tile step.
+static double plan_cost(const GemmArgs& a, int tn, int sk) {
+  const int nkt = a.K / BK;
+  const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, 64 * tn);
+  const long nb = tiles * sk;
+  const double per_tile = tn == 2 ? 1.0 : 0.78;      // measured: 64-wide tiles run at ~0.65x the FLOP rate
+  const double t_block = (cdiv(nkt, sk) + 6) * per_tile;
+  double rounds = (double)((nb + 255) / 256);                 // blocks per CU, executed back to back
+  if (nb <= 256) rounds = 1.2;                                // a lone block per CU does not hide its own latency
+  double t = rounds * t_block;
+  if (sk > 1) t += 45.0 + ((double)a.M * a.N * 4.0 * (sk + 1) / 5.0e12) / 0.14e-6;
+  return t;
 }
 
 void dmx_gemm_plan(const GemmArgs& a, int* tn_out, int* splitk_out, int* ktps_out) {
-  const int tn = pick_tn(a);
-  const int bn = 64 * tn;
-  const long blocks = (long)cdiv(a.M, BM) * cdiv(a.N, bn);
   const int nkt = a.K / BK;
-  int splitk = 1;
-  if (!a.geglu && (a.N % 4) == 0 && blocks < 160 && nkt >= 8) {
-    splitk = (int)((384 + blocks - 1) / blocks);
-    if (splitk > nkt / 4) splitk = nkt / 4;
-    if (splitk > 16) splitk = 16;
-    if (splitk < 1) splitk = 1;
+  int best_tn = 2, best_sk = 1; double best = 1e300;
+  for (int tn = 2; tn >= 1; --tn) {
+    if (a.geglu && tn != 2) continue;
+    if (a.force_tn && tn != a.force_tn) continue;
+    if (tn == 2 && a.N <= 64 && !a.force_tn) continue;
+    const int max_sk = (a.geglu || (a.N % 4) != 0) ? 1 : 16;
+    for (int sk = 1; sk <= max_sk; ++sk) {
+      if (a.force_splitk && sk != a.force_splitk) continue;
+      if (sk > 1 && nkt / sk < 8) break;
+      const double c = plan_cost(a, tn, sk);
+      if (c < best) { best = c; best_tn = tn; best_sk = sk; }
+    }
   }
-  int ktps = cdiv(nkt, splitk);
-  splitk = cdiv(nkt, ktps);
-  *tn_out = tn; *splitk_out = splitk; *ktps_out = ktps;
+  int ktps = cdiv(nkt, best_sk);
+  best_sk = cdiv(nkt, ktps);
+  *tn_out = best_tn; *splitk_out = best_sk; *ktps_out = ktps;
 }
 
 size_t dmx_gemm_workspace_bytes(const GemmArgs& a) {
@@ -393,17 +549,21 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   }
   const int bn = 64 * tn;
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, bn), sk, 1);
-  const size_t lds = 2 * (size_t)(BM * BK * 2 + bn * BK * 2);
+  size_t lds = NSTAGE * (size_t)(BM * BK * 2 + bn * BK * 2);
+  const size_t lds_epi = (size_t)BM * (bn + 4) * sizeof(float);       // fp32 staging tile of the coalesced epilogue
+  if (lds_epi > lds) lds = lds_epi;
   // algorithmic work of this launch: 2*M*N*K flops; bytes = activations read once + weights + output
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = 2.0 * ((double)a.M * (a.K / (a.direct ? 1 : (a.ksize * a.ksize))) + (double)a.N * a.K + (double)a.M * (a.geglu ? a.N / 2 : a.N));
+  char tag[96];
+  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, tn, sk);
   if (tn == 2) {
-    ProfScope ps(PROF_GEMM128, stream, flops, bytes);
+    ProfScope ps(PROF_GEMM128, stream, flops, bytes, tag);
     static bool attr2 = false;
     if (!attr2) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
     hipLaunchKernelGGL(dmx_gemm_kernel<2>, grid, dim3(256), lds, stream, a);
   } else {
-    ProfScope ps(PROF_GEMM64, stream, flops, bytes);
+    ProfScope ps(PROF_GEMM64, stream, flops, bytes, tag);
     static bool attr1 = false;
     if (!attr1) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
     hipLaunchKernelGGL(dmx_gemm_kernel<1>, grid, dim3(256), lds, stream, a);

@@ -7,7 +7,7 @@
 enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN = 3, PROF_GNORM = 4, PROF_LNORM = 5,
                  PROF_OTHER = 6, PROF_NCLASS = 7 };
 struct ProfScope {
-  ProfScope(ProfClass c, hipStream_t s, double flops, double bytes);
+  ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag = nullptr);
   ~ProfScope();
   int slot = -1;
   hipStream_t stream_ = nullptr;
@@ -32,6 +32,8 @@ struct GemmArgs {
   int rows_per_group, ldrb;
   const bf16* res; int ldres;   // residual or null
   void* out; int ldo; int out_f32; int geglu;
+  int force_tn, force_splitk;                  // 0 = automatic
+  long long* timing;                           // optional per-block timeline (probe builds), normally null
   float* partial; int splitk, kt_per_split;   // filled by the launcher
   const bf16* zeros;                           // filled by the launcher
 };
@@ -47,9 +49,9 @@ struct GroupNormArgs {
   const float* gamma; const float* beta; float eps; int silu;
   bf16* y; int ldy;
   float* partial;     // [B][nchunk][groups][2]
+  float* coef;        // [B][C][2] (filled by the launcher: lives behind partial in the workspace)
   int nchunk, rows_per_chunk;
 };
-int dmx_groupnorm_chunks(int HW);
 size_t dmx_gn_workspace_bytes(int B, int HW, int groups);
 int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream);
 int dmx_layernorm_launch(const bf16* x, int ldx, bf16* y, int ldy, const float* gamma, const float* beta,

@@ -2,11 +2,13 @@
 //
 // Both are HBM-bound: every load/store is 16 B per lane (8 bf16), statistics in fp32.
 //
-// GroupNorm is two launches and deterministic (no float atomics):
-//   stats : grid (nchunk, B); each block reduces rows_per_chunk pixels x C channels to
-//           per-group (sum, sumsq) partials  -> partial[b][chunk][g][2]
-//   apply : grid (row blocks, B); prologue folds the <=256 partials of its sample in fixed
-//           order into per-channel scale/shift in LDS, then y = x*a + b (+SiLU), bf16 out.
+// GroupNorm is three launches and deterministic (no float atomics):
+//   stats    : grid (nchunk, B); each block reduces rows_per_chunk pixels x C channels to
+//              per-group (sum, sumsq) partials  -> partial[b][chunk][g][2]
+//   finalize : grid (B); folds the <=256 partials of a sample in fixed order and writes the
+//              per-channel affine (a = rstd*gamma, b = beta - mean*a)
+//   apply    : grid (row blocks, B); y = x*a + b (+SiLU), bf16 out; the thread's 8 channels'
+//              coefficients stay in registers, 4 rows in flight per thread.
 // The input may be the virtual channel-concat of two tensors (UNet skip connections), so
 // torch.cat([h, skip], 1) is never materialised.
 #include "common.h"
@@ -16,7 +18,8 @@ __device__ __forceinline__ const bf16* gn_src(const GroupNormArgs& p, size_t row
   return (c < p.c0) ? (p.x0 + row * p.ldx0 + c) : (p.x1 + row * p.ldx1 + (c - p.c0));
 }
 
-__global__ __launch_bounds__(320) void dmx_gn_stats_kernel(const GroupNormArgs p) {
+// stats: thread = (row lane r, channel octet co); 4 rows in flight per thread
+__global__ __launch_bounds__(1024) void dmx_gn_stats_kernel(const GroupNormArgs p) {
   extern __shared__ float sm[];          // [R][C] sums, [R][C] sumsq, then [C] x2
   const int oc = p.C >> 3;               // octets per row
   const int R = blockDim.x / oc;
@@ -28,19 +31,28 @@ __global__ __launch_bounds__(320) void dmx_gn_stats_kernel(const GroupNormArgs p
   float s[8], ss[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
-  if (r < R) {
-    for (int row = row0 + r; row < row1; row += R) {
-      const u32x4 v = *(const u32x4*)gn_src(p, (size_t)b * p.HW + row, co * 8);
-      float f[8]; unpack_bf8(v, f);
+  const size_t base = (size_t)b * p.HW;
+  int row = row0 + r;
+  for (; row + 3 * R < row1; row += 4 * R) {
+    u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *(const u32x4*)gn_src(p, base + row + j * R, co * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f[8]; unpack_bf8(v[j], f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s[i] += f[i]; ss[i] += f[i] * f[i]; }
     }
   }
-  float* S = sm; float* SS = sm + R * p.C;
-  if (r < R) {
+  for (; row < row1; row += R) {
+    const u32x4 v = *(const u32x4*)gn_src(p, base + row, co * 8);
+    float f[8]; unpack_bf8(v, f);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { S[r * p.C + co * 8 + i] = s[i]; SS[r * p.C + co * 8 + i] = ss[i]; }
+    for (int i = 0; i < 8; ++i) { s[i] += f[i]; ss[i] += f[i] * f[i]; }
   }
+  float* S = sm; float* SS = sm + R * p.C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { S[r * p.C + co * 8 + i] = s[i]; SS[r * p.C + co * 8 + i] = ss[i]; }
   __syncthreads();
   float* CS = sm + 2 * R * p.C; float* CSS = CS + p.C;
   for (int c = t; c < p.C; c += blockDim.x) {
@@ -58,16 +70,26 @@ __global__ __launch_bounds__(320) void dmx_gn_stats_kernel(const GroupNormArgs p
   }
 }
 
-__global__ __launch_bounds__(256) void dmx_gn_apply_kernel(const GroupNormArgs p, int rows_per_block) {
-  extern __shared__ float sm[];          // [C] scale, [C] shift, [groups] mean, [groups] rstd
-  float* A = sm; float* Bs = sm + p.C; float* MEAN = Bs + p.C; float* RSTD = MEAN + p.groups;
-  const int t = threadIdx.x;
-  const int b = blockIdx.y;
-  const int cpg = p.C / p.groups;
-  if (t < p.groups) {
+// finalize: one block per sample folds the partials in a fixed order (deterministic) and writes the
+// per-channel affine  y = x*a + b  with a = rstd*gamma, b = beta - mean*a  -> coef[b][c][2]
+__global__ __launch_bounds__(256) void dmx_gn_finalize_kernel(const GroupNormArgs p) {
+  __shared__ float red[2][8][64];
+  __shared__ float MEAN[64], RSTD[64];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int G = p.groups;
+  const int slices = 256 / G > 8 ? 8 : 256 / G;       // G <= 64 -> >= 4 slices
+  const int g = t % G, sl = t / G;
+  if (sl < slices) {
     float a = 0.f, q = 0.f;
-    const float* pp = p.partial + ((size_t)b * p.nchunk * p.groups + t) * 2;
-    for (int k = 0; k < p.nchunk; ++k) { a += pp[(size_t)k * p.groups * 2]; q += pp[(size_t)k * p.groups * 2 + 1]; }
+    const float* pp = p.partial + ((size_t)b * p.nchunk * G + g) * 2;
+    for (int k = sl; k < p.nchunk; k += slices) { a += pp[(size_t)k * G * 2]; q += pp[(size_t)k * G * 2 + 1]; }
+    red[0][sl][g] = a; red[1][sl][g] = q;
+  }
+  __syncthreads();
+  const int cpg = p.C / G;
+  if (t < G) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < slices; ++k) { a += red[0][k][t]; q += red[1][k][t]; }
     const float inv_n = 1.0f / ((float)p.HW * (float)cpg);
     const float mean = a * inv_n;
     float var = q * inv_n - mean * mean;
@@ -75,111 +97,156 @@ __global__ __launch_bounds__(256) void dmx_gn_apply_kernel(const GroupNormArgs p
     MEAN[t] = mean; RSTD[t] = rsqrtf(var + p.eps);
   }
   __syncthreads();
-  for (int c = t; c < p.C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float a = RSTD[g] * p.gamma[c];
-    A[c] = a; Bs[c] = p.beta[c] - MEAN[g] * a;
+  float* coef = p.coef + (size_t)b * p.C * 2;
+  for (int c = t; c < p.C; c += 256) {
+    const int gg = c / cpg;
+    const float a = RSTD[gg] * p.gamma[c];
+    coef[2 * c] = a; coef[2 * c + 1] = p.beta[c] - MEAN[gg] * a;
   }
-  __syncthreads();
+}
+
+// apply: same thread mapping as stats; each thread keeps its 8 channels' (a, b) in registers
+__global__ __launch_bounds__(1024) void dmx_gn_apply_kernel(const GroupNormArgs p, int rows_per_block) {
   const int oc = p.C >> 3;
+  const int R = blockDim.x / oc;
+  const int t = threadIdx.x;
+  const int r = t / oc, co = t - r * oc;
+  const int b = blockIdx.y;
   const int row0 = blockIdx.x * rows_per_block;
-  const int nrow = min(rows_per_block, p.HW - row0);
-  const int total = nrow * oc;
-  for (int idx = t; idx < total; idx += blockDim.x) {
-    const int rr = idx / oc, co = idx - rr * oc;
-    const size_t row = (size_t)b * p.HW + row0 + rr;
-    const int c = co * 8;
-    const u32x4 v = *(const u32x4*)gn_src(p, row, c);
+  const int row1 = min(row0 + rows_per_block, p.HW);
+  float A[8], Bv[8];
+  {
+    const f32x4* cp = (const f32x4*)(p.coef + ((size_t)b * p.C + co * 8) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const f32x4 v = cp[j]; A[2 * j] = v[0]; Bv[2 * j] = v[1]; A[2 * j + 1] = v[2]; Bv[2 * j + 1] = v[3]; }
+  }
+  const size_t base = (size_t)b * p.HW;
+  int row = row0 + r;
+  for (; row + 3 * R < row1; row += 4 * R) {
+    u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *(const u32x4*)gn_src(p, base + row + j * R, co * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f[8]; unpack_bf8(v[j], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { float y = f[i] * A[i] + Bv[i]; f[i] = p.silu ? silu_f(y) : y; }
+      *(u32x4*)(p.y + (base + row + j * R) * p.ldy + co * 8) = pack_bf8(f);
+    }
+  }
+  for (; row < row1; row += R) {
+    const u32x4 v = *(const u32x4*)gn_src(p, base + row, co * 8);
     float f[8]; unpack_bf8(v, f);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float y = f[i] * A[c + i] + Bs[c + i];
-      if (p.silu) y = silu_f(y);
-      f[i] = y;
-    }
-    *(u32x4*)(p.y + row * p.ldy + c) = pack_bf8(f);
+    for (int i = 0; i < 8; ++i) { float y = f[i] * A[i] + Bv[i]; f[i] = p.silu ? silu_f(y) : y; }
+    *(u32x4*)(p.y + (base + row) * p.ldy + co * 8) = pack_bf8(f);
   }
 }
 
-int dmx_groupnorm_chunks(int HW) {
-  int n = cdiv(HW, 64);          // 64 pixels per stats block, at most 256 partials per sample
-  if (n > 256) n = 256;
-  return n;
-}
-
+#define GN_MAX_CHUNKS 256
 size_t dmx_gn_workspace_bytes(int B, int HW, int groups) {
-  return (size_t)B * dmx_groupnorm_chunks(HW) * groups * 2 * sizeof(float);
+  // partials [B][<=256 chunks][groups][2] + per-channel affine [B][C<=2560][2]
+  (void)HW;
+  return (size_t)B * GN_MAX_CHUNKS * groups * 2 * sizeof(float) + (size_t)B * 2560 * 2 * sizeof(float);
 }
 
 int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream) {
   DMX_REQUIRE(a.C % 8 == 0 && a.C % a.groups == 0, "groupnorm: C=%d must be a multiple of 8 and of groups=%d", a.C, a.groups);
-  DMX_REQUIRE(a.C <= 2560 && a.groups <= 64, "groupnorm: C=%d > 2560 unsupported", a.C);
+  DMX_REQUIRE(a.C <= 2560 && a.groups <= 64, "groupnorm: C=%d > 2560 or groups > 64 unsupported", a.C);
   DMX_REQUIRE(a.c0 % 8 == 0 && a.ldx0 % 8 == 0 && a.ldy % 8 == 0, "groupnorm: strides/splits must be multiples of 8");
   DMX_REQUIRE(a.partial != nullptr, "groupnorm: partial workspace is null");
   if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; }
-  a.nchunk = dmx_groupnorm_chunks(a.HW);
-  a.rows_per_chunk = cdiv(a.HW, a.nchunk);
-  a.nchunk = cdiv(a.HW, a.rows_per_chunk);
+  // thread = (row lane r < R, channel octet); wide blocks so each thread walks only a few rows
   const int oc = a.C / 8;
-  int R = 256 / oc; if (R < 1) R = 1;
+  int R = 1024 / oc; if (R > 16) R = 16; if (R < 1) R = 1;
   const int threads = oc * R;
+  int rpc = 4 * R;                                                  // rows per stats block: 4 per thread
+  if (cdiv(a.HW, rpc) > GN_MAX_CHUNKS) rpc = cdiv(cdiv(a.HW, GN_MAX_CHUNKS), R) * R;
+  a.rows_per_chunk = rpc;
+  a.nchunk = cdiv(a.HW, rpc);
+  a.coef = (float*)((char*)a.partial + (size_t)a.B * GN_MAX_CHUNKS * a.groups * 2 * sizeof(float));
   const size_t lds_stats = (size_t)(2 * R * a.C + 2 * a.C) * sizeof(float);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gn_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gn_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
   hipLaunchKernelGGL(dmx_gn_stats_kernel, dim3(a.nchunk, a.B), dim3(threads), lds_stats, stream, a);
   int rc = dmx_check_launch("dmx_gn_stats_kernel");
   if (rc) return rc;
-  int rpb = a.HW <= 1024 ? 16 : (a.HW <= 4096 ? 32 : 64);
-  if (a.C <= 256) rpb *= 4;
-  const size_t lds_apply = (size_t)(2 * a.C + 2 * a.groups) * sizeof(float);
-  hipLaunchKernelGGL(dmx_gn_apply_kernel, dim3(cdiv(a.HW, rpb), a.B), dim3(256), lds_apply, stream, a, rpb);
+  hipLaunchKernelGGL(dmx_gn_finalize_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  rc = dmx_check_launch("dmx_gn_finalize_kernel");
+  if (rc) return rc;
+  int rpb = 8 * R;                                                  // up to 8 rows per thread in apply
+  while (rpb > R && (long)cdiv(a.HW, rpb) * a.B < 512) rpb -= R;
+  hipLaunchKernelGGL(dmx_gn_apply_kernel, dim3(cdiv(a.HW, rpb), a.B), dim3(threads), 0, stream, a, rpb);
   return dmx_check_launch("dmx_gn_apply_kernel");
 }
 
 // ---------------------------------------------------------------------------- LayerNorm
-// One wave per row; the row lives in registers (<= 4 octets per lane, C <= 2048).
+// One wave per row, LN_ROWS rows per wave with all their loads issued up front (memory-level parallelism);
+// a row lives in registers (<= 4 octets per lane, C <= 2048).
+#define LN_ROWS 1
 __global__ __launch_bounds__(256) void dmx_layernorm_kernel(const bf16* x, int ldx, bf16* y, int ldy,
                                                             const float* gamma, const float* beta,
                                                             int rows, int C, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+  if (row0 >= rows) return;
   const int oc = C >> 3;
-  float f[4][8];
-  float s = 0.f;
+  const int nj = (oc + 63) >> 6;              // octets per lane (1..4)
+  u32x4 raw[LN_ROWS][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int o = lane + 64 * j;
-    if (o < oc) {
-      const u32x4 v = *(const u32x4*)(x + (size_t)row * ldx + o * 8);
-      unpack_bf8(v, f[j]);
+  for (int r = 0; r < LN_ROWS; ++r) {
+    int row = row0 + r; if (row >= rows) row = rows - 1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += f[j][i];
+    for (int j = 0; j < 4; ++j) {
+      const int o = lane + 64 * j;
+      if (j < nj && o < oc) raw[r][j] = *(const u32x4*)(x + (size_t)row * ldx + o * 8);
     }
   }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-  const float mean = s / (float)C;
-  float q = 0.f;
+  for (int r = 0; r < LN_ROWS; ++r) {
+    const int row = row0 + r;
+    float f[4][8];
+    float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int o = lane + 64 * j;
-    if (o < oc) {
+    for (int j = 0; j < 4; ++j) {
+      const int o = lane + 64 * j;
+      if (j < nj && o < oc) {
+        unpack_bf8(raw[r][j], f[j]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const float d = f[j][i] - mean; q += d * d; }
+        for (int i = 0; i < 8; ++i) s += f[j][i];
+      }
     }
-  }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d);
-  const float rstd = rsqrtf(q / (float)C + eps);
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    const float mean = s / (float)C;
+    float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int o = lane + 64 * j;
-    if (o < oc) {
-      float g[8];
+    for (int j = 0; j < 4; ++j) {
+      const int o = lane + 64 * j;
+      if (j < nj && o < oc) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) g[i] = (f[j][i] - mean) * rstd * gamma[o * 8 + i] + beta[o * 8 + i];
-      *(u32x4*)(y + (size_t)row * ldy + o * 8) = pack_bf8(g);
+        for (int i = 0; i < 8; ++i) { const float d = f[j][i] - mean; q += d * d; }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (row < rows) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = lane + 64 * j;
+        if (j < nj && o < oc) {
+          float g[8];
+          const f32x4 g0 = *(const f32x4*)(gamma + o * 8), g1 = *(const f32x4*)(gamma + o * 8 + 4);
+          const f32x4 b0 = *(const f32x4*)(beta + o * 8), b1 = *(const f32x4*)(beta + o * 8 + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            g[i] = (f[j][i] - mean) * rstd * g0[i] + b0[i];
+            g[4 + i] = (f[j][4 + i] - mean) * rstd * g1[i] + b1[i];
+          }
+          *(u32x4*)(y + (size_t)row * ldy + o * 8) = pack_bf8(g);
+        }
+      }
     }
   }
 }
@@ -188,7 +255,7 @@ int dmx_layernorm_launch(const bf16* x, int ldx, bf16* y, int ldy, const float* 
                          int rows, int C, float eps, hipStream_t stream) {
   DMX_REQUIRE(C % 8 == 0 && C <= 2048, "layernorm: C=%d must be a multiple of 8 and <= 2048", C);
   DMX_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "layernorm: strides must be multiples of 8");
-  hipLaunchKernelGGL(dmx_layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, y, ldy, gamma, beta, rows, C, eps);
+  hipLaunchKernelGGL(dmx_layernorm_kernel, dim3(cdiv(rows, 4 * LN_ROWS)), dim3(256), 0, stream, x, ldx, y, ldy, gamma, beta, rows, C, eps);
   return dmx_check_launch("dmx_layernorm_kernel");
 }
 

@@ -14,7 +14,9 @@
 //   - all 22 time_emb_proj Linear layers: one GEMV launch
 //   - cross-attention K / V^T of the glyph context computed once per image (set_context)
 #include <math.h>
+#include <map>
 #include <memory>
+#include <tuple>
 #include "exec.h"
 #include "../../include/diffute_hip.h"
 
@@ -42,6 +44,13 @@ struct dmx_unet {
   ResW mid_res[2]; XfW mid_xf;
   std::vector<XfW*> xf_all;          // cross-attention layers in graph order (context cache slots)
   bool finalized = false;
+  // hipGraph cache: one captured UNet step per distinct argument tuple (pointers are baked into the nodes)
+  typedef std::tuple<const void*, const void*, const void*, const void*, const void*, const void*, const void*,
+                     int, int, int, int, int, int, int, int> GraphKey;
+  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
+  std::map<GraphKey, GraphEntry> graphs;
+  void drop_graphs() { for (auto& kv : graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); graphs.clear(); }
+  ~dmx_unet() { drop_graphs(); }
 
   template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
 };
@@ -181,7 +190,7 @@ extern "C" int dmx_unet_param_info(const dmx_unet* u, int index, const char** na
 extern "C" size_t dmx_unet_arena_bytes(const dmx_unet* u) { return u ? u->pt.total() : 0; }
 extern "C" int dmx_unet_bind_arena(dmx_unet* u, void* arena, size_t bytes) {
   DMX_REQUIRE(u && arena && bytes >= u->pt.total(), "unet_bind_arena: need %zu bytes", u ? u->pt.total() : (size_t)0);
-  u->arena = (char*)arena; u->finalized = false;
+  u->arena = (char*)arena; u->finalized = false; u->drop_graphs();
   DMX_HIP(hipMemset(arena, 0, u->pt.total()));      // zero the K padding of conv_in
   return DMX_OK;
 }
@@ -201,7 +210,10 @@ extern "C" int dmx_unet_finalize(dmx_unet* u, const float* h_freq, dmx_stream_t 
   for (int i = 0; i < 4 && !rc; ++i) { for (auto& r : u->down_res[i]) if (!rc) rc = fuse(r); for (auto& r : u->up_res[i]) if (!rc) rc = fuse(r); }
   if (!rc) rc = fuse(u->mid_res[0]); if (!rc) rc = fuse(u->mid_res[1]);
   DMX_HIP(hipStreamSynchronize(s));
+  const bf16* zp = nullptr;
+  if (!rc) rc = dmx_zero_page(&zp);                  // allocate the padding page now, never inside a stream capture
   u->finalized = (rc == 0);
+  u->drop_graphs();
   return rc;
 }
 
@@ -397,4 +409,39 @@ extern "C" int dmx_unet_forward(dmx_unet* u, const float* f0, int c0, const floa
   DMX_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "unet_forward: H=%d W=%d must be positive multiples of 8", H, W);
   Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
   return unet_run(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
+}
+
+// Same contract as dmx_unet_forward, but the launch sequence (~600 kernels) is captured into a hipGraph the second
+// time an identical argument tuple is seen and replayed afterwards (one hipGraphLaunch per UNet step).  Needs a
+// non-default stream (the legacy NULL stream cannot be captured); falls back to eager launches otherwise or while
+// the profiler is recording.
+bool dmx_profile_active();
+extern "C" int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                                      const int64_t* timesteps, int t_count, const void* cache, int ctx_len,
+                                      float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->finalized, "unet_forward_graph: weights not finalized");
+  if (stream == nullptr || dmx_profile_active())
+    return dmx_unet_forward(u, f0, c0, f1, c1, f2, c2, timesteps, t_count, cache, ctx_len, out, B, H, W, workspace, workspace_bytes, stream);
+  dmx_unet::GraphKey key(f0, f1, f2, timesteps, cache, out, workspace, c0, c1, c2, t_count, ctx_len, B, H, W);
+  dmx_unet::GraphEntry& e = u->graphs[key];
+  hipStream_t s = (hipStream_t)stream;
+  if (e.exec) { DMX_HIP(hipGraphLaunch(e.exec, s)); return DMX_OK; }
+  if (e.seen++ == 0)        // first sight: eager (also runs every one-time hipFuncSetAttribute outside a capture)
+    return dmx_unet_forward(u, f0, c0, f1, c1, f2, c2, timesteps, t_count, cache, ctx_len, out, B, H, W, workspace, workspace_bytes, stream);
+  if (u->graphs.size() > 64) { u->graphs.erase(key); u->drop_graphs(); }
+  DMX_REQUIRE(f0 && out && timesteps && cache && workspace, "unet_forward_graph: null argument");
+  DMX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  Exec ex; ex.stream = s; ex.ws.reset(workspace, workspace_bytes, false);
+  const int rc = unet_run(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
+  hipGraph_t g = nullptr;
+  const hipError_t ce = hipStreamEndCapture(s, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (ce != hipSuccess || !g) { dmx_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return DMX_ERR_HIP; }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ie != hipSuccess) { dmx_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ie)); return DMX_ERR_HIP; }
+  u->graphs[key].exec = exec;
+  DMX_HIP(hipGraphLaunch(exec, s));
+  return DMX_OK;
 }

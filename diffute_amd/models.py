@@ -282,10 +282,11 @@ class UNet2DConditionModel(_HipModel):
                          encoder_hidden_states.dtype)
         self._ctx_shape = (B, S)
 
-    def forward_parts(self, parts, timesteps_dev, out=None):
+    def forward_parts(self, parts, timesteps_dev, out=None, graph=False):
         """Hot-loop entry: `parts` = list of (NCHW fp32 cuda tensor) whose channels sum to in_channels
         (fuses the torch.cat of app.ipynb:811); timesteps_dev = int64 cuda tensor [1] or [B];
-        context must have been set with set_context()."""
+        context must have been set with set_context().  graph=True replays a captured hipGraph when the same
+        buffers are passed again (needs a non-default current stream)."""
         lib = _cabi.lib()
         x0 = parts[0]
         B, _, H, W = x0.shape
@@ -299,7 +300,8 @@ class UNet2DConditionModel(_HipModel):
         if wsb is None or wsb[0] != key:
             self._ws_need = wsb = (key, lib.dmx_unet_workspace_bytes(self._h, B, H, W, self._ctx_shape[1]))
         ws = self._workspace(wsb[1])
-        _cabi.check(lib.dmx_unet_forward(self._h, _cabi.ptr(ps[0][0]), ps[0][1], _cabi.ptr(ps[1][0]), ps[1][1],
+        fwd = lib.dmx_unet_forward_graph if graph else lib.dmx_unet_forward
+        _cabi.check(fwd(self._h, _cabi.ptr(ps[0][0]), ps[0][1], _cabi.ptr(ps[1][0]), ps[1][1],
                                          _cabi.ptr(ps[2][0]), ps[2][1], _cabi.ptr(timesteps_dev), timesteps_dev.numel(),
                                          _cabi.ptr(self._ctx_cache), self._ctx_shape[1], _cabi.ptr(out), B, H, W,
                                          _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_forward")

@@ -11,6 +11,16 @@ from . import _cabi
 from .schedulers import DDIMScheduler, DDPMScheduler
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def mask_to_latent(mask, vae_scale_factor=8):
     """F.interpolate(mask, size=(H/8, W/8)) with the default nearest mode (app.ipynb:787-791,
     train_diffute_v1.py:880-884): out[y, x] = in[floor(y*8), floor(x*8)]."""
@@ -19,7 +29,7 @@ def mask_to_latent(mask, vae_scale_factor=8):
 
 @torch.no_grad()
 def denoise(unet, scheduler, latents, mask, masked_image_latents, encoder_hidden_states,
-            num_inference_steps, variance_noise=None, eta=0.0, callback=None):
+            num_inference_steps, variance_noise=None, eta=0.0, callback=None, use_graph=True):
     """latents/masked_image_latents [B,4,h,w], mask [B,1,h,w] (already at latent resolution), context
     [B,S,1024]; all on the GPU.  variance_noise: optional [steps,B,4,h,w] injected in place of the
     per-step device randn of DDPMScheduler.step (app.ipynb:816).  Returns the final latents (fp32)."""
@@ -34,29 +44,36 @@ def denoise(unet, scheduler, latents, mask, masked_image_latents, encoder_hidden
     m = mask.to(torch.float32).contiguous()
     ml = masked_image_latents.to(torch.float32).contiguous()
     eps = torch.empty_like(x)
-    x_next = torch.empty_like(x)
+    t_cur = torch.empty(1, dtype=torch.int64, device=x.device)        # fixed address: the captured graph reads it
     is_ddim = isinstance(scheduler, DDIMScheduler)
     vpred = int(scheduler.config.prediction_type == "v_prediction")
-    st = _cabi.current_stream()
-    for i, t in enumerate(ts_host):
-        unet.forward_parts([x, m, ml], ts_dev[i:i + 1], out=eps)
-        if is_ddim:
-            sbt, sat, sap, dirc, std = scheduler.step_coefficients(t, eta)
-            nz = None
-            if eta > 0:
-                nz = (variance_noise[i] if variance_noise is not None else torch.randn_like(x)).to(torch.float32).contiguous()
-            _cabi.check(lib.dmx_sched_step_ddim(_cabi.ptr(x), _cabi.ptr(eps), _cabi.ptr(nz), _cabi.ptr(x_next), x.numel(),
-                                                sbt, sat, sap, dirc, std, vpred, st), "sched_step_ddim")
-        else:
-            sbt, sat, c0, c1, sigma = scheduler.step_coefficients(t)
-            nz = None
-            if t > 0:
-                nz = (variance_noise[i] if variance_noise is not None else torch.randn_like(x)).to(torch.float32).contiguous()
-            _cabi.check(lib.dmx_sched_step_ddpm(_cabi.ptr(x), _cabi.ptr(eps), _cabi.ptr(nz), _cabi.ptr(x_next), x.numel(),
-                                                sbt, sat, c0, c1, sigma, vpred, st), "sched_step_ddpm")
-        x, x_next = x_next, x
-        if callback is not None:
-            callback(i, t, x, eps)
+    # the step loop runs on a side stream: hipGraph capture / replay needs a non-default stream
+    main = torch.cuda.current_stream(x.device)
+    side = _side_stream(x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        st = _cabi.current_stream()
+        for i, t in enumerate(ts_host):
+            t_cur.copy_(ts_dev[i:i + 1], non_blocking=True)
+            unet.forward_parts([x, m, ml], t_cur, out=eps, graph=use_graph)
+            # the update is elementwise, so prev_sample overwrites the sample in place (stable pointers for the graph)
+            if is_ddim:
+                sbt, sat, sap, dirc, std = scheduler.step_coefficients(t, eta)
+                nz = None
+                if eta > 0:
+                    nz = (variance_noise[i] if variance_noise is not None else torch.randn_like(x)).to(torch.float32).contiguous()
+                _cabi.check(lib.dmx_sched_step_ddim(_cabi.ptr(x), _cabi.ptr(eps), _cabi.ptr(nz), _cabi.ptr(x), x.numel(),
+                                                    sbt, sat, sap, dirc, std, vpred, st), "sched_step_ddim")
+            else:
+                sbt, sat, c0, c1, sigma = scheduler.step_coefficients(t)
+                nz = None
+                if t > 0:
+                    nz = (variance_noise[i] if variance_noise is not None else torch.randn_like(x)).to(torch.float32).contiguous()
+                _cabi.check(lib.dmx_sched_step_ddpm(_cabi.ptr(x), _cabi.ptr(eps), _cabi.ptr(nz), _cabi.ptr(x), x.numel(),
+                                                    sbt, sat, c0, c1, sigma, vpred, st), "sched_step_ddpm")
+            if callback is not None:
+                callback(i, t, x, eps)
+    main.wait_stream(side)
     return x
 
 

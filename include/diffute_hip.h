@@ -68,6 +68,9 @@ typedef struct dmx_gemm_desc {
   const void* res; int ldres;       /* bf16 residual or NULL                                 */
   void* out; int ldo; int out_f32;  /* bf16 (default) or fp32 output                         */
   int geglu;                        /* 1: weights/bias GEGLU-packed, out[m][j] = a*gelu(b)   */
+  int force_tn, force_splitk;       /* 0 = automatic plan; tuning / tests may pin the tile (1|2) and split */
+  long long* timing;                /* optional device buffer [blocks][4]: per-block start / prologue / loop / end
+                                       timestamps in 10 ns ticks (measurement aid), normally NULL */
 } dmx_gemm_desc;
 size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d);
 int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
@@ -174,6 +177,12 @@ int dmx_unet_forward(dmx_unet* u, const float* f0, int c0, const float* f1, int 
                      const int64_t* timesteps, int t_count, const void* context_cache, int ctx_len,
                      float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* Same as dmx_unet_forward; the launch sequence is captured into a hipGraph the second time an identical argument
+ * tuple is seen and replayed afterwards.  Requires a non-NULL stream (falls back to eager launches otherwise). */
+int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                           const int64_t* timesteps, int t_count, const void* context_cache, int ctx_len,
+                           float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
 typedef struct dmx_vae_config {
   int in_channels, out_channels, latent_channels;
   int block_out_channels[4];
@@ -206,6 +215,8 @@ int dmx_vae_decode(dmx_vae* v, const float* z, float* image, int B, int h, int w
  * ---------------------------------------------------------------------------------- */
 int dmx_profile_begin(void);
 int dmx_profile_end(double* h_out, int n_out);
+/* optional: write one CSV row per launch (class, ms, flops, bytes, shape tag) at the next dmx_profile_end */
+int dmx_profile_dump_path(const char* h_path);
 
 #ifdef __cplusplus
 }
