@@ -46,13 +46,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     import diffute_amd as D
+    from diffute_amd import dist as DD
+    dist = DD.init_from_env("nccl")
     from diffute_amd import _cabi
     from diffute_amd.flops import context_kv_flops, unet_flops
     from diffute_amd.synthetic import synth_inputs
@@ -67,9 +63,7 @@ def main():
         return D.denoise(unet, sched, lat, mask, mlat, ctx, T)
 
     def sync_all():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        DD.barrier_sync(dist, dev)
 
     for _ in range(args.warmup):
         out = one_pass()
@@ -79,13 +73,9 @@ def main():
         out = one_pass()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, value = DD.whole_job_throughput(dist, elapsed, B * args.steps, dev)     # max time, total images / it
     assert torch.isfinite(out).all(), "non-finite latents"
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * B * args.steps / elapsed
 
     loop_flops = T * unet_flops(unet.config, B, hw, hw, 577, True) + context_kv_flops(unet.config, B, 577)
     result = {
