@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROF_CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other"]
+PROF_CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128"]
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -113,7 +113,7 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                              "kernel": "dmx_gemm_kernel<%d>" % (2 if dom == "gemm_128x128" else 1),
+                              "kernel": {"gemm_128x128": "dmx_gemm_kernel<2,2,32>", "gemm_128x64": "dmx_gemm_kernel<2,1,32>", "gemm_256x128": "dmx_gemm_kernel<4,2,64>"}[dom],
                               "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
                               "note": "hipEvent-bracketed launches over one 50-step pass; traffic (PMC) in profiles/"}

@@ -26,10 +26,6 @@
 #include "kernels.h"
 #include <stdio.h>
 
-#define BM 128
-#define BK 32
-#define NSTAGE 4
-
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -39,21 +35,31 @@ struct RowSrc {          // per-thread state for one staged activation row
   int valid;             // m < M
 };
 
-template <int TN>
-__global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
-  constexpr int BN = 64 * TN;
-  constexpr int X_BYTES = BM * BK * 2;
-  constexpr int W_BYTES = BN * BK * 2;
-  constexpr int STAGE = X_BYTES + W_BYTES;
-  constexpr int NLOADS = 2 + TN;                       // glds per thread per stage
+// Tile configurations (WM waves along m x 2 along n, each wave a 64 x 32*TN sub-tile; BKT = K-tile depth):
+//   <2,2,32>  128x128x32, 256 thr, 4-stage ring  64 KB -> 2 blocks/CU   (mid-size GEMMs)
+//   <2,1,32>  128x 64x32, 256 thr, 4-stage ring  48 KB -> 3 blocks/CU   (N <= 64, small grids)
+//   <4,2,64>  256x128x64, 512 thr, 3-stage ring 144 KB -> 1 block/CU    (large GEMMs: 128-byte DMA rows, 85 FLOP/B)
+template <int WM, int TN, int BKT>
+__global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p) {
+  constexpr int BM = 64 * WM, BN = 64 * TN, NT = 128 * WM;
+  constexpr int CPR = BKT / 8;                         // 16-byte chunks per LDS row
+  constexpr int ROWB = BKT * 2;                        // LDS row bytes
+  constexpr int RSTEP = NT / CPR;                      // row distance between a thread's consecutive chunks
+  constexpr int XL = BM * CPR / NT, WL = BN * CPR / NT; // DMA loads per thread per K-tile (activations, weights)
+  constexpr int NLOADS = XL + WL;
+  constexpr int NSTAGE = (BKT == 32) ? 4 : 3;
+  constexpr int X_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = X_BYTES + W_BYTES;
+  constexpr int KSTEPS = BKT / 16;
+  static_assert(XL >= 1 && WL >= 1, "tile too small for the block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto swz = [](int r) { return BKT == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); };
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   long long tm0 = 0, tm1 = 0, tm2 = 0;
   if (p.timing) tm0 = (long long)__builtin_amdgcn_s_memrealtime();
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
 
   // ---- block -> tile mapping (XCD-aware: each XCD's L2 sees one n-tile at a time)
   int bid = blockIdx.x;
@@ -65,22 +71,22 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
-  const int nkt_total = p.K / BK;
+  const int nkt_total = p.K / BKT;
   int kt_begin = 0, kt_end = nkt_total;
   if (p.splitk > 1) {
     kt_begin = blockIdx.y * p.kt_per_split;
     kt_end = min(kt_begin + p.kt_per_split, nkt_total);
   }
 
-  // ---- per-thread staging rows: 16-byte chunk q = t + 256*i -> row q>>2, slot q&3 (rows are 64 B)
-  const int slot = t & 3;
-  RowSrc xr[2];
-  int kcx[2];
+  // ---- per-thread staging rows: 16-byte chunk q = t + NT*i -> row q/CPR, slot q%CPR
+  const int slot = t % CPR;
+  RowSrc xr[XL];
+  int kcx[XL];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (t >> 2) + 64 * i;
+  for (int i = 0; i < XL; ++i) {
+    const int r = t / CPR + RSTEP * i;
     const int m = m0 + r;
-    kcx[i] = (slot ^ ((r >> 2) & 3)) * 8;
+    kcx[i] = (slot ^ swz(r)) * 8;
     xr[i].valid = m < p.M;
     if (p.direct) {
       xr[i].bbase = m; xr[i].iy0 = 0; xr[i].ix0 = 0;
@@ -99,16 +105,16 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
   const int ew = p.ups ? 2 * p.IW : p.IW;
 
   // ---- producer state.  K is walked in SEGMENTS inside which the source tensor and the filter tap are fixed
-  // (tap x {x0,x1}, then the fused shortcut {s0,s1}); inside a segment staging a K-tile is: 2+TN DMA loads from
-  // per-row pointers, then pointer += 64 bytes.  All address decoding lives in segment_setup (rare).
-  const char* xp[2]; int xinc[2];
-  const char* wp[TN]; int winc[TN];
+  // (tap x {x0,x1}, then the fused shortcut {s0,s1}); inside a segment staging a K-tile is NLOADS DMA loads from
+  // per-row pointers, then pointer += one LDS row.  All address decoding lives in segment_setup (rare).
+  const char* xp[XL]; int xinc[XL];
+  const char* wp[WL]; int winc[WL];
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int r = (t >> 2) + 64 * i;
+  for (int i = 0; i < WL; ++i) {
+    const int r = t / CPR + RSTEP * i;
     const int n = n0 + r;
-    const int kc = (slot ^ ((r >> 2) & 3)) * 8;
-    if (n < p.N) { wp[i] = (const char*)(p.w + (size_t)n * p.ldw + (size_t)kt_begin * BK + kc); winc[i] = BK * 2; }
+    const int kc = (slot ^ swz(r)) * 8;
+    if (n < p.N) { wp[i] = (const char*)(p.w + (size_t)n * p.ldw + (size_t)kt_begin * BKT + kc); winc[i] = ROWB; }
     else { wp[i] = (const char*)p.zeros; winc[i] = 0; }
   }
   int p_kt = kt_begin, p_left = 0;
@@ -122,15 +128,15 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
       sc = true; ci = k0 - p.Ktaps; const int ctot = p.K - p.Ktaps;
       if (ci < p.cs0) { src = p.s0 + ci; ld = p.lds0; cend = p.cs0; } else { src = p.s1 + (ci - p.cs0); ld = p.lds1; cend = ctot; }
     }
-    p_left = (cend - ci) / BK;
+    p_left = (cend - ci) / BKT;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < XL; ++i) {
       const bf16* g = nullptr;
       if (xr[i].valid) {
         if (p.direct) {
           g = src + (size_t)xr[i].bbase * ld;
         } else if (sc) {       // shortcut: 1x1 at the output pixel (shortcut source has the output grid)
-          g = src + (size_t)(m0 + (t >> 2) + 64 * i) * ld;
+          g = src + (size_t)(m0 + t / CPR + RSTEP * i) * ld;
         } else {
           const int iy = xr[i].iy0 + dy, ix = xr[i].ix0 + dx;
           if (iy >= 0 && iy < eh && ix >= 0 && ix < ew) {
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
           }
         }
       }
-      if (g) { xp[i] = (const char*)(g + kcx[i]); xinc[i] = BK * 2; }
+      if (g) { xp[i] = (const char*)(g + kcx[i]); xinc[i] = ROWB; }
       else { xp[i] = (const char*)p.zeros; xinc[i] = 0; }       // padding / M tail: re-read the zero page
     }
   };
@@ -149,22 +155,22 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
     char* xs = smem + buf * STAGE;
     char* ws = xs + X_BYTES;
     if (p_kt < kt_end) {
-      if (p_left == 0) segment_setup(p_kt * BK);
+      if (p_left == 0) segment_setup(p_kt * BKT);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)xp[i], (lptr_t)(xs + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+      for (int i = 0; i < XL; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)xp[i], (lptr_t)(xs + (wave * 64 + NT * i) * 16), 16, 0, 0);
         xp[i] += xinc[i];
       }
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(ws + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+      for (int i = 0; i < WL; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(ws + (wave * 64 + NT * i) * 16), 16, 0, 0);
         wp[i] += winc[i];
       }
       ++p_kt; --p_left;
     } else {
 #pragma unroll
       for (int i = 0; i < NLOADS; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)p.zeros, (lptr_t)(xs + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)p.zeros, (lptr_t)(xs + (wave * 64 + NT * (i % XL)) * 16), 16, 0, 0);
     }
   };
 
@@ -178,33 +184,45 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
 
   // fragment read addresses for this lane (stage offset is an immediate: the loop is unrolled over the ring)
   const int lr = lane & 31, lh = lane >> 5;
-  int xad[2][2], wad[TN][2];
+  int xad[2][KSTEPS], wad[TN][KSTEPS];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int r = wm * 64 + b * 32 + lr;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) xad[b][kk] = r * 64 + (((2 * kk + lh) ^ ((r >> 2) & 3)) << 4);
+    for (int kk = 0; kk < KSTEPS; ++kk) xad[b][kk] = r * ROWB + (((2 * kk + lh) ^ swz(r)) << 4);
   }
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
     const int r = wn * 32 * TN + a * 32 + lr;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) wad[a][kk] = X_BYTES + r * 64 + (((2 * kk + lh) ^ ((r >> 2) & 3)) << 4);
+    for (int kk = 0; kk < KSTEPS; ++kk) wad[a][kk] = X_BYTES + r * ROWB + (((2 * kk + lh) ^ swz(r)) << 4);
   }
+  // MFMA phase of one K-tile.  Fragments are double-buffered in registers: the ds_reads of k-step kk+1 are issued
+  // before the MFMAs of k-step kk, so LDS latency hides under the matrix pipe instead of serialising with it.
   auto compute = [&](const int J) {
     const char* st = smem + J * STAGE;
+    bf16x8 xf[2][2], wf[2][TN];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 xf[2], wf[TN];
+    for (int b = 0; b < 2; ++b) xf[0][b] = *(const bf16x8*)(st + xad[b][0]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) xf[b] = *(const bf16x8*)(st + xad[b][kk]);
+    for (int a = 0; a < TN; ++a) wf[0][a] = *(const bf16x8*)(st + wad[a][0]);
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[a] = *(const bf16x8*)(st + wad[a][kk]);
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < KSTEPS) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) xf[nxt][b] = *(const bf16x8*)(st + xad[b][kk + 1]);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[nxt][a] = *(const bf16x8*)(st + wad[a][kk + 1]);
+      }
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][a], xf[cur][b], acc[a][b], 0, 0, 0);
+      // pin the issue order the scheduler would otherwise undo: [ds_reads of k-step kk+1] then [MFMAs of kk]
+      if (kk + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2 + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
     }
   };
 
@@ -217,12 +235,13 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
   {                                                                                         \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLOADS) : "memory");            \
     __builtin_amdgcn_s_barrier(); /* tile kt is in LDS for every wave; tile kt-1's buffer is free */ \
-    produce((J + NSTAGE - 1) & (NSTAGE - 1));                                               \
+    produce((J + NSTAGE - 1) % NSTAGE);                                                     \
     compute(J);                                                                             \
     if (++kt >= kt_end) break;                                                              \
   }
   for (;;) {
-    DMX_SUBITER(0) DMX_SUBITER(1) DMX_SUBITER(2) DMX_SUBITER(3)
+    DMX_SUBITER(0) DMX_SUBITER(1) DMX_SUBITER(2)
+    if constexpr (NSTAGE == 4) DMX_SUBITER(3)
   }
 #undef DMX_SUBITER
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the dummy tail loads before LDS is released
@@ -258,7 +277,8 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
     // lgkmcnt only: __syncthreads() would also wait for the global stores (vmcnt counts stores on gfx950), and
     // every global load is issued before the first store for the same reason.
     constexpr int LDT = BN + 4;                        // padded row stride (floats): conflict-free b128 writes
-    constexpr int OCT = BM * (BN / 8) / 256;           // (row, octet) items per thread: 8 (BN=128) or 4 (BN=64)
+    constexpr int OC = BN / 8;                         // output octets per tile row (NT % OC == 0: o fixed per thread)
+    constexpr int OCT = BM * OC / NT;                  // (row, octet) items per thread: 4*TN
     float* tile = (float*)smem;
     const bool geglu = p.geglu != 0;
     if (p.rowbias) {                                   // uniform branch; columns past N are clamped (never stored)
@@ -303,9 +323,9 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
           for (int e = 0; e < 4; ++e) { ba[4 * q + e] = x0[e]; bg[4 * q + e] = x1[e]; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < BM * 8 / NT; ++k) {
           asm volatile("" ::: "memory");
-          const int r = (t >> 3) + 32 * k;
+          const int r = (t >> 3) + (NT / 8) * k;
           const int m = m0 + r;
           if (m >= p.M) continue;
           const float* ta = tile + r * LDT + 64 * G + jj;
@@ -320,7 +340,6 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
         }
       }
     } else {
-      constexpr int OC = BN / 8;                       // octets per tile row; 256 % OC == 0 so o is fixed per thread
       const int o = t % OC, n = n0 + o * 8;
       if (n < p.N) {
         float bs[8];
@@ -335,14 +354,14 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
         if (p.res) {
 #pragma unroll
           for (int k = 0; k < OCT; ++k) {
-            int m = m0 + t / OC + (256 / OC) * k; if (m >= p.M) m = p.M - 1;
+            int m = m0 + t / OC + (NT / OC) * k; if (m >= p.M) m = p.M - 1;
             rv[k] = *(const u32x4*)(p.res + (size_t)m * p.ldres + n);
           }
         }
 #pragma unroll
         for (int k = 0; k < OCT; ++k) {
           asm volatile("" ::: "memory");               // keep each item's LDS reads in its own iteration (VGPR pressure)
-          const int r = t / OC + (256 / OC) * k;
+          const int r = t / OC + (NT / OC) * k;
           const int m = m0 + r;
           if (m >= p.M) continue;
           const f32x4 v0 = *(const f32x4*)(tile + r * LDT + o * 8), v1 = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
@@ -358,70 +377,24 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
         }
       }
     }
-  } else if (p.geglu) {
-    if constexpr (TN == 2) {
-      // packed weight rows: [32 'a' rows | 32 matching 'b' rows] per 64-row group
+  } else {
+    // ---- generic epilogue (fp32 output, channel counts that are not multiples of 8): per-lane 4-channel groups
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldo & 3) == 0);
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int m = m0 + wm * 64 + b * 32 + lr;
         if (m >= p.M) continue;
+        const float* rb = p.rowbias ? (p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb) : nullptr;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int nl = 8 * g + 4 * lh;
-          const int na = n0 + wn * 64 + nl;          // packed row of the 'a' half
-          const int j = (n0 + wn * 64) / 2 + nl;     // output column
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float av = acc[0][b][4 * g + e] + p.bias[na + e];
-            const float bv = acc[1][b][4 * g + e] + p.bias[na + 32 + e];
-            v[e] = av * gelu_erf_f(bv);
-          }
-          u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-          *(u32x2*)((bf16*)p.out + (size_t)m * p.ldo + j) = pk;
-        }
-      }
-    }
-  } else {
-  const bool vec_ok = ((p.N & 3) == 0) && ((p.ldo & 3) == 0);
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int m = m0 + wm * 64 + b * 32 + lr;
-      if (m >= p.M) continue;
-      const float* rb = p.rowbias ? (p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb) : nullptr;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 32 * TN + a * 32 + 8 * g + 4 * lh;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
-        if (vec_ok && n + 3 < p.N) {
-          if (p.bias) { const f32x4 bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bv[e]; }
-          if (rb) { const f32x4 bv = *(const f32x4*)(rb + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bv[e]; }
-          if (p.res) {
-            const u32x2 rv = *(const u32x2*)(p.res + (size_t)m * p.ldres + n);
-            v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
-            v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
-          }
-          if (p.out_f32) {
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = o;
-          } else {
-            u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *(u32x2*)((bf16*)p.out + (size_t)m * p.ldo + n) = pk;
-          }
-        } else {
+          const int n = n0 + wn * 32 * TN + a * 32 + 8 * g + 4 * lh;
+          if (n >= p.N) continue;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (n + e >= p.N) continue;
-            float x = v[e];
+            float x = acc[a][b][4 * g + e];
             if (p.bias) x += p.bias[n + e];
             if (rb) x += rb[n + e];
             if (p.res) x += bf_bits2f(*(const unsigned short*)(p.res + (size_t)m * p.ldres + n + e));
@@ -430,9 +403,9 @@ __global__ __launch_bounds__(256, 2) void dmx_gemm_kernel(const GemmArgs p) {
           }
         }
       }
-    }
+    (void)vec_ok;
   }
-  if (p.timing && t == 0) {        // probe build aid: per-block timeline in 10 ns ticks (s_memrealtime)
+  if (p.timing && t == 0) {        // measurement aid: per-block timeline in 10 ns ticks (s_memrealtime)
     long long* o = p.timing + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
     o[0] = tm0; o[1] = tm1; o[2] = tm2; o[3] = (long long)__builtin_amdgcn_s_memrealtime();
   }
@@ -483,61 +456,102 @@ int dmx_zero_page(const bf16** out) {
   return DMX_OK;
 }
 
-// Tile / split-K plan.  The chip holds 256 CUs x 2 resident blocks; the UNet's GEMMs are small next to that
-// (M = 256..16384 rows), so the plan trades tile efficiency (128x128 does 8 MFMAs per barrier, 128x64 only 4)
-// against filling the CUs, with split-K (fp32 partials + a reduce pass) when even 64-wide tiles leave CUs idle.
-// Costs are in units of one 128x128x32 K-tile step.
-static double plan_cost(const GemmArgs& a, int tn, int sk) {
-  const int nkt = a.K / BK;
-  const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, 64 * tn);
+// Tile / split-K plan.  Config ids: 0 = 128x128x32 (2 blocks/CU), 1 = 128x64x32, 2 = 256x128x64 (1 block/CU).
+// The UNet's GEMMs are small next to 256 CUs (M = 256..16384 rows), so the plan trades tile efficiency against
+// filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
+// units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
+struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
+static const TileCfg kCfg[3] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+    {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
+    {128, 64, 32, 512, 0.78, 6.0},
+    {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
+};
+
+static double plan_cost(const GemmArgs& a, int c, int sk) {
+  const TileCfg& T = kCfg[c];
+  const int nkt = a.K / T.bk;
+  const long tiles = (long)cdiv(a.M, T.bm) * cdiv(a.N, T.bn);
   const long nb = tiles * sk;
-  const double per_tile = tn == 2 ? 1.0 : 0.78;      // measured: 64-wide tiles run at ~0.65x the FLOP rate
-  const double t_block = (cdiv(nkt, sk) + 6) * per_tile;
-  double rounds = (double)((nb + 255) / 256);                 // blocks per CU, executed back to back
-  if (nb <= 256) rounds = 1.2;                                // a lone block per CU does not hide its own latency
+  const double t_block = cdiv(nkt, sk) * T.per_ktile + T.fixed;
+  const int per_round = 256;                                   // CUs
+  double rounds = (double)((nb + per_round - 1) / per_round);
+  if (T.slots == 512) {                                        // two co-resident blocks overlap each other's stalls
+    if (nb <= 256) rounds = 1.2; 
+  } else {
+    rounds *= 1.0;
+  }
   double t = rounds * t_block;
-  if (sk > 1) t += 45.0 + ((double)a.M * a.N * 4.0 * (sk + 1) / 5.0e12) / 0.14e-6;
+  if (sk > 1) t += 12.0 + ((double)a.M * a.N * 4.0 * (sk + 1) / 5.0e12) / 0.45e-6;   // reduce pass: ~5 us + traffic
   return t;
 }
 
-void dmx_gemm_plan(const GemmArgs& a, int* tn_out, int* splitk_out, int* ktps_out) {
-  const int nkt = a.K / BK;
-  int best_tn = 2, best_sk = 1; double best = 1e300;
-  for (int tn = 2; tn >= 1; --tn) {
-    if (a.geglu && tn != 2) continue;
-    if (a.force_tn && tn != a.force_tn) continue;
-    if (tn == 2 && a.N <= 64 && !a.force_tn) continue;
+#include "gemm_tuned.h"
+
+void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_out) {
+  int best_c = 0, best_sk = 1; double best = 1e300;
+  if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
+    for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
+      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == a.ups &&
+          !(a.geglu && (tp.cfg == 1 || tp.sk > 1))) {
+        const int nkt = a.K / kCfg[tp.cfg].bk;
+        int ktps = cdiv(nkt, tp.sk);
+        *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
+        return;
+      }
+  }
+  for (int c = 0; c < 3; ++c) {
+    const TileCfg& T = kCfg[c];
+    if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
+    if (a.geglu && c == 1) continue;
+    if (a.force_tn == 1 && c != 1) continue;
+    if (a.force_tn == 2 && c != 0) continue;
+    if (a.force_tn == 3 && c != 2) continue;
+    if (!a.force_tn && c != 1 && a.N <= 64) continue;
+    if (!a.force_tn && c == 2 && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
+    const int nkt = a.K / T.bk;
     const int max_sk = (a.geglu || (a.N % 4) != 0) ? 1 : 16;
     for (int sk = 1; sk <= max_sk; ++sk) {
       if (a.force_splitk && sk != a.force_splitk) continue;
-      if (sk > 1 && nkt / sk < 8) break;
-      const double c = plan_cost(a, tn, sk);
-      if (c < best) { best = c; best_tn = tn; best_sk = sk; }
+      if (sk > 1 && nkt / sk < (T.bk == 64 ? 4 : 8)) break;
+      const double cst = plan_cost(a, c, sk);
+      if (cst < best) { best = cst; best_c = c; best_sk = sk; }
     }
   }
+  const int nkt = a.K / kCfg[best_c].bk;
   int ktps = cdiv(nkt, best_sk);
   best_sk = cdiv(nkt, ktps);
-  *tn_out = best_tn; *splitk_out = best_sk; *ktps_out = ktps;
+  *cfg_out = best_c; *splitk_out = best_sk; *ktps_out = ktps;
 }
 
 size_t dmx_gemm_workspace_bytes(const GemmArgs& a) {
-  int tn, sk, ktps;
-  dmx_gemm_plan(a, &tn, &sk, &ktps);
+  int c, sk, ktps;
+  dmx_gemm_plan(a, &c, &sk, &ktps);
   return sk > 1 ? (size_t)sk * a.M * a.N * sizeof(float) : 0;
+}
+
+template <int WM, int TN, int BKT>
+static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+  constexpr int BM = 64 * WM, BN = 64 * TN, NST = (BKT == 32) ? 4 : 3;
+  size_t lds = (size_t)NST * (BM + BN) * BKT * 2;
+  const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);       // fp32 staging tile of the coalesced epilogue
+  if (lds_epi > lds) lds = lds_epi;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT>), grid, dim3(128 * WM), lds, stream, a);
 }
 
 int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   DMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-  DMX_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+  DMX_REQUIRE(a.K % 32 == 0, "gemm: K=%d must be a multiple of 32", a.K);
   DMX_REQUIRE(a.ldw % 8 == 0 && a.ldx0 % 8 == 0, "gemm: leading dimensions must be multiples of 8 (ldw=%d ldx0=%d)", a.ldw, a.ldx0);
-  DMX_REQUIRE(a.cx0 % BK == 0 && a.Cin % BK == 0, "gemm: channel splits must be multiples of %d (Cin=%d cx0=%d)", BK, a.Cin, a.cx0);
-  DMX_REQUIRE(a.Ktaps % BK == 0 && a.Ktaps <= a.K, "gemm: bad Ktaps=%d K=%d", a.Ktaps, a.K);
-  if (a.Ktaps < a.K) DMX_REQUIRE(a.s0 != nullptr && a.cs0 % BK == 0, "gemm: shortcut segment needs s0 and aligned cs0");
-  if (a.geglu) DMX_REQUIRE(a.bias && a.N % 128 == 0 && !a.out_f32 && !a.res && !a.rowbias, "gemm: GEGLU needs bias, N%%128==0, bf16 out");
+  DMX_REQUIRE(a.cx0 % 32 == 0 && a.Cin % 32 == 0, "gemm: channel splits must be multiples of 32 (Cin=%d cx0=%d)", a.Cin, a.cx0);
+  DMX_REQUIRE(a.Ktaps % 32 == 0 && a.Ktaps <= a.K, "gemm: bad Ktaps=%d K=%d", a.Ktaps, a.K);
+  if (a.Ktaps < a.K) DMX_REQUIRE(a.s0 != nullptr && a.cs0 % 32 == 0, "gemm: shortcut segment needs s0 and aligned cs0");
+  if (a.geglu) DMX_REQUIRE(a.bias && a.N % 128 == 0 && !a.out_f32 && !a.res && !a.rowbias && a.ldo % 8 == 0, "gemm: GEGLU needs bias, N%%128==0, bf16 out");
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;
-  int tn, sk, ktps;
-  dmx_gemm_plan(a, &tn, &sk, &ktps);
+  int c, sk, ktps;
+  dmx_gemm_plan(a, &c, &sk, &ktps);
   a.splitk = sk; a.kt_per_split = ktps;
   if (sk > 1) {
     const size_t need = (size_t)sk * a.M * a.N * sizeof(float);
@@ -547,26 +561,18 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     }
     a.partial = (float*)workspace;
   }
-  const int bn = 64 * tn;
-  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, bn), sk, 1);
-  size_t lds = NSTAGE * (size_t)(BM * BK * 2 + bn * BK * 2);
-  const size_t lds_epi = (size_t)BM * (bn + 4) * sizeof(float);       // fp32 staging tile of the coalesced epilogue
-  if (lds_epi > lds) lds = lds_epi;
+  const TileCfg& T = kCfg[c];
+  dim3 grid(cdiv(a.M, T.bm) * cdiv(a.N, T.bn), sk, 1);
   // algorithmic work of this launch: 2*M*N*K flops; bytes = activations read once + weights + output
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = 2.0 * ((double)a.M * (a.K / (a.direct ? 1 : (a.ksize * a.ksize))) + (double)a.N * a.K + (double)a.M * (a.geglu ? a.N / 2 : a.N));
   char tag[96];
-  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, tn, sk);
-  if (tn == 2) {
-    ProfScope ps(PROF_GEMM128, stream, flops, bytes, tag);
-    static bool attr2 = false;
-    if (!attr2) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
-    hipLaunchKernelGGL(dmx_gemm_kernel<2>, grid, dim3(256), lds, stream, a);
-  } else {
-    ProfScope ps(PROF_GEMM64, stream, flops, bytes, tag);
-    static bool attr1 = false;
-    if (!attr1) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-    hipLaunchKernelGGL(dmx_gemm_kernel<1>, grid, dim3(256), lds, stream, a);
+  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, c == 0 ? 2 : (c == 1 ? 1 : 3), sk);
+  {
+    ProfScope ps(c == 0 ? PROF_GEMM128 : (c == 1 ? PROF_GEMM64 : PROF_GEMM256), stream, flops, bytes, tag);
+    if (c == 0) launch_cfg<2, 2, 32>(a, grid, stream);
+    else if (c == 1) launch_cfg<2, 1, 32>(a, grid, stream);
+    else launch_cfg<4, 2, 64>(a, grid, stream);
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;

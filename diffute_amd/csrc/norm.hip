@@ -2,13 +2,12 @@
 //
 // Both are HBM-bound: every load/store is 16 B per lane (8 bf16), statistics in fp32.
 //
-// GroupNorm is three launches and deterministic (no float atomics):
-//   stats    : grid (nchunk, B); each block reduces rows_per_chunk pixels x C channels to
-//              per-group (sum, sumsq) partials  -> partial[b][chunk][g][2]
-//   finalize : grid (B); folds the <=256 partials of a sample in fixed order and writes the
-//              per-channel affine (a = rstd*gamma, b = beta - mean*a)
-//   apply    : grid (row blocks, B); y = x*a + b (+SiLU), bf16 out; the thread's 8 channels'
-//              coefficients stay in registers, 4 rows in flight per thread.
+// GroupNorm is two launches and deterministic (no float atomics):
+//   stats : grid (nchunk, B); each block reduces rows_per_chunk pixels x C channels to
+//           per-group (sum, sumsq) partials  -> partial[b][chunk][g][2]
+//   apply : grid (row blocks, B); a parallel prologue folds the <=256 partials of its sample in a
+//           fixed order into mean/rstd, each thread derives its 8 channels' affine into registers,
+//           then y = x*a + b (+SiLU), bf16 out, 4 rows in flight per thread.
 // The input may be the virtual channel-concat of two tensors (UNet skip connections), so
 // torch.cat([h, skip], 1) is never materialised.
 #include "common.h"
@@ -70,56 +69,62 @@ __global__ __launch_bounds__(1024) void dmx_gn_stats_kernel(const GroupNormArgs 
   }
 }
 
-// finalize: one block per sample folds the partials in a fixed order (deterministic) and writes the
-// per-channel affine  y = x*a + b  with a = rstd*gamma, b = beta - mean*a  -> coef[b][c][2]
-__global__ __launch_bounds__(256) void dmx_gn_finalize_kernel(const GroupNormArgs p) {
-  __shared__ float red[2][8][64];
-  __shared__ float MEAN[64], RSTD[64];
-  const int t = threadIdx.x, b = blockIdx.x;
-  const int G = p.groups;
-  const int slices = 256 / G > 8 ? 8 : 256 / G;       // G <= 64 -> >= 4 slices
-  const int g = t % G, sl = t / G;
-  if (sl < slices) {
-    float a = 0.f, q = 0.f;
-    const float* pp = p.partial + ((size_t)b * p.nchunk * G + g) * 2;
-    for (int k = sl; k < p.nchunk; k += slices) { a += pp[(size_t)k * G * 2]; q += pp[(size_t)k * G * 2 + 1]; }
-    red[0][sl][g] = a; red[1][sl][g] = q;
-  }
-  __syncthreads();
-  const int cpg = p.C / G;
-  if (t < G) {
-    float a = 0.f, q = 0.f;
-    for (int k = 0; k < slices; ++k) { a += red[0][k][t]; q += red[1][k][t]; }
-    const float inv_n = 1.0f / ((float)p.HW * (float)cpg);
-    const float mean = a * inv_n;
-    float var = q * inv_n - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    MEAN[t] = mean; RSTD[t] = rsqrtf(var + p.eps);
-  }
-  __syncthreads();
-  float* coef = p.coef + (size_t)b * p.C * 2;
-  for (int c = t; c < p.C; c += 256) {
-    const int gg = c / cpg;
-    const float a = RSTD[gg] * p.gamma[c];
-    coef[2 * c] = a; coef[2 * c + 1] = p.beta[c] - MEAN[gg] * a;
-  }
-}
-
-// apply: same thread mapping as stats; each thread keeps its 8 channels' (a, b) in registers
+// apply: prologue folds the <=256 partials of the block's sample in a fixed order (deterministic; all loads of a
+// thread are independent and issued together), derives each thread's 8 channel affines a = rstd*gamma,
+// b = beta - mean*a into registers, then streams rows: y = x*a + b (+SiLU), 4 rows in flight per thread.
 __global__ __launch_bounds__(1024) void dmx_gn_apply_kernel(const GroupNormArgs p, int rows_per_block) {
+  __shared__ float red[2][16][64];
+  __shared__ float MEAN[64], RSTD[64];
   const int oc = p.C >> 3;
   const int R = blockDim.x / oc;
   const int t = threadIdx.x;
   const int r = t / oc, co = t - r * oc;
   const int b = blockIdx.y;
-  const int row0 = blockIdx.x * rows_per_block;
-  const int row1 = min(row0 + rows_per_block, p.HW);
+  const int G = p.groups;
+  {
+    int slices = blockDim.x / G; if (slices > 16) slices = 16;
+    const int g = t % G, sl = t / G;
+    if (sl < slices) {
+      float a = 0.f, q = 0.f;
+      const float* pp = p.partial + ((size_t)b * p.nchunk * G + g) * 2;
+      int k = sl;
+      for (; k + 3 * slices < p.nchunk; k += 4 * slices) {
+        float va[4], vq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] = pp[(size_t)(k + j * slices) * G * 2]; vq[j] = pp[(size_t)(k + j * slices) * G * 2 + 1]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a += va[j]; q += vq[j]; }
+      }
+      for (; k < p.nchunk; k += slices) { a += pp[(size_t)k * G * 2]; q += pp[(size_t)k * G * 2 + 1]; }
+      red[0][sl][g] = a; red[1][sl][g] = q;
+    }
+    __syncthreads();
+    const int cpg = p.C / G;
+    if (t < G) {
+      float a = 0.f, q = 0.f;
+      for (int k2 = 0; k2 < slices; ++k2) { a += red[0][k2][t]; q += red[1][k2][t]; }
+      const float inv_n = 1.0f / ((float)p.HW * (float)cpg);
+      const float mean = a * inv_n;
+      float var = q * inv_n - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      MEAN[t] = mean; RSTD[t] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+  }
   float A[8], Bv[8];
   {
-    const f32x4* cp = (const f32x4*)(p.coef + ((size_t)b * p.C + co * 8) * 2);
+    const int cpg = p.C / G;
+    const f32x4 g0 = *(const f32x4*)(p.gamma + co * 8), g1 = *(const f32x4*)(p.gamma + co * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(p.beta + co * 8), b1 = *(const f32x4*)(p.beta + co * 8 + 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const f32x4 v = cp[j]; A[2 * j] = v[0]; Bv[2 * j] = v[1]; A[2 * j + 1] = v[2]; Bv[2 * j + 1] = v[3]; }
+    for (int i = 0; i < 8; ++i) {
+      const int gg = (co * 8 + i) / cpg;
+      const float gm = i < 4 ? g0[i] : g1[i - 4], bt = i < 4 ? b0[i] : b1[i - 4];
+      A[i] = RSTD[gg] * gm; Bv[i] = bt - MEAN[gg] * A[i];
+    }
   }
+  const int row0 = blockIdx.x * rows_per_block;
+  const int row1 = min(row0 + rows_per_block, p.HW);
   const size_t base = (size_t)b * p.HW;
   int row = row0 + r;
   for (; row + 3 * R < row1; row += 4 * R) {
@@ -170,9 +175,6 @@ int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream) {
   if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gn_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
   hipLaunchKernelGGL(dmx_gn_stats_kernel, dim3(a.nchunk, a.B), dim3(threads), lds_stats, stream, a);
   int rc = dmx_check_launch("dmx_gn_stats_kernel");
-  if (rc) return rc;
-  hipLaunchKernelGGL(dmx_gn_finalize_kernel, dim3(a.B), dim3(256), 0, stream, a);
-  rc = dmx_check_launch("dmx_gn_finalize_kernel");
   if (rc) return rc;
   int rpb = 8 * R;                                                  // up to 8 rows per thread in apply
   while (rpb > R && (long)cdiv(a.HW, rpb) * a.B < 512) rpb -= R;

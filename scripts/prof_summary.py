@@ -3,7 +3,7 @@ import collections
 import csv
 import sys
 
-NAMES = ["gemm128", "gemm64", "splitk", "attn", "gn", "ln", "other"]
+NAMES = ["gemm128", "gemm64", "splitk", "attn", "gn", "ln", "other", "gemm256"]
 
 
 def main(path, top=40):

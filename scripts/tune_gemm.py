@@ -31,6 +31,8 @@ def main(path):
         shapes[key] = shapes.get(key, 0) + 1
     dev = torch.device("cuda")
     tot_auto = tot_best = 0.0
+    floor = time_it(lambda: ops.conv_gemm(torch.zeros(1, 1, 128, 64, device=dev, dtype=torch.bfloat16), torch.zeros(64, 64, device=dev, dtype=torch.bfloat16), 64, ksize=1, pad=0))
+    print(f'host/launch floor of this harness: {floor:.1f} us per call')
     for (M, N, K, ks, st, ups), cnt in sorted(shapes.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
         B = 4 if M % 4 == 0 else 1
         if ks == 3:
@@ -48,9 +50,9 @@ def main(path):
             run = lambda tn, sk: ops.conv_gemm(x, w, N, ksize=1, pad=0, force_tn=tn, force_splitk=sk)
         t_auto = time_it(lambda: run(0, 0))
         res = []
-        for tn in (2, 1):
+        for tn in (3, 2, 1):
             for sk in (1, 2, 3, 4, 6, 8, 12, 16):
-                if sk > 1 and (K // 32) // sk < 8:
+                if sk > 1 and (K // (64 if tn == 3 else 32)) // sk < (4 if tn == 3 else 8):
                     continue
                 try:
                     res.append((time_it(lambda: run(tn, sk)), tn, sk))

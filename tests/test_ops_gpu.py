@@ -62,6 +62,27 @@ def test_conv(cuda, case):
     assert_close(nchw(out), ref, TOL, name)
 
 
+@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2)])
+def test_conv_every_tile_config(cuda, tn, sk):
+    """All three tile configurations (128x64, 128x128, 256x128) and split-K give the same conv + epilogue."""
+    from diffute_amd import ops
+    B, H, W, C0, C1, Co = 2, 24, 24, 128, 64, 192           # M = 1152 (tail for 256-row tiles), two-source input
+    h = bf(seeded((B, C0, H, W), 1)); s_ = bf(seeded((B, C1, H, W), 2)); x = torch.cat([h, s_], 1)
+    w = bf(seeded((Co, C0 + C1, 3, 3), 3, 1 / math.sqrt(9 * (C0 + C1)))); b = seeded((Co,), 4, 0.1)
+    temb = seeded((B, Co), 5); r = bf(seeded((B, Co, H, W), 6))
+    ref = bf(F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + r)
+    out = ops.conv_gemm(nhwc(h, cuda), ops.pack_conv_weight(w.to(cuda)), Co, x1=nhwc(s_, cuda), bias=b.to(cuda),
+                        rowbias=temb.to(cuda).contiguous(), res=nhwc(r, cuda), force_tn=tn, force_splitk=sk)
+    assert_close(nchw(out), ref, TOL, f"conv tn={tn} sk={sk}")
+    if tn != 1:
+        M, C = 640, 128
+        xg = bf(seeded((M, C), 7)); wg = bf(seeded((8 * C, C), 8, 1 / math.sqrt(C))); bg = seeded((8 * C,), 9, 0.1)
+        g = F.linear(xg, wg, bg); a_, gate = g.chunk(2, dim=-1)
+        outg = ops.conv_gemm(xg.to(cuda).to(torch.bfloat16).reshape(1, 1, M, C), ops.pack_linear_weight(wg.to(cuda), geglu=True), 8 * C,
+                             ksize=1, pad=0, bias=ops.pack_geglu_bias(bg.to(cuda)), geglu=True, force_tn=tn)
+        assert_close(outg.reshape(M, 4 * C), bf(a_ * F.gelu(gate)), TOL, f"geglu tn={tn}")
+
+
 def test_conv_concat_temb_shortcut(cuda):
     """ResnetBlock2D conv pair of an up block: conv1 over (h|skip)+temb; conv2 + fused 1x1 shortcut over (h|skip)."""
     from diffute_amd import ops
