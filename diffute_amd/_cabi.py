@@ -20,7 +20,7 @@ class GemmDesc(ctypes.Structure):
         ("w", c_void_p), ("ldw", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
         ("bias", c_void_p), ("rowbias", c_void_p), ("rows_per_group", c_int), ("ldrb", c_int),
         ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("geglu", c_int),
-        ("force_tn", c_int), ("force_splitk", c_int), ("timing", c_void_p),
+        ("force_tn", c_int), ("force_splitk", c_int), ("group_m", c_int), ("timing", c_void_p),
     ]
 
 
@@ -45,6 +45,7 @@ _PROTOS = {
     "dmx_groupnorm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, c_int, _P, c_size_t, _P]),
     "dmx_layernorm": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P]),
     "dmx_attention_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "dmx_attention_fwd_v": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "dmx_timestep_embedding": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "dmx_linear_small": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dmx_im2col_small": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

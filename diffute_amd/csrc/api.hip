@@ -18,7 +18,7 @@ static GemmArgs to_args(const dmx_gemm_desc* d) {
   a.w = (const bf16*)d->w; a.ldw = d->ldw; a.M = d->M; a.N = d->N; a.K = d->K;
   a.bias = d->bias; a.rowbias = d->rowbias; a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1; a.ldrb = d->ldrb;
   a.res = (const bf16*)d->res; a.ldres = d->ldres; a.out = d->out; a.ldo = d->ldo; a.out_f32 = d->out_f32; a.geglu = d->geglu;
-  a.force_tn = d->force_tn; a.force_splitk = d->force_splitk; a.timing = d->timing;
+  a.force_tn = d->force_tn; a.force_splitk = d->force_splitk; a.group_m = d->group_m; a.timing = d->timing;
   return a;
 }
 extern "C" size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d) { return d ? dmx_gemm_workspace_bytes(to_args(d)) : 0; }
@@ -49,6 +49,15 @@ extern "C" int dmx_attention_fwd(const void* q, int ldq, const void* k, int ldk,
   AttnArgs a{};
   a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.kv_rows = kv_rows;
   a.vt = (const bf16*)vt; a.ldvt = ldvt; a.skv_stride = skv_stride; a.o = (bf16*)o; a.ldo = ldo;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  return dmx_attention_launch(a, (hipStream_t)stream);
+}
+extern "C" int dmx_attention_fwd_v(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                                   void* o, int ldo, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream) {
+  DMX_REQUIRE(q && k && v && o, "attention: null argument");
+  AttnArgs a{};
+  a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.kv_rows = kv_rows;
+  a.v = (const bf16*)v; a.ldv = ldv; a.o = (bf16*)o; a.ldo = ldo;
   a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
   return dmx_attention_launch(a, (hipStream_t)stream);
 }

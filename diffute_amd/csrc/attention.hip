@@ -16,9 +16,23 @@
 
 #define KROW 72      // K tile row stride in elements (144 B: conflict-free ds_read_b128)
 #define VROW 68      // V^T tile row stride in elements (136 B: conflict-free ds_read_b64)
+#define VRS 192      // row-major V tile row stride in BYTES (64 data + 32 pad elements: conflict-free tr reads)
 #define KT_BYTES (64 * KROW * 2)
-#define VT_BYTES (64 * VROW * 2)
+#define VT_BYTES (64 * VRS)          // sized for the larger of the two V layouts (V^T needs 64*136)
 
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read; semantics verified by scripts/probes/tr_probe.hip): within each
+// 16-lane group, lane p supplies the address of 4 contiguous b16 = row (p>>2), columns 4*(p&3).. of a [4][16] block;
+// lane q receives column q of that block, rows 0..3.  Eight reads, one asm statement (the compiler does not count
+// asm LDS ops: the caller waits with s_waitcnt lgkmcnt + sched_barrier before consuming).
+#define DMX_TR8(V, A, O0, O1, O2, O3, O4, O5, O6, O7)                                                     \
+  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%9\n\tds_read_b64_tr_b16 %1, %8 offset:%10\n\t"          \
+               "ds_read_b64_tr_b16 %2, %8 offset:%11\n\tds_read_b64_tr_b16 %3, %8 offset:%12\n\t"         \
+               "ds_read_b64_tr_b16 %4, %8 offset:%13\n\tds_read_b64_tr_b16 %5, %8 offset:%14\n\t"         \
+               "ds_read_b64_tr_b16 %6, %8 offset:%15\n\tds_read_b64_tr_b16 %7, %8 offset:%16"              \
+               : "=&v"(V[0]), "=&v"(V[1]), "=&v"(V[2]), "=&v"(V[3]), "=&v"(V[4]), "=&v"(V[5]), "=&v"(V[6]), "=&v"(V[7]) \
+               : "v"(A), "i"(O0), "i"(O1), "i"(O2), "i"(O3), "i"(O4), "i"(O5), "i"(O6), "i"(O7) : "memory")
+
+template <bool VROWMAJOR>
 __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (KT_BYTES + VT_BYTES)];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -26,6 +40,7 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const float sl2 = p.scale * 1.4426950408889634f;
+  const float thr = 8.0f / sl2;                      // defer-max threshold in raw-score units
 
   // ---- Q fragment (MFMA B operand): query lr, d = 16*kk + 8*lh .. +8
   bf16x8 qf[4];
@@ -39,16 +54,21 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
   // ---- staging assignment: chunk c = t + 256*i -> row c>>3, 16-byte piece c&7
   const int srow0 = t >> 3, spc = t & 7;
   const bf16* kbase = p.k + (size_t)b * p.kv_rows * p.ldk + h * 64 + spc * 8;
-  const bf16* vbase = p.vt + (size_t)(h * 64) * p.ldvt + (size_t)b * p.skv_stride + spc * 8;
+  const bf16* vbase = VROWMAJOR ? (p.v + (size_t)b * p.kv_rows * p.ldv + h * 64 + spc * 8)
+                                : (p.vt + (size_t)(h * 64) * p.ldvt + (size_t)b * p.skv_stride + spc * 8);
   u32x4 kreg[2], vreg[2];
   auto load_tile = [&](int kv0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int key = kv0 + srow0 + 32 * i; if (key >= p.Skv) key = p.Skv - 1;
       kreg[i] = *(const u32x4*)(kbase + (size_t)key * p.ldk);
-      const int d = srow0 + 32 * i;
-      if (kv0 + spc * 8 < p.Skv) vreg[i] = *(const u32x4*)(vbase + (size_t)d * p.ldvt + kv0);
-      else vreg[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (VROWMAJOR) {
+        vreg[i] = *(const u32x4*)(vbase + (size_t)key * p.ldv);          // row = key (clamped: P is 0 past Skv)
+      } else {
+        const int d = srow0 + 32 * i;
+        if (kv0 + spc * 8 < p.Skv) vreg[i] = *(const u32x4*)(vbase + (size_t)d * p.ldvt + kv0);
+        else vreg[i] = (u32x4){0u, 0u, 0u, 0u};
+      }
     }
   };
   auto write_tile = [&](int buf) {
@@ -58,9 +78,13 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
     for (int i = 0; i < 2; ++i) {
       const int r = srow0 + 32 * i;
       *(u32x4*)(ks + r * (KROW * 2) + spc * 16) = kreg[i];
-      u32x2 lo = {vreg[i][0], vreg[i][1]}, hi = {vreg[i][2], vreg[i][3]};
-      *(u32x2*)(vs + r * (VROW * 2) + spc * 16) = lo;
-      *(u32x2*)(vs + r * (VROW * 2) + spc * 16 + 8) = hi;
+      if (VROWMAJOR) {
+        *(u32x4*)(vs + r * VRS + spc * 16) = vreg[i];
+      } else {
+        u32x2 lo = {vreg[i][0], vreg[i][1]}, hi = {vreg[i][2], vreg[i][3]};
+        *(u32x2*)(vs + r * (VROW * 2) + spc * 16) = lo;
+        *(u32x2*)(vs + r * (VROW * 2) + spc * 16 + 8) = hi;
+      }
     }
   };
 
@@ -91,25 +115,33 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt], 0, 0, 0);
       }
     }
-    // ---- scale to log2 domain, mask the tail, row max
+    // ---- online softmax on the RAW scores: p = exp2(s*c - m*c) with c = scale*log2(e) folded into one fma per
+    // score (no separate scaling pass); the running max is only raised - and O / l rescaled - when a score exceeds
+    // it by more than 8/c (p stays <= 2^8: harmless in bf16/fp32, saves the O-wide rescale on almost every tile).
     float mx = -INFINITY;
-    const bool tail = kv0 + 64 > p.Skv;
+    if (kv0 + 64 > p.Skv) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= p.Skv) s[kt][r] = -INFINITY;
+        }
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[kt][r] * sl2;
-        if (tail) {
-          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= p.Skv) v = -INFINITY;
-        }
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    if (!__all(mx <= m_run + thr)) {                   // wave-uniform: some query row needs a higher reference max
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    }
+    const float mc = -m_run * sl2;
     float psum = 0.f;
     bf16x8 pf[4];
 #pragma unroll
@@ -119,29 +151,52 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
         unsigned int w[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p0 = __builtin_amdgcn_exp2f(s[kt][8 * u + 2 * e] - m_new);
-          const float p1 = __builtin_amdgcn_exp2f(s[kt][8 * u + 2 * e + 1] - m_new);
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][8 * u + 2 * e], sl2, mc));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][8 * u + 2 * e + 1], sl2, mc));
           psum += p0 + p1;
           w[e] = pack_bf2(p0, p1);
         }
         u32x4 wv = {w[0], w[1], w[2], w[3]};
         pf[2 * kt + u] = __builtin_bit_cast(bf16x8, wv);
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    l_run += psum;
 
     // ---- O^T += V^T P^T : k-slot e of step s4 <-> key 16*s4 + 4lh + (e&3) + 8(e>>2)
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    if (VROWMAJOR) {
+      // V tile is [key][d]; the MFMA A operand (rows d, k-slots = keys) comes from LDS transpose reads:
+      // group g = lane>>4 covers d = 32dt + 16(g&1) + 0..15 and key-half lh = g>>1; two reads per operand.
+      const int p16 = lane & 15, g = lane >> 4;
+      const unsigned va = (unsigned)(unsigned long long)(const void*)vs +
+                          (unsigned)((4 * (g >> 1) + (p16 >> 2)) * VRS + (16 * (g & 1) + 4 * (p16 & 3)) * 2);
+      unsigned long long v0[8], v1[8];
+      DMX_TR8(v0, va, 0 * VRS, 8 * VRS, 16 * VRS, 24 * VRS, 32 * VRS, 40 * VRS, 48 * VRS, 56 * VRS);
+      DMX_TR8(v1, va, 64 + 0 * VRS, 64 + 8 * VRS, 64 + 16 * VRS, 64 + 24 * VRS, 64 + 32 * VRS, 64 + 40 * VRS, 64 + 48 * VRS, 64 + 56 * VRS);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const char* vp = vs + (32 * dt + lr) * (VROW * 2) + (16 * s4 + 4 * lh) * 2;
-        const u32x2 lo = *(const u32x2*)vp;
-        const u32x2 hi = *(const u32x2*)(vp + 16);
-        const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s4], o[dt], 0, 0, 0);
+        const u32x4 vv = {(unsigned)v0[2 * s4], (unsigned)(v0[2 * s4] >> 32), (unsigned)v0[2 * s4 + 1], (unsigned)(v0[2 * s4 + 1] >> 32)};
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s4], o[0], 0, 0, 0);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const u32x4 vv = {(unsigned)v1[2 * s4], (unsigned)(v1[2 * s4] >> 32), (unsigned)v1[2 * s4 + 1], (unsigned)(v1[2 * s4 + 1] >> 32)};
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s4], o[1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const char* vp = vs + (32 * dt + lr) * (VROW * 2) + (16 * s4 + 4 * lh) * 2;
+          const u32x2 lo = *(const u32x2*)vp;
+          const u32x2 hi = *(const u32x2*)(vp + 16);
+          const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s4], o[dt], 0, 0, 0);
+        }
+    }
 
     if (it + 1 < ntiles) write_tile((it + 1) & 1);
     __syncthreads();
@@ -166,11 +221,16 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
 
 int dmx_attention_launch(const AttnArgs& a, hipStream_t stream) {
   DMX_REQUIRE(a.B > 0 && a.H > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
-  DMX_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.skv_stride % 8 == 0 && a.ldo % 4 == 0,
-              "attention: strides must be multiples of 8 (ldq=%d ldk=%d ldvt=%d skv_stride=%d)", a.ldq, a.ldk, a.ldvt, a.skv_stride);
   DMX_REQUIRE(a.kv_rows >= a.Skv, "attention: kv_rows=%d < Skv=%d", a.kv_rows, a.Skv);
-  DMX_REQUIRE(a.skv_stride >= (a.Skv + 7) / 8 * 8, "attention: skv_stride=%d < Skv=%d rounded to 8", a.skv_stride, a.Skv);
+  DMX_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "attention: strides must be multiples of 8 (ldq=%d ldk=%d)", a.ldq, a.ldk);
   dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
-  hipLaunchKernelGGL(dmx_attn_d64_kernel, grid, dim3(256), 0, stream, a);
+  if (a.v) {
+    DMX_REQUIRE(a.ldv % 8 == 0, "attention: ldv=%d must be a multiple of 8", a.ldv);
+    hipLaunchKernelGGL(dmx_attn_d64_kernel<true>, grid, dim3(256), 0, stream, a);
+  } else {
+    DMX_REQUIRE(a.vt && a.ldvt % 8 == 0 && a.skv_stride % 8 == 0, "attention: V^T strides must be multiples of 8 (ldvt=%d skv_stride=%d)", a.ldvt, a.skv_stride);
+    DMX_REQUIRE(a.skv_stride >= (a.Skv + 7) / 8 * 8, "attention: skv_stride=%d < Skv=%d rounded to 8", a.skv_stride, a.Skv);
+    hipLaunchKernelGGL(dmx_attn_d64_kernel<false>, grid, dim3(256), 0, stream, a);
+  }
   return dmx_check_launch("dmx_attn_d64_kernel");
 }

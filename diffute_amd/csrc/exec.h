@@ -118,7 +118,8 @@ class Exec {
   void gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N, int K, const float* bias,
                 void* out, int ldo, int out_f32);
   Tn layernorm(const Tn& x, const float* gamma, const float* beta, float eps);
-  void attention(const bf16* q, int ldq, const bf16* k, int ldk, int kv_rows, const bf16* vt, int ldvt, int skv_stride,
+  // fused attention core; V row-major (LDS transpose-read path)
+  void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                  bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale);
  private:
   void run_gemm(GemmArgs& a);

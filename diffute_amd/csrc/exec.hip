@@ -214,11 +214,11 @@ Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps
   return y;
 }
 
-void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, int kv_rows, const bf16* vt, int ldvt, int skv_stride,
+void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                      bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale) {
   if (dry || rc) return;
   AttnArgs a{};
-  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.vt = vt; a.ldvt = ldvt; a.skv_stride = skv_stride;
+  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.v = v; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
   char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
   ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv), tag);

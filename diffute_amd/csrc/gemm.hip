@@ -61,13 +61,23 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   if (p.timing) tm0 = (long long)__builtin_amdgcn_s_memrealtime();
   const int wm = wave % WM, wn = wave / WM;
 
-  // ---- block -> tile mapping (XCD-aware: each XCD's L2 sees one n-tile at a time)
+  // ---- block -> tile mapping.  Blocks are dealt round-robin to the 8 XCDs, so first give every XCD a contiguous
+  // range of tile ids, then rasterise that range in GROUP_M x tiles_n super-tiles: the blocks resident on one XCD at
+  // a time cover a compact (m, n) patch and share both their activation rows and their weight rows through that
+  // XCD's L2 (otherwise every n-tile of a conv re-reads the whole activation tensor from HBM / Infinity Cache).
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
   if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tile_n = bid / tiles_m;
-  const int tile_m = bid - tile_n * tiles_m;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int gm = p.group_m > 0 ? p.group_m : 8;
+  const int width = gm * tiles_n;
+  const int gid = bid / width;
+  const int first_m = gid * gm;
+  const int gsz = min(tiles_m - first_m, gm);
+  const int rem_id = bid - gid * width;
+  const int tile_m = first_m + rem_id % gsz;
+  const int tile_n = rem_id / gsz;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 

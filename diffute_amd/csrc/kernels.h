@@ -33,6 +33,7 @@ struct GemmArgs {
   const bf16* res; int ldres;   // residual or null
   void* out; int ldo; int out_f32; int geglu;
   int force_tn, force_splitk;                  // 0 = automatic
+  int group_m;                                 // m-tiles per rasterisation super-tile (0 = default 8)
   long long* timing;                           // optional per-block timeline (probe builds), normally null
   float* partial; int splitk, kt_per_split;   // filled by the launcher
   const bf16* zeros;                           // filled by the launcher
@@ -64,7 +65,8 @@ struct AttnArgs {
   const bf16* q; int ldq;        // row (b*Sq + s), head h at column h*D
   const bf16* k; int ldk;        // row (b*kv_rows + s)
   int kv_rows;                   // rows per batch in k (>= Skv; Skv unless padded)
-  const bf16* vt; int ldvt;      // V^T: row (h*D + d), column (b*skv_stride + s)
+  const bf16* vt; int ldvt;      // V^T: row (h*D + d), column (b*skv_stride + s)   (used when v == nullptr)
+  const bf16* v; int ldv;        // row-major V: row (b*kv_rows + s), head h at column h*D (LDS transpose-read path)
   int skv_stride;                // column offset between batches in vt
   bf16* o; int ldo;
   int B, H, Sq, Skv;

@@ -9,7 +9,7 @@
 //   - conv1 + bias + time-embedding broadcast add: one launch
 //   - conv2 + 1x1 conv_shortcut + residual add: one launch (shortcut appended as extra K)
 //   - nearest x2 upsample: folded into the following conv's gather
-//   - to_q|to_k one GEMM; to_v as a role-swapped GEMM that emits V^T for the attention kernel
+//   - to_q|to_k|to_v one GEMM (N = 3C); the attention kernel reads V row-major through LDS transpose reads
 //   - GEGLU: Linear(C,8C) + a*gelu(b) in one launch; every Linear bias / residual in the GEMM epilogue
 //   - all 22 time_emb_proj Linear layers: one GEMV launch
 //   - cross-attention K / V^T of the glyph context computed once per image (set_context)
@@ -25,7 +25,7 @@ namespace {
 struct XfW {
   int C = 0, heads = 0, ctx_slot = -1;
   size_t ng, nb, wpi, bpi, l1g, l1b, l2g, l2b, l3g, l3b;
-  size_t wqk, wv, wo1, bo1, wq2, wk2, wv2, wo2, bo2, wf1, bf1, wf2, bf2, wpo, bpo;
+  size_t wqkv, wo1, bo1, wq2, wkv2, wo2, bo2, wf1, bf1, wf2, bf2, wpo, bpo;
 };
 struct ConvW { size_t w, b; int c; };
 
@@ -70,15 +70,16 @@ void build_xf(dmx_unet* u, XfW& x, const std::string& p, int C, int heads) {
   x.wpi = pt.linear(p + "proj_in.weight", C, C); x.bpi = pt.f32(p + "proj_in.bias", C);
   const std::string t = p + "transformer_blocks.0.";
   x.l1g = pt.f32(t + "norm1.weight", C); x.l1b = pt.f32(t + "norm1.bias", C);
-  x.wqk = pt.reserve((size_t)2 * C * C * 2);
-  pt.linear_at(t + "attn1.to_q.weight", C, C, x.wqk, C);
-  pt.linear_at(t + "attn1.to_k.weight", C, C, x.wqk + (size_t)C * C * 2, C);
-  x.wv = pt.linear(t + "attn1.to_v.weight", C, C);
+  x.wqkv = pt.reserve((size_t)3 * C * C * 2);                      // to_q | to_k | to_v stacked: one GEMM, N = 3C
+  pt.linear_at(t + "attn1.to_q.weight", C, C, x.wqkv, C);
+  pt.linear_at(t + "attn1.to_k.weight", C, C, x.wqkv + (size_t)C * C * 2, C);
+  pt.linear_at(t + "attn1.to_v.weight", C, C, x.wqkv + (size_t)2 * C * C * 2, C);
   x.wo1 = pt.linear(t + "attn1.to_out.0.weight", C, C); x.bo1 = pt.f32(t + "attn1.to_out.0.bias", C);
   x.l2g = pt.f32(t + "norm2.weight", C); x.l2b = pt.f32(t + "norm2.bias", C);
   x.wq2 = pt.linear(t + "attn2.to_q.weight", C, C);
-  x.wk2 = pt.linear(t + "attn2.to_k.weight", C, ctx);
-  x.wv2 = pt.linear(t + "attn2.to_v.weight", C, ctx);
+  x.wkv2 = pt.reserve((size_t)2 * C * ctx * 2);                    // to_k | to_v stacked (context projections)
+  pt.linear_at(t + "attn2.to_k.weight", C, ctx, x.wkv2, ctx);
+  pt.linear_at(t + "attn2.to_v.weight", C, ctx, x.wkv2 + (size_t)C * ctx * 2, ctx);
   x.wo2 = pt.linear(t + "attn2.to_out.0.weight", C, C); x.bo2 = pt.f32(t + "attn2.to_out.0.bias", C);
   x.l3g = pt.f32(t + "norm3.weight", C); x.l3b = pt.f32(t + "norm3.bias", C);
   { PackRule r; r.kind = PackRule::GEGLU_W; r.dst = pt.reserve((size_t)8 * C * C * 2); r.rows = 8 * C; r.cols = C; r.ld = C;
@@ -224,14 +225,14 @@ extern "C" size_t dmx_unet_context_bytes(const dmx_unet* u, int B, int ctx_len) 
   if (!u) return 0;
   size_t tot = 0;
   const int sp = ctx_pad(ctx_len);
-  for (const XfW* x : u->xf_all) tot += 2 * align_up((size_t)B * sp * x->C * 2, 256);
+  for (const XfW* x : u->xf_all) tot += align_up((size_t)B * sp * 2 * x->C * 2, 256);
   return tot;
 }
-static void ctx_slot_ptrs(const dmx_unet* u, const void* cache, int B, int ctx_len, int slot, const bf16** k, const bf16** vt) {
+// context cache slot of one cross-attention layer: [B*sp][2C] bf16, columns [0,C) = K, [C,2C) = V
+static const bf16* ctx_slot_ptr(const dmx_unet* u, const void* cache, int B, int ctx_len, int slot) {
   size_t off = 0; const int sp = ctx_pad(ctx_len);
-  for (int s = 0; s < slot; ++s) off += 2 * align_up((size_t)B * sp * u->xf_all[s]->C * 2, 256);
-  const size_t one = align_up((size_t)B * sp * u->xf_all[slot]->C * 2, 256);
-  *k = (const bf16*)((const char*)cache + off); *vt = (const bf16*)((const char*)cache + off + one);
+  for (int s = 0; s < slot; ++s) off += align_up((size_t)B * sp * 2 * u->xf_all[s]->C * 2, 256);
+  return (const bf16*)((const char*)cache + off);
 }
 
 extern "C" int dmx_unet_set_context(dmx_unet* u, const void* ctx, int ctx_is_bf16, int B, int ctx_len,
@@ -245,10 +246,9 @@ extern "C" int dmx_unet_set_context(dmx_unet* u, const void* ctx, int ctx_is_bf1
   int rc = dmx_cast_pad_rows_launch(ctx, ctx_is_bf16, cp, B, ctx_len, sp, D, ex.stream);
   if (rc) return rc;
   for (const XfW* x : u->xf_all) {
-    const bf16 *k, *vt; ctx_slot_ptrs(u, cache, B, ctx_len, x->ctx_slot, &k, &vt);
-    // K[b*sp + s][C] = ctx W_k^T ; V^T[C][b*sp + s] = W_v ctx^T (role-swapped GEMM)
-    ex.gemm_raw(cp, D, B * sp, u->at<bf16>(x->wk2), D, x->C, D, nullptr, (void*)k, x->C, 0);
-    ex.gemm_raw(u->at<bf16>(x->wv2), D, x->C, cp, D, B * sp, D, nullptr, (void*)vt, B * sp, 0);
+    const bf16* kv = ctx_slot_ptr(u, cache, B, ctx_len, x->ctx_slot);
+    // [K | V][b*sp + s][2C] = ctx [W_k ; W_v]^T   (padded context rows are zero -> finite K/V rows)
+    ex.gemm_raw(cp, D, B * sp, u->at<bf16>(x->wkv2), D, 2 * x->C, D, nullptr, (void*)kv, 2 * x->C, 0);
     if (ex.rc) return ex.rc;
   }
   return ex.rc;
@@ -271,34 +271,21 @@ struct Fwd {
     ex.drop(t);
     // ---- self attention
     Tn n = ex.layernorm(h, u->at<float>(w.l1g), u->at<float>(w.l1b), 1e-5f);
-    Tn qk = ex.linear(n, u->at<bf16>(w.wqk), 2 * C, nullptr, nullptr, false);
-    // V^T[C][b*Sp + s]: one role-swapped GEMM when S is a multiple of 8 (always at 512/768 px); otherwise
-    // per-sample GEMMs into a zeroed buffer whose per-sample column stride is padded to 8 (16-byte loads).
-    const int Sp = (S + 7) / 8 * 8, ldvt = x.B * Sp;
-    bf16* vt = (bf16*)ex.raw((size_t)C * ldvt * 2);
-    if (Sp == S) {
-      ex.gemm_raw(u->at<bf16>(w.wv), C, C, n.p, n.ld, M, C, nullptr, vt, ldvt, 0);
-    } else {
-      if (!ex.dry && !ex.rc && hipMemsetAsync(vt, 0, (size_t)C * ldvt * 2, ex.stream) != hipSuccess) {
-        dmx_set_error("hipMemsetAsync failed"); ex.rc = DMX_ERR_HIP;
-      }
-      for (int b = 0; b < x.B; ++b)
-        ex.gemm_raw(u->at<bf16>(w.wv), C, C, n.p + (size_t)b * S * n.ld, n.ld, S, C, nullptr, vt + (size_t)b * Sp, ldvt, 0);
-    }
+    Tn qkv = ex.linear(n, u->at<bf16>(w.wqkv), 3 * C, nullptr, nullptr, false);
     ex.drop(n);
     Tn a = ex.make(x.B, x.H, x.W, C);
-    ex.attention(qk.p, 2 * C, qk.p + C, 2 * C, S, vt, ldvt, Sp, a.p, C, x.B, w.heads, S, S, 0.125f);
-    ex.drop(qk); ex.drop(vt);
+    ex.attention(qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, S, a.p, C, x.B, w.heads, S, S, 0.125f);
+    ex.drop(qkv);
     Tn h2 = ex.linear(a, u->at<bf16>(w.wo1), C, u->at<float>(w.bo1), &h, false);
     ex.drop(a); ex.drop(h);
     // ---- cross attention over the cached glyph-context K / V^T
     n = ex.layernorm(h2, u->at<float>(w.l2g), u->at<float>(w.l2b), 1e-5f);
     Tn q = ex.linear(n, u->at<bf16>(w.wq2), C, nullptr, nullptr, false);
     ex.drop(n);
-    const bf16 *kc = nullptr, *vtc = nullptr; const int sp = ctx_pad(ctx_len);
-    ctx_slot_ptrs(u, cache, x.B, ctx_len, w.ctx_slot, &kc, &vtc);
+    const int sp = ctx_pad(ctx_len);
+    const bf16* kvc = ctx_slot_ptr(u, cache, x.B, ctx_len, w.ctx_slot);
     a = ex.make(x.B, x.H, x.W, C);
-    ex.attention(q.p, C, kc, C, sp, vtc, x.B * sp, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
+    ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
     ex.drop(q);
     Tn h3 = ex.linear(a, u->at<bf16>(w.wo2), C, u->at<float>(w.bo2), &h2, false);
     ex.drop(a); ex.drop(h2);
@@ -392,10 +379,8 @@ extern "C" size_t dmx_unet_workspace_bytes(dmx_unet* u, int B, int H, int W, int
   Exec e2; e2.dry = true; e2.ws.reset(nullptr, 0, true);
   const int D = u->cfg.cross_attention_dim, sp = ctx_pad(ctx_len);
   void* cp = e2.raw((size_t)B * sp * D * 2);
-  for (const XfW* x : u->xf_all) {
-    e2.gemm_raw((const bf16*)cp, D, B * sp, nullptr, D, x->C, D, nullptr, nullptr, x->C, 0);
-    e2.gemm_raw(nullptr, D, x->C, (const bf16*)cp, D, B * sp, D, nullptr, nullptr, B * sp, 0);
-  }
+  for (const XfW* x : u->xf_all)
+    e2.gemm_raw((const bf16*)cp, D, B * sp, nullptr, D, 2 * x->C, D, nullptr, nullptr, 2 * x->C, 0);
   if (e2.ws.peak() > need) need = e2.ws.peak();
   return need + 4096;
 }

@@ -62,7 +62,7 @@ def pack_geglu_bias(b):
 
 
 def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=None, rowbias=None,
-              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None):
+              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0):
     """Fused conv / linear.  x0 (and x1) NHWC bf16; w packed bf16 [N][K].  Returns NHWC (bf16 or fp32)."""
     B, H, W, C0 = x0.shape
     Cin = C0 + (x1.shape[-1] if x1 is not None else 0)
@@ -96,7 +96,7 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
     Nout = N // 2 if geglu else N
     out = torch.empty(B, OH, OW, Nout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x0.device)
     d.out = out.data_ptr(); d.ldo = Nout; d.out_f32 = int(out_f32); d.geglu = int(geglu)
-    d.force_tn = force_tn; d.force_splitk = force_splitk
+    d.force_tn = force_tn; d.force_splitk = force_splitk; d.group_m = group_m
     if timing is not None:
         d.timing = timing.data_ptr()
     wsb = lib().dmx_conv_gemm_workspace_bytes(ctypes.byref(d))
@@ -140,6 +140,15 @@ def attention(q, k, vt, B, H, Sq, Skv, scale, kv_rows=None, skv_stride=None):
     skv_stride = Skv if skv_stride is None else skv_stride
     check(lib().dmx_attention_fwd(ptr(q), q.stride(0), ptr(k), k.stride(0), kv_rows, ptr(vt), vt.stride(0), skv_stride,
                                   ptr(o), H * 64, B, H, Sq, Skv, float(scale), current_stream()), "attention_fwd")
+    return o
+
+
+def attention_v(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
+    """q [B*Sq, >=H*64], k / v [B*kv_rows, >=H*64] row-major 2-D views (V read through LDS transpose reads)."""
+    o = torch.empty(B * Sq, H * 64, dtype=torch.bfloat16, device=q.device)
+    kv_rows = Skv if kv_rows is None else kv_rows
+    check(lib().dmx_attention_fwd_v(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), kv_rows,
+                                    ptr(o), H * 64, B, H, Sq, Skv, float(scale), current_stream()), "attention_fwd_v")
     return o
 
 

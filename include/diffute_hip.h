@@ -69,6 +69,7 @@ typedef struct dmx_gemm_desc {
   void* out; int ldo; int out_f32;  /* bf16 (default) or fp32 output                         */
   int geglu;                        /* 1: weights/bias GEGLU-packed, out[m][j] = a*gelu(b)   */
   int force_tn, force_splitk;       /* 0 = automatic plan; tuning / tests may pin the tile (1|2) and split */
+  int group_m;                      /* m-tiles per L2 super-tile of the block rasterisation (0 = default) */
   long long* timing;                /* optional device buffer [blocks][4]: per-block start / prologue / loop / end
                                        timestamps in 10 ns ticks (measurement aid), normally NULL */
 } dmx_gemm_desc;
@@ -93,6 +94,11 @@ int dmx_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, 
 int dmx_attention_fwd(const void* q, int ldq, const void* k, int ldk, int kv_rows,
                       const void* vt, int ldvt, int skv_stride, void* o, int ldo,
                       int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream);
+
+/* Same attention with V given row-major (row b*kv_rows+s, head h at column 64h - e.g. a slice of a fused
+ * q|k|v projection): the P.V operand is fetched with gfx950 LDS transpose reads, no V^T tensor is needed. */
+int dmx_attention_fwd_v(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                        void* o, int ldo, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream);
 
 /* K9: sinusoidal timestep embedding (flip_sin_to_cos) and the small-M fp32 linear used by the
  * time-embedding MLP.  t: int64 [t_count] (t_count 1 or B); freq: fp32 [dim/2] table. */

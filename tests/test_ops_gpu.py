@@ -188,6 +188,16 @@ def test_attention(cuda, case):
     # zero-mean random V the output is a random-walk sum, so that rounding does not average out relative to |O|:
     # expected rel error ~ 2^-9/sqrt(3) (P) (+) 2^-9/sqrt(3) (bf16 output, both sides) ~ 2.3e-3.  Stated bound 4e-3.
     assert_close(out, ref, 4e-3, name)
+    # row-major V (slices of one fused q|k|v buffer with row stride 3*H*64): LDS transpose-read path
+    if Sq == Skv:
+        qkv = torch.cat([q, k, v], dim=-1).reshape(B * Sq, 3 * H * 64).to(cuda).to(torch.bfloat16)
+        C = H * 64
+        out2 = ops.attention_v(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, H, Sq, Skv, 0.125)
+    else:
+        kv = torch.cat([kp, vp], dim=-1).reshape(B * pad, 2 * H * 64).to(cuda).to(torch.bfloat16)
+        C = H * 64
+        out2 = ops.attention_v(q.reshape(B * Sq, -1).to(cuda).to(torch.bfloat16), kv[:, :C], kv[:, C:], B, H, Sq, Skv, 0.125, kv_rows=pad)
+    assert_close(out2, ref, 4e-3, name + " (row-major V)")
 
 
 def test_im2col_and_conv_in(cuda):
