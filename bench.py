@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512 px)")
     ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--micro-batches", type=int, default=1, help="independent chains of the batch run concurrently on separate streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-csv", default="", help="write one row per kernel launch of the profiled pass")
@@ -60,7 +61,7 @@ def main():
     unet._ensure_packed()
 
     def one_pass():
-        return D.denoise(unet, sched, lat, mask, mlat, ctx, T)
+        return D.denoise(unet, sched, lat, mask, mlat, ctx, T, micro_batches=args.micro_batches)
 
     def sync_all():
         DD.barrier_sync(dist, dev)

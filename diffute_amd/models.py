@@ -245,8 +245,7 @@ class UNet2DConditionModel(_HipModel):
         h = _cabi.lib().dmx_unet_create(ctypes.byref(c))
         if not h:
             raise ValueError("UNet2DConditionModel: " + _cabi.lib().dmx_last_error().decode())
-        self._ctx_cache = None
-        self._ctx_key = None
+        self._slots = {}
         self._setup(h, seed, device)
 
     def _finalize(self, st):
@@ -256,11 +255,27 @@ class UNet2DConditionModel(_HipModel):
         freq = torch.exp(exponent / (half - self.config.freq_shift)).contiguous()
         self._freq_host = freq
         _cabi.check(_cabi.lib().dmx_unet_finalize(self._h, ctypes.c_void_p(freq.data_ptr()), st), "unet_finalize")
-        self._ctx_key = None
+        for sl in self._slots.values():
+            sl["ctx_key"] = None
+
+    # ---- execution slots: independent (workspace, context cache) pairs so that several micro-batches can be in
+    # flight on different streams at once (pipeline.denoise(..., micro_batches=n)); slot 0 serves the plain API.
+    def _slot(self, i):
+        sl = self._slots.get(i)
+        if sl is None:
+            sl = self._slots[i] = dict(ws=None, ctx_cache=None, ctx_key=None, ctx_shape=None, ws_need=None)
+        return sl
+
+    def _slot_workspace(self, sl, nbytes):
+        if sl["ws"] is None or sl["ws"].numel() < nbytes or sl["ws"].device != self.device:
+            sl["ws"] = None
+            sl["ws"] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return sl["ws"]
 
     # ---- glyph-context K/V cache (constant across denoise steps, app.ipynb:776,814)
-    def set_context(self, encoder_hidden_states):
+    def set_context(self, encoder_hidden_states, slot=0):
         self._ensure_packed()
+        sl = self._slot(slot)
         ctx = encoder_hidden_states
         _cabi.require_cuda(ctx)
         if ctx.dtype not in (torch.float32, torch.bfloat16):
@@ -271,40 +286,39 @@ class UNet2DConditionModel(_HipModel):
             raise ValueError(f"encoder_hidden_states last dim {D} != cross_attention_dim {self.config.cross_attention_dim}")
         lib = _cabi.lib()
         nb = lib.dmx_unet_context_bytes(self._h, B, S)
-        if self._ctx_cache is None or self._ctx_cache.numel() < nb or self._ctx_cache.device != ctx.device:
-            self._ctx_cache = torch.empty(nb, dtype=torch.uint8, device=ctx.device)
-        wsb = lib.dmx_unet_workspace_bytes(self._h, B, 8, 8, S)
-        ws = self._workspace(wsb)
+        if sl["ctx_cache"] is None or sl["ctx_cache"].numel() < nb or sl["ctx_cache"].device != ctx.device:
+            sl["ctx_cache"] = torch.empty(nb, dtype=torch.uint8, device=ctx.device)
+        ws = self._slot_workspace(sl, lib.dmx_unet_workspace_bytes(self._h, B, 8, 8, S))
         _cabi.check(lib.dmx_unet_set_context(self._h, _cabi.ptr(ctx), int(ctx.dtype == torch.bfloat16), B, S,
-                                             _cabi.ptr(self._ctx_cache), self._ctx_cache.numel(),
+                                             _cabi.ptr(sl["ctx_cache"]), sl["ctx_cache"].numel(),
                                              _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_set_context")
-        self._ctx_key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
+        sl["ctx_key"] = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
                          encoder_hidden_states.dtype)
-        self._ctx_shape = (B, S)
+        sl["ctx_shape"] = (B, S)
 
-    def forward_parts(self, parts, timesteps_dev, out=None, graph=False):
+    def forward_parts(self, parts, timesteps_dev, out=None, graph=False, slot=0):
         """Hot-loop entry: `parts` = list of (NCHW fp32 cuda tensor) whose channels sum to in_channels
         (fuses the torch.cat of app.ipynb:811); timesteps_dev = int64 cuda tensor [1] or [B];
-        context must have been set with set_context().  graph=True replays a captured hipGraph when the same
-        buffers are passed again (needs a non-default current stream)."""
+        context must have been set with set_context() on the same slot.  graph=True replays a captured hipGraph
+        when the same buffers are passed again (needs a non-default current stream)."""
         lib = _cabi.lib()
+        sl = self._slot(slot)
         x0 = parts[0]
         B, _, H, W = x0.shape
-        if self._ctx_key is None or self._ctx_shape[0] != B:
+        if sl["ctx_key"] is None or sl["ctx_shape"][0] != B:
             raise RuntimeError("UNet2DConditionModel: set_context() must be called with a batch-matching context first")
         ps = [(p, p.shape[1]) for p in parts] + [(None, 0)] * (3 - len(parts))
         if out is None:
             out = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=x0.device)
-        wsb = getattr(self, "_ws_need", None)
-        key = (B, H, W, self._ctx_shape[1])
-        if wsb is None or wsb[0] != key:
-            self._ws_need = wsb = (key, lib.dmx_unet_workspace_bytes(self._h, B, H, W, self._ctx_shape[1]))
-        ws = self._workspace(wsb[1])
+        key = (B, H, W, sl["ctx_shape"][1])
+        if sl["ws_need"] is None or sl["ws_need"][0] != key:
+            sl["ws_need"] = (key, lib.dmx_unet_workspace_bytes(self._h, B, H, W, sl["ctx_shape"][1]))
+        ws = self._slot_workspace(sl, sl["ws_need"][1])
         fwd = lib.dmx_unet_forward_graph if graph else lib.dmx_unet_forward
         _cabi.check(fwd(self._h, _cabi.ptr(ps[0][0]), ps[0][1], _cabi.ptr(ps[1][0]), ps[1][1],
-                                         _cabi.ptr(ps[2][0]), ps[2][1], _cabi.ptr(timesteps_dev), timesteps_dev.numel(),
-                                         _cabi.ptr(self._ctx_cache), self._ctx_shape[1], _cabi.ptr(out), B, H, W,
-                                         _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_forward")
+                        _cabi.ptr(ps[2][0]), ps[2][1], _cabi.ptr(timesteps_dev), timesteps_dev.numel(),
+                        _cabi.ptr(sl["ctx_cache"]), sl["ctx_shape"][1], _cabi.ptr(out), B, H, W,
+                        _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_forward")
         return out
 
     def forward(self, sample, timestep, encoder_hidden_states, return_dict=True, **unused):
@@ -317,7 +331,7 @@ class UNet2DConditionModel(_HipModel):
         self._ensure_packed()
         key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
                encoder_hidden_states.dtype)
-        if key != self._ctx_key:
+        if key != self._slot(0)["ctx_key"]:
             self.set_context(encoder_hidden_states)
         B = sample.shape[0]
         if not torch.is_tensor(timestep):

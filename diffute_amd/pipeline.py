@@ -14,11 +14,12 @@ from .schedulers import DDIMScheduler, DDPMScheduler
 _SIDE = {}
 
 
-def _side_stream(device):
+def _side_streams(device, n):
     key = str(device)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
+    pool = _SIDE.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool
 
 
 def mask_to_latent(mask, vae_scale_factor=8):
@@ -27,54 +28,84 @@ def mask_to_latent(mask, vae_scale_factor=8):
     return mask[:, :, ::vae_scale_factor, ::vae_scale_factor].to(torch.float32).contiguous()
 
 
-@torch.no_grad()
-def denoise(unet, scheduler, latents, mask, masked_image_latents, encoder_hidden_states,
-            num_inference_steps, variance_noise=None, eta=0.0, callback=None, use_graph=True):
-    """latents/masked_image_latents [B,4,h,w], mask [B,1,h,w] (already at latent resolution), context
-    [B,S,1024]; all on the GPU.  variance_noise: optional [steps,B,4,h,w] injected in place of the
-    per-step device randn of DDPMScheduler.step (app.ipynb:816).  Returns the final latents (fp32)."""
-    _cabi.require_cuda(latents, mask, masked_image_latents, encoder_hidden_states)
-    lib = _cabi.lib()
-    unet._ensure_packed()
-    unet.set_context(encoder_hidden_states)
-    scheduler.set_timesteps(int(num_inference_steps))
-    ts_host = [int(t) for t in scheduler.timesteps]
-    ts_dev = scheduler.timesteps.to(device=latents.device, dtype=torch.int64).contiguous()
-    x = (latents.to(torch.float32) * scheduler.init_noise_sigma).contiguous()      # app.ipynb:800
-    m = mask.to(torch.float32).contiguous()
-    ml = masked_image_latents.to(torch.float32).contiguous()
-    eps = torch.empty_like(x)
-    t_cur = torch.empty(1, dtype=torch.int64, device=x.device)        # fixed address: the captured graph reads it
-    is_ddim = isinstance(scheduler, DDIMScheduler)
-    vpred = int(scheduler.config.prediction_type == "v_prediction")
-    # the step loop runs on a side stream: hipGraph capture / replay needs a non-default stream
-    main = torch.cuda.current_stream(x.device)
-    side = _side_stream(x.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        st = _cabi.current_stream()
-        for i, t in enumerate(ts_host):
-            t_cur.copy_(ts_dev[i:i + 1], non_blocking=True)
-            unet.forward_parts([x, m, ml], t_cur, out=eps, graph=use_graph)
+class _Run:
+    """One micro-batch of the denoise loop: its own stream, UNet execution slot and fixed-address buffers."""
+
+    def __init__(self, unet, scheduler, latents, mask, mlat, ctx, slot, stream, use_graph):
+        self.unet, self.sched, self.slot, self.stream, self.use_graph = unet, scheduler, slot, stream, use_graph
+        with torch.cuda.stream(stream):
+            self.x = (latents.to(torch.float32) * scheduler.init_noise_sigma).contiguous()      # app.ipynb:800
+            self.m = mask.to(torch.float32).contiguous()
+            self.ml = mlat.to(torch.float32).contiguous()
+            self.eps = torch.empty_like(self.x)
+            self.t_cur = torch.empty(1, dtype=torch.int64, device=self.x.device)   # fixed address: the captured graph reads it
+            unet.set_context(ctx, slot=slot)
+
+    def step(self, i, t, ts_dev, coefs, noise, is_ddim, vpred):
+        lib = _cabi.lib()
+        x, eps = self.x, self.eps
+        with torch.cuda.stream(self.stream):
+            st = _cabi.current_stream()
+            self.t_cur.copy_(ts_dev[i:i + 1], non_blocking=True)
+            self.unet.forward_parts([x, self.m, self.ml], self.t_cur, out=eps, graph=self.use_graph, slot=self.slot)
             # the update is elementwise, so prev_sample overwrites the sample in place (stable pointers for the graph)
             if is_ddim:
-                sbt, sat, sap, dirc, std = scheduler.step_coefficients(t, eta)
-                nz = None
-                if eta > 0:
-                    nz = (variance_noise[i] if variance_noise is not None else torch.randn_like(x)).to(torch.float32).contiguous()
-                _cabi.check(lib.dmx_sched_step_ddim(_cabi.ptr(x), _cabi.ptr(eps), _cabi.ptr(nz), _cabi.ptr(x), x.numel(),
+                sbt, sat, sap, dirc, std = coefs
+                _cabi.check(lib.dmx_sched_step_ddim(_cabi.ptr(x), _cabi.ptr(eps), _cabi.ptr(noise), _cabi.ptr(x), x.numel(),
                                                     sbt, sat, sap, dirc, std, vpred, st), "sched_step_ddim")
             else:
-                sbt, sat, c0, c1, sigma = scheduler.step_coefficients(t)
-                nz = None
-                if t > 0:
-                    nz = (variance_noise[i] if variance_noise is not None else torch.randn_like(x)).to(torch.float32).contiguous()
-                _cabi.check(lib.dmx_sched_step_ddpm(_cabi.ptr(x), _cabi.ptr(eps), _cabi.ptr(nz), _cabi.ptr(x), x.numel(),
+                sbt, sat, c0, c1, sigma = coefs
+                _cabi.check(lib.dmx_sched_step_ddpm(_cabi.ptr(x), _cabi.ptr(eps), _cabi.ptr(noise), _cabi.ptr(x), x.numel(),
                                                     sbt, sat, c0, c1, sigma, vpred, st), "sched_step_ddpm")
-            if callback is not None:
-                callback(i, t, x, eps)
-    main.wait_stream(side)
-    return x
+
+
+@torch.no_grad()
+def denoise(unet, scheduler, latents, mask, masked_image_latents, encoder_hidden_states,
+            num_inference_steps, variance_noise=None, eta=0.0, callback=None, use_graph=True, micro_batches=1):
+    """latents/masked_image_latents [B,4,h,w], mask [B,1,h,w] (already at latent resolution), context
+    [B,S,1024]; all on the GPU.  variance_noise: optional [steps,B,4,h,w] injected in place of the
+    per-step device randn of DDPMScheduler.step (app.ipynb:816).  Returns the final latents (fp32).
+
+    micro_batches=n splits the batch into n independent chains (images do not interact), each on its own stream
+    with its own captured graph: one chain's kernels fill the CUs the other chain's small / draining kernels
+    leave idle.  Results are identical to micro_batches=1 up to per-kernel tile-plan rounding."""
+    _cabi.require_cuda(latents, mask, masked_image_latents, encoder_hidden_states)
+    unet._ensure_packed()
+    scheduler.set_timesteps(int(num_inference_steps))
+    ts_host = [int(t) for t in scheduler.timesteps]
+    dev = latents.device
+    ts_dev = scheduler.timesteps.to(device=dev, dtype=torch.int64).contiguous()
+    is_ddim = isinstance(scheduler, DDIMScheduler)
+    vpred = int(scheduler.config.prediction_type == "v_prediction")
+    B = latents.shape[0]
+    n = max(1, min(int(micro_batches), B))
+    bounds = [(B * j // n, B * (j + 1) // n) for j in range(n)]
+    main = torch.cuda.current_stream(dev)
+    streams = _side_streams(dev, n)             # the loop runs on side streams: graph capture needs a non-default stream
+    runs = []
+    for j, (lo, hi) in enumerate(bounds):
+        streams[j].wait_stream(main)
+        runs.append(_Run(unet, scheduler, latents[lo:hi], mask[lo:hi], masked_image_latents[lo:hi],
+                         encoder_hidden_states[lo:hi].contiguous(), j, streams[j], use_graph))
+    for i, t in enumerate(ts_host):
+        coefs = scheduler.step_coefficients(t, eta) if is_ddim else scheduler.step_coefficients(t)
+        need_noise = (eta > 0) if is_ddim else (t > 0)
+        for j, (lo, hi) in enumerate(bounds):
+            nz = None
+            if need_noise:
+                with torch.cuda.stream(streams[j]):
+                    nz = (variance_noise[i][lo:hi] if variance_noise is not None else torch.randn_like(runs[j].x)).to(torch.float32).contiguous()
+            runs[j].step(i, t, ts_dev, coefs, nz, is_ddim, vpred)
+        if callback is not None:
+            for s_ in streams[:n]:
+                main.wait_stream(s_)
+            callback(i, t, runs[0].x if n == 1 else torch.cat([r.x for r in runs], 0),
+                     runs[0].eps if n == 1 else torch.cat([r.eps for r in runs], 0))
+            for s_ in streams[:n]:
+                s_.wait_stream(main)            # the callback's reads finish before the next step overwrites x / eps
+    for s_ in streams[:n]:
+        main.wait_stream(s_)
+    return runs[0].x if n == 1 else torch.cat([r.x for r in runs], 0)
 
 
 @torch.no_grad()
