@@ -113,7 +113,12 @@ class Exec {
   // conv (3x3 / 1x1, optional stride-2, upsample, concat input, fused shortcut/residual/temb)
   Tn conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpts& o, void* f32_out = nullptr);
   // y[rows][N] = x[rows][K] W[N][K]^T (+bias)(+res) ; geglu -> N/2 columns
-  Tn linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu);
+  // rowstats: if non-null, *rowstats receives a workspace buffer [tiles_n][rows][2] with per-row partial (sum, sumsq)
+  // of the output (for a following folded LayerNorm); ln: statistics of x from its producer + folded vectors.
+  struct LnIn { const float* stats = nullptr; int tiles = 0; const float* c1 = nullptr; const float* c2 = nullptr; float eps = 1e-5f; };
+  struct RowStats { float* buf = nullptr; int tiles = 0; };
+  Tn linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu,
+            RowStats* rowstats = nullptr, const LnIn* ln = nullptr);
   // generic gemm on raw pointers (swapped-role V^T projection etc.)
   void gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N, int K, const float* bias,
                 void* out, int ldo, int out_f32);

@@ -179,7 +179,8 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   return y;
 }
 
-Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu) {
+Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu,
+                RowStats* rowstats, const LnIn* ln) {
   const int Nout = geglu ? N / 2 : N;
   Tn y = make(x.B, x.H, x.W, Nout);
   GemmArgs a{};
@@ -190,6 +191,13 @@ Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* 
   a.bias = bias; a.rows_per_group = 1;
   if (res) { a.res = res->p; a.ldres = res->ld; }
   a.out = y.p; a.ldo = Nout; a.geglu = geglu ? 1 : 0;
+  if (ln) { a.ln_stats = ln->stats; a.ln_tiles = ln->tiles; a.ln_c1 = ln->c1; a.ln_c2 = ln->c2; a.ln_C = x.C; a.ln_eps = ln->eps; }
+  if (rowstats) {
+    a.rowstats_out = (float*)8;                      // non-null marker so the plan is the one the launch will use
+    rowstats->tiles = dmx_gemm_tiles_n(a);
+    rowstats->buf = (float*)raw((size_t)rowstats->tiles * a.M * 2 * sizeof(float));
+    a.rowstats_out = rowstats->buf;
+  }
   run_gemm(a);
   return y;
 }

@@ -39,7 +39,7 @@ struct RowSrc {          // per-thread state for one staged activation row
 //   <2,2,32>  128x128x32, 256 thr, 4-stage ring  64 KB -> 2 blocks/CU   (mid-size GEMMs)
 //   <2,1,32>  128x 64x32, 256 thr, 4-stage ring  48 KB -> 3 blocks/CU   (N <= 64, small grids)
 //   <4,2,64>  256x128x64, 512 thr, 3-stage ring 144 KB -> 1 block/CU    (large GEMMs: 128-byte DMA rows, 85 FLOP/B)
-template <int WM, int TN, int BKT>
+template <int WM, int TN, int BKT, int NSTAGE>
 __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p) {
   constexpr int BM = 64 * WM, BN = 64 * TN, NT = 128 * WM;
   constexpr int CPR = BKT / 8;                         // 16-byte chunks per LDS row
@@ -47,7 +47,6 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   constexpr int RSTEP = NT / CPR;                      // row distance between a thread's consecutive chunks
   constexpr int XL = BM * CPR / NT, WL = BN * CPR / NT; // DMA loads per thread per K-tile (activations, weights)
   constexpr int NLOADS = XL + WL;
-  constexpr int NSTAGE = (BKT == 32) ? 4 : 3;
   constexpr int X_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = X_BYTES + W_BYTES;
   constexpr int KSTEPS = BKT / 16;
   static_assert(XL >= 1 && WL >= 1, "tile too small for the block");
@@ -236,6 +235,25 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
     }
   };
 
+  // ---- folded LayerNorm (consumer side): the GEMM runs on the RAW rows x with W' = W*diag(gamma); the epilogue
+  // applies y = rstd*(acc - mean*c1[n]) + c2[n].  Row mean / rstd come from the producer's per-n-tile partial sums.
+  constexpr int EPI_BYTES = BM * (BN + 4) * 4;
+  constexpr int LN_OFF = (NSTAGE * STAGE > EPI_BYTES) ? NSTAGE * STAGE : EPI_BYTES;
+  float* lnst = (float*)(smem + LN_OFF);               // [BM][2] = (mean, rstd); only allocated when ln_stats != null
+  if (p.ln_stats) {
+    for (int r = t; r < BM; r += NT) {
+      int m = m0 + r; if (m >= p.M) m = p.M - 1;
+      float sa = 0.f, sq = 0.f;
+      for (int j = 0; j < p.ln_tiles; ++j) {
+        const float* q = p.ln_stats + ((size_t)j * p.M + m) * 2;
+        sa += q[0]; sq += q[1];
+      }
+      const float mean = sa / (float)p.ln_C;
+      float var = sq / (float)p.ln_C - mean * mean; var = var < 0.f ? 0.f : var;
+      lnst[2 * r] = mean; lnst[2 * r + 1] = rsqrtf(var + p.ln_eps);
+    }
+  }
+
   // ---- NSTAGE-deep LDS ring, NSTAGE-1 K-tiles of DMA in flight, counted vmcnt (never drained to 0 in the loop)
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) produce(s);
@@ -251,7 +269,9 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   }
   for (;;) {
     DMX_SUBITER(0) DMX_SUBITER(1) DMX_SUBITER(2)
-    if constexpr (NSTAGE == 4) DMX_SUBITER(3)
+    if constexpr (NSTAGE >= 4) DMX_SUBITER(3)
+    if constexpr (NSTAGE >= 5) DMX_SUBITER(4)
+    if constexpr (NSTAGE >= 6) DMX_SUBITER(5)
   }
 #undef DMX_SUBITER
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the dummy tail loads before LDS is released
@@ -325,12 +345,18 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
         // 64 output columns per tile: octet o -> packed group G = o>>2 ('a' rows 64G.., gate rows 64G+32..)
         const int o = t & 7, G = o >> 2, jj = (o & 3) * 8;
         const int na = n0 + 64 * G + jj;
-        float ba[8], bg[8];
+        float ba[8], bg[8], ca[8], cg[8];
+        const float* bsrc = p.ln_stats ? p.ln_c2 : p.bias;     // LN fold: c2 already contains the bias
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const f32x4 x0 = *(const f32x4*)(p.bias + na + 4 * q), x1 = *(const f32x4*)(p.bias + na + 32 + 4 * q);
+          const f32x4 x0 = *(const f32x4*)(bsrc + na + 4 * q), x1 = *(const f32x4*)(bsrc + na + 32 + 4 * q);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { ba[4 * q + e] = x0[e]; bg[4 * q + e] = x1[e]; }
+          for (int e = 0; e < 4; ++e) { ba[4 * q + e] = x0[e]; bg[4 * q + e] = x1[e]; ca[4 * q + e] = 0.f; cg[4 * q + e] = 0.f; }
+          if (p.ln_stats) {
+            const f32x4 y0 = *(const f32x4*)(p.ln_c1 + na + 4 * q), y1 = *(const f32x4*)(p.ln_c1 + na + 32 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ca[4 * q + e] = y0[e]; cg[4 * q + e] = y1[e]; }
+          }
         }
 #pragma unroll
         for (int k = 0; k < BM * 8 / NT; ++k) {
@@ -339,51 +365,88 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
           const int m = m0 + r;
           if (m >= p.M) continue;
           const float* ta = tile + r * LDT + 64 * G + jj;
+          float mean = 0.f, rstd = 1.f;
+          if (p.ln_stats) { mean = lnst[2 * r]; rstd = lnst[2 * r + 1]; }
           float v[8];
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const f32x4 av = *(const f32x4*)(ta + 4 * q), gv = *(const f32x4*)(ta + 32 + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = (av[e] + ba[4 * q + e]) * gelu_erf_f(gv[e] + bg[4 * q + e]);
+            for (int e = 0; e < 4; ++e) {
+              const float a_ = rstd * (av[e] - mean * ca[4 * q + e]) + ba[4 * q + e];
+              const float g_ = rstd * (gv[e] - mean * cg[4 * q + e]) + bg[4 * q + e];
+              v[4 * q + e] = a_ * gelu_erf_f(g_);
+            }
           }
           *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + (n0 >> 1) + 32 * G + jj) = pack_bf8(v);
         }
       }
     } else {
-      const int o = t % OC, n = n0 + o * 8;
-      if (n < p.N) {
-        float bs[8];
+      const int o = t % OC;
+      const bool nvalid = n0 + o * 8 < p.N;
+      const int n = nvalid ? n0 + o * 8 : 0;             // clamped: loads stay in range, nothing is stored
+      float bs[8], c1[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bs[e] = 0.f;
-        if (p.bias) {
-          const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+      for (int e = 0; e < 8; ++e) { bs[e] = 0.f; c1[e] = 0.f; }
+      const float* bsrc = p.ln_stats ? p.ln_c2 : p.bias;
+      if (bsrc) {
+        const f32x4 b0 = *(const f32x4*)(bsrc + n), b1 = *(const f32x4*)(bsrc + n + 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
-        }
-        u32x4 rv[OCT];
-        if (p.res) {
+        for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
+      }
+      if (p.ln_stats) {
+        const f32x4 y0 = *(const f32x4*)(p.ln_c1 + n), y1 = *(const f32x4*)(p.ln_c1 + n + 4);
 #pragma unroll
-          for (int k = 0; k < OCT; ++k) {
-            int m = m0 + t / OC + (NT / OC) * k; if (m >= p.M) m = p.M - 1;
-            rv[k] = *(const u32x4*)(p.res + (size_t)m * p.ldres + n);
-          }
-        }
+        for (int e = 0; e < 4; ++e) { c1[e] = y0[e]; c1[4 + e] = y1[e]; }
+      }
+      u32x4 rv[OCT];
+      if (p.res) {
 #pragma unroll
         for (int k = 0; k < OCT; ++k) {
-          asm volatile("" ::: "memory");               // keep each item's LDS reads in its own iteration (VGPR pressure)
-          const int r = t / OC + (NT / OC) * k;
-          const int m = m0 + r;
-          if (m >= p.M) continue;
-          const f32x4 v0 = *(const f32x4*)(tile + r * LDT + o * 8), v1 = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
-          float v[8];
+          int m = m0 + t / OC + (NT / OC) * k; if (m >= p.M) m = p.M - 1;
+          rv[k] = *(const u32x4*)(p.res + (size_t)m * p.ldres + n);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < OCT; ++k) {
+        asm volatile("" ::: "memory");               // keep each item's LDS reads in its own iteration (VGPR pressure)
+        const int r = t / OC + (NT / OC) * k;
+        const int m = m0 + r;
+        const bool live = nvalid && m < p.M;
+        const f32x4 v0 = *(const f32x4*)(tile + r * LDT + o * 8), v1 = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
+        float v[8];
+        if (p.ln_stats) {
+          const float mean = lnst[2 * r], rstd = lnst[2 * r + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = rstd * (v0[e] - mean * c1[e]) + bs[e];
+            v[4 + e] = rstd * (v1[e] - mean * c1[4 + e]) + bs[4 + e];
+          }
+        } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bs[e]; v[4 + e] = v1[e] + bs[4 + e]; }
-          if (p.res) {
-            float rf[8]; unpack_bf8(rv[k], rf);
+        }
+        if (p.res) {
+          float rf[8]; unpack_bf8(rv[k], rf);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          for (int e = 0; e < 8; ++e) v[e] += rf[e];
+        }
+        const u32x4 pk = pack_bf8(v);
+        if (live) *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + n) = pk;
+        if (p.rowstats_out) {
+          // per-row (sum, sumsq) of the rounded outputs over this n-tile: the OC lanes of a row are adjacent lanes
+          float f[8]; unpack_bf8(pk, f);
+          float sa = 0.f, sq = 0.f;
+          if (live) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sa += f[e]; sq += f[e] * f[e]; }
           }
-          *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + n) = pack_bf8(v);
+#pragma unroll
+          for (int d = 1; d < OC; d <<= 1) { sa += __shfl_xor(sa, d); sq += __shfl_xor(sq, d); }
+          if (o == 0 && m < p.M) {
+            float* q = p.rowstats_out + ((size_t)tile_n * p.M + m) * 2;
+            q[0] = sa; q[1] = sq;
+          }
         }
       }
     }
@@ -471,10 +534,11 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[3] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[4] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
+    {256, 128, 32, 256, 1.20, 10.0},        // experimental: 6-stage ring of 32-deep tiles (only via force_tn = 4)
 };
 
 static double plan_cost(const GemmArgs& a, int c, int sk) {
@@ -499,7 +563,7 @@ static double plan_cost(const GemmArgs& a, int c, int sk) {
 
 void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_out) {
   int best_c = 0, best_sk = 1; double best = 1e300;
-  if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
+  if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0 && !a.rowstats_out && !a.ln_stats) {
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == a.ups &&
           !(a.geglu && (tp.cfg == 1 || tp.sk > 1))) {
@@ -509,17 +573,19 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
         return;
       }
   }
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < 4; ++c) {
     const TileCfg& T = kCfg[c];
+    if (c == 3 && a.force_tn != 4) continue;
     if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
     if (a.geglu && c == 1) continue;
     if (a.force_tn == 1 && c != 1) continue;
     if (a.force_tn == 2 && c != 0) continue;
     if (a.force_tn == 3 && c != 2) continue;
+    if (a.force_tn == 4 && c != 3) continue;
     if (!a.force_tn && c != 1 && a.N <= 64) continue;
     if (!a.force_tn && c == 2 && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
     const int nkt = a.K / T.bk;
-    const int max_sk = (a.geglu || (a.N % 4) != 0) ? 1 : 16;
+    const int max_sk = (a.geglu || (a.N % 4) != 0 || a.rowstats_out || a.ln_stats) ? 1 : 16;   // those epilogues live in the GEMM kernel
     for (int sk = 1; sk <= max_sk; ++sk) {
       if (a.force_splitk && sk != a.force_splitk) continue;
       if (sk > 1 && nkt / sk < (T.bk == 64 ? 4 : 8)) break;
@@ -533,21 +599,28 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
   *cfg_out = best_c; *splitk_out = best_sk; *ktps_out = ktps;
 }
 
+int dmx_gemm_tiles_n(const GemmArgs& a) {
+  int c, sk, ktps;
+  dmx_gemm_plan(a, &c, &sk, &ktps);
+  return cdiv(a.N, kCfg[c].bn);
+}
+
 size_t dmx_gemm_workspace_bytes(const GemmArgs& a) {
   int c, sk, ktps;
   dmx_gemm_plan(a, &c, &sk, &ktps);
   return sk > 1 ? (size_t)sk * a.M * a.N * sizeof(float) : 0;
 }
 
-template <int WM, int TN, int BKT>
+template <int WM, int TN, int BKT, int NST>
 static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-  constexpr int BM = 64 * WM, BN = 64 * TN, NST = (BKT == 32) ? 4 : 3;
+  constexpr int BM = 64 * WM, BN = 64 * TN;
   size_t lds = (size_t)NST * (BM + BN) * BKT * 2;
   const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);       // fp32 staging tile of the coalesced epilogue
   if (lds_epi > lds) lds = lds_epi;
+  if (a.ln_stats) lds += (size_t)BM * 2 * sizeof(float);               // (mean, rstd) per row of the folded LayerNorm
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT>), grid, dim3(128 * WM), lds, stream, a);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float))); attr = true; }
+  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST>), grid, dim3(128 * WM), lds, stream, a);
 }
 
 int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -557,7 +630,9 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   DMX_REQUIRE(a.cx0 % 32 == 0 && a.Cin % 32 == 0, "gemm: channel splits must be multiples of 32 (Cin=%d cx0=%d)", a.Cin, a.cx0);
   DMX_REQUIRE(a.Ktaps % 32 == 0 && a.Ktaps <= a.K, "gemm: bad Ktaps=%d K=%d", a.Ktaps, a.K);
   if (a.Ktaps < a.K) DMX_REQUIRE(a.s0 != nullptr && a.cs0 % 32 == 0, "gemm: shortcut segment needs s0 and aligned cs0");
-  if (a.geglu) DMX_REQUIRE(a.bias && a.N % 128 == 0 && !a.out_f32 && !a.res && !a.rowbias && a.ldo % 8 == 0, "gemm: GEGLU needs bias, N%%128==0, bf16 out");
+  if (a.ln_stats) DMX_REQUIRE(a.ln_c1 && a.ln_c2 && a.ln_tiles > 0 && a.ln_C > 0 && !a.out_f32 && a.N % 8 == 0 && a.ldo % 8 == 0, "gemm: folded LayerNorm needs c1/c2, bf16 output and N %% 8 == 0");
+  if (a.rowstats_out) DMX_REQUIRE(!a.out_f32 && a.N % 8 == 0 && a.ldo % 8 == 0 && !a.geglu, "gemm: row statistics need the bf16 coalesced epilogue");
+  if (a.geglu) DMX_REQUIRE((a.bias || a.ln_stats) && a.N % 128 == 0 && !a.out_f32 && !a.res && !a.rowbias && a.ldo % 8 == 0, "gemm: GEGLU needs bias, N%%128==0, bf16 out");
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;
   int c, sk, ktps;
@@ -577,12 +652,13 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = 2.0 * ((double)a.M * (a.K / (a.direct ? 1 : (a.ksize * a.ksize))) + (double)a.N * a.K + (double)a.M * (a.geglu ? a.N / 2 : a.N));
   char tag[96];
-  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, c == 0 ? 2 : (c == 1 ? 1 : 3), sk);
+  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, c == 0 ? 2 : (c == 1 ? 1 : c + 1), sk);
   {
     ProfScope ps(c == 0 ? PROF_GEMM128 : (c == 1 ? PROF_GEMM64 : PROF_GEMM256), stream, flops, bytes, tag);
-    if (c == 0) launch_cfg<2, 2, 32>(a, grid, stream);
-    else if (c == 1) launch_cfg<2, 1, 32>(a, grid, stream);
-    else launch_cfg<4, 2, 64>(a, grid, stream);
+    if (c == 0) launch_cfg<2, 2, 32, 4>(a, grid, stream);
+    else if (c == 1) launch_cfg<2, 1, 32, 4>(a, grid, stream);
+    else if (c == 2) launch_cfg<4, 2, 64, 3>(a, grid, stream);
+    else launch_cfg<4, 2, 32, 6>(a, grid, stream);
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;
@@ -595,4 +671,35 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     rc = dmx_check_launch("dmx_splitk_reduce_kernel");
   }
   return rc;
+}
+
+// ------------------------------------------------------------------------- folded-LayerNorm weight preparation
+// One wave per output row n: W'[n][k] = bf16(W[n][k] * gamma[k]); c1[n] = sum_k W'[n][k] (the values the MFMA will
+// actually multiply); c2[n] = sum_k beta[k] * W[n][k] (+ bias[n]).
+__global__ __launch_bounds__(256) void dmx_ln_fold_kernel(const bf16* w_raw, bf16* w_out, const float* gamma, const float* beta,
+                                                          const float* bias, float* c1, float* c2, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    float w[8]; unpack_bf8(*(const u32x4*)(w_raw + (size_t)n * K + k), w);
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { o[i] = w[i] * gamma[k + i]; s2 += beta[k + i] * w[i]; }
+    const u32x4 pk = pack_bf8(o);
+    float r[8]; unpack_bf8(pk, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1 += r[i];
+    *(u32x4*)(w_out + (size_t)n * K + k) = pk;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+  if (lane == 0) { c1[n] = s1; c2[n] = s2 + (bias ? bias[n] : 0.f); }
+}
+int dmx_ln_fold_launch(const bf16* w_raw, bf16* w_out, const float* gamma, const float* beta, const float* bias,
+                       float* c1, float* c2, int N, int K, hipStream_t stream) {
+  DMX_REQUIRE(K % 8 == 0, "ln_fold: K=%d must be a multiple of 8", K);
+  hipLaunchKernelGGL(dmx_ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, stream, w_raw, w_out, gamma, beta, bias, c1, c2, N, K);
+  return dmx_check_launch("dmx_ln_fold_kernel");
 }

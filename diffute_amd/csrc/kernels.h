@@ -34,6 +34,12 @@ struct GemmArgs {
   void* out; int ldo; int out_f32; int geglu;
   int force_tn, force_splitk;                  // 0 = automatic
   int group_m;                                 // m-tiles per rasterisation super-tile (0 = default 8)
+  // folded LayerNorm: a producer GEMM emits per-row partial (sum, sumsq) of its rounded output, the consumer GEMM
+  // multiplies the RAW rows by W' = W*diag(gamma) and finishes y = rstd*(acc - mean*c1[n]) + c2[n] in its epilogue
+  float* rowstats_out;                         // producer: [tiles_n][M][2] or null
+  const float* ln_stats; int ln_tiles;         // consumer: the producer's partials and how many n-tiles it had
+  const float* ln_c1; const float* ln_c2;      // [N]: c1 = sum_k W'[n][k] ; c2 = sum_k beta[k]*W[n][k] (+ bias[n])
+  int ln_C; float ln_eps;                      // normalised feature count (= K) and epsilon
   long long* timing;                           // optional per-block timeline (probe builds), normally null
   float* partial; int splitk, kt_per_split;   // filled by the launcher
   const bf16* zeros;                           // filled by the launcher
@@ -42,6 +48,10 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
 size_t dmx_gemm_workspace_bytes(const GemmArgs& a);
 void dmx_gemm_plan(const GemmArgs& a, int* tn, int* splitk, int* ktps);
 int dmx_zero_page(const bf16** out);
+int dmx_gemm_tiles_n(const GemmArgs& a);       // n-tiles of the plan that dmx_gemm_launch will pick (rowstats_out sizing)
+// W' = bf16(W*gamma) and the c1 / c2 vectors of the folded LayerNorm, from the raw bf16 weights (rows may be GEGLU-packed)
+int dmx_ln_fold_launch(const bf16* w_raw, bf16* w_out, const float* gamma, const float* beta, const float* bias,
+                       float* c1, float* c2, int N, int K, hipStream_t stream);
 
 // ------------------------------------------------------------------ norm.hip
 struct GroupNormArgs {

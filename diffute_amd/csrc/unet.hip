@@ -26,6 +26,8 @@ struct XfW {
   int C = 0, heads = 0, ctx_slot = -1;
   size_t ng, nb, wpi, bpi, l1g, l1b, l2g, l2b, l3g, l3b;
   size_t wqkv, wo1, bo1, wq2, wkv2, wo2, bo2, wf1, bf1, wf2, bf2, wpo, bpo;
+  // folded LayerNorm: raw (as loaded) copies of the three LN-consuming weights + the derived c1 / c2 vectors
+  size_t wqkv_raw, wq2_raw, wf1_raw, c1_qkv, c2_qkv, c1_q2, c2_q2, c1_f1, c2_f1;
 };
 struct ConvW { size_t w, b; int c; };
 
@@ -70,20 +72,24 @@ void build_xf(dmx_unet* u, XfW& x, const std::string& p, int C, int heads) {
   x.wpi = pt.linear(p + "proj_in.weight", C, C); x.bpi = pt.f32(p + "proj_in.bias", C);
   const std::string t = p + "transformer_blocks.0.";
   x.l1g = pt.f32(t + "norm1.weight", C); x.l1b = pt.f32(t + "norm1.bias", C);
-  x.wqkv = pt.reserve((size_t)3 * C * C * 2);                      // to_q | to_k | to_v stacked: one GEMM, N = 3C
-  pt.linear_at(t + "attn1.to_q.weight", C, C, x.wqkv, C);
-  pt.linear_at(t + "attn1.to_k.weight", C, C, x.wqkv + (size_t)C * C * 2, C);
-  pt.linear_at(t + "attn1.to_v.weight", C, C, x.wqkv + (size_t)2 * C * C * 2, C);
+  x.wqkv_raw = pt.reserve((size_t)3 * C * C * 2);                  // to_q | to_k | to_v stacked: one GEMM, N = 3C
+  pt.linear_at(t + "attn1.to_q.weight", C, C, x.wqkv_raw, C);
+  pt.linear_at(t + "attn1.to_k.weight", C, C, x.wqkv_raw + (size_t)C * C * 2, C);
+  pt.linear_at(t + "attn1.to_v.weight", C, C, x.wqkv_raw + (size_t)2 * C * C * 2, C);
+  x.wqkv = pt.reserve((size_t)3 * C * C * 2);                      // norm1's gamma folded in (finalize)
+  x.c1_qkv = pt.reserve((size_t)3 * C * 4); x.c2_qkv = pt.reserve((size_t)3 * C * 4);
   x.wo1 = pt.linear(t + "attn1.to_out.0.weight", C, C); x.bo1 = pt.f32(t + "attn1.to_out.0.bias", C);
   x.l2g = pt.f32(t + "norm2.weight", C); x.l2b = pt.f32(t + "norm2.bias", C);
-  x.wq2 = pt.linear(t + "attn2.to_q.weight", C, C);
+  x.wq2_raw = pt.linear(t + "attn2.to_q.weight", C, C);
+  x.wq2 = pt.reserve((size_t)C * C * 2); x.c1_q2 = pt.reserve((size_t)C * 4); x.c2_q2 = pt.reserve((size_t)C * 4);
   x.wkv2 = pt.reserve((size_t)2 * C * ctx * 2);                    // to_k | to_v stacked (context projections)
   pt.linear_at(t + "attn2.to_k.weight", C, ctx, x.wkv2, ctx);
   pt.linear_at(t + "attn2.to_v.weight", C, ctx, x.wkv2 + (size_t)C * ctx * 2, ctx);
   x.wo2 = pt.linear(t + "attn2.to_out.0.weight", C, C); x.bo2 = pt.f32(t + "attn2.to_out.0.bias", C);
   x.l3g = pt.f32(t + "norm3.weight", C); x.l3b = pt.f32(t + "norm3.bias", C);
   { PackRule r; r.kind = PackRule::GEGLU_W; r.dst = pt.reserve((size_t)8 * C * C * 2); r.rows = 8 * C; r.cols = C; r.ld = C;
-    pt.add(t + "ff.net.0.proj.weight", {8 * C, C}, r); x.wf1 = r.dst; }
+    pt.add(t + "ff.net.0.proj.weight", {8 * C, C}, r); x.wf1_raw = r.dst; }
+  x.wf1 = pt.reserve((size_t)8 * C * C * 2); x.c1_f1 = pt.reserve((size_t)8 * C * 4); x.c2_f1 = pt.reserve((size_t)8 * C * 4);
   { PackRule r; r.kind = PackRule::GEGLU_B; r.dst = pt.reserve((size_t)8 * C * 4); r.rows = 8 * C;
     pt.add(t + "ff.net.0.proj.bias", {8 * C}, r); x.bf1 = r.dst; }
   x.wf2 = pt.linear(t + "ff.net.2.weight", C, 4 * C); x.bf2 = pt.f32(t + "ff.net.2.bias", C);
@@ -210,6 +216,16 @@ extern "C" int dmx_unet_finalize(dmx_unet* u, const float* h_freq, dmx_stream_t 
   int rc = 0;
   for (int i = 0; i < 4 && !rc; ++i) { for (auto& r : u->down_res[i]) if (!rc) rc = fuse(r); for (auto& r : u->up_res[i]) if (!rc) rc = fuse(r); }
   if (!rc) rc = fuse(u->mid_res[0]); if (!rc) rc = fuse(u->mid_res[1]);
+  // fold norm1/2/3 of every BasicTransformerBlock into the GEMM that consumes it (W' = W*gamma, c1, c2)
+  for (const XfW* x : u->xf_all) {
+    const int C = x->C;
+    if (!rc) rc = dmx_ln_fold_launch(u->at<bf16>(x->wqkv_raw), u->at<bf16>(x->wqkv), u->at<float>(x->l1g), u->at<float>(x->l1b), nullptr,
+                                     u->at<float>(x->c1_qkv), u->at<float>(x->c2_qkv), 3 * C, C, s);
+    if (!rc) rc = dmx_ln_fold_launch(u->at<bf16>(x->wq2_raw), u->at<bf16>(x->wq2), u->at<float>(x->l2g), u->at<float>(x->l2b), nullptr,
+                                     u->at<float>(x->c1_q2), u->at<float>(x->c2_q2), C, C, s);
+    if (!rc) rc = dmx_ln_fold_launch(u->at<bf16>(x->wf1_raw), u->at<bf16>(x->wf1), u->at<float>(x->l3g), u->at<float>(x->l3b), u->at<float>(x->bf1),
+                                     u->at<float>(x->c1_f1), u->at<float>(x->c2_f1), 8 * C, C, s);
+  }
   DMX_HIP(hipStreamSynchronize(s));
   const bf16* zp = nullptr;
   if (!rc) rc = dmx_zero_page(&zp);                  // allocate the padding page now, never inside a stream capture
@@ -267,32 +283,35 @@ struct Fwd {
   Tn xformer(const XfW& w, const Tn& x) {
     const int G = u->cfg.norm_num_groups, C = w.C, S = x.H * x.W, M = x.rows();
     Tn t = ex.groupnorm(x, nullptr, u->at<float>(w.ng), u->at<float>(w.nb), G, 1e-6f, false);
-    Tn h = ex.linear(t, u->at<bf16>(w.wpi), C, u->at<float>(w.bpi), nullptr, false);
+    // LayerNorms are folded: each residual-stream producer also emits per-row (sum, sumsq) partials and the
+    // consuming GEMM multiplies the raw rows by W*gamma and normalises in its epilogue - no LN kernels, no LN tensors.
+    Exec::RowStats st1, st2, st3;
+    Tn h = ex.linear(t, u->at<bf16>(w.wpi), C, u->at<float>(w.bpi), nullptr, false, &st1);
     ex.drop(t);
     // ---- self attention
-    Tn n = ex.layernorm(h, u->at<float>(w.l1g), u->at<float>(w.l1b), 1e-5f);
-    Tn qkv = ex.linear(n, u->at<bf16>(w.wqkv), 3 * C, nullptr, nullptr, false);
-    ex.drop(n);
+    Exec::LnIn ln1; ln1.stats = st1.buf; ln1.tiles = st1.tiles; ln1.c1 = u->at<float>(w.c1_qkv); ln1.c2 = u->at<float>(w.c2_qkv);
+    Tn qkv = ex.linear(h, u->at<bf16>(w.wqkv), 3 * C, nullptr, nullptr, false, nullptr, &ln1);
+    ex.drop(st1.buf);
     Tn a = ex.make(x.B, x.H, x.W, C);
     ex.attention(qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, S, a.p, C, x.B, w.heads, S, S, 0.125f);
     ex.drop(qkv);
-    Tn h2 = ex.linear(a, u->at<bf16>(w.wo1), C, u->at<float>(w.bo1), &h, false);
+    Tn h2 = ex.linear(a, u->at<bf16>(w.wo1), C, u->at<float>(w.bo1), &h, false, &st2);
     ex.drop(a); ex.drop(h);
-    // ---- cross attention over the cached glyph-context K / V^T
-    n = ex.layernorm(h2, u->at<float>(w.l2g), u->at<float>(w.l2b), 1e-5f);
-    Tn q = ex.linear(n, u->at<bf16>(w.wq2), C, nullptr, nullptr, false);
-    ex.drop(n);
+    // ---- cross attention over the cached glyph-context K / V
+    Exec::LnIn ln2; ln2.stats = st2.buf; ln2.tiles = st2.tiles; ln2.c1 = u->at<float>(w.c1_q2); ln2.c2 = u->at<float>(w.c2_q2);
+    Tn q = ex.linear(h2, u->at<bf16>(w.wq2), C, nullptr, nullptr, false, nullptr, &ln2);
+    ex.drop(st2.buf);
     const int sp = ctx_pad(ctx_len);
     const bf16* kvc = ctx_slot_ptr(u, cache, x.B, ctx_len, w.ctx_slot);
     a = ex.make(x.B, x.H, x.W, C);
     ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
     ex.drop(q);
-    Tn h3 = ex.linear(a, u->at<bf16>(w.wo2), C, u->at<float>(w.bo2), &h2, false);
+    Tn h3 = ex.linear(a, u->at<bf16>(w.wo2), C, u->at<float>(w.bo2), &h2, false, &st3);
     ex.drop(a); ex.drop(h2);
     // ---- GEGLU feed-forward
-    n = ex.layernorm(h3, u->at<float>(w.l3g), u->at<float>(w.l3b), 1e-5f);
-    Tn g = ex.linear(n, u->at<bf16>(w.wf1), 8 * C, u->at<float>(w.bf1), nullptr, true);
-    ex.drop(n);
+    Exec::LnIn ln3; ln3.stats = st3.buf; ln3.tiles = st3.tiles; ln3.c1 = u->at<float>(w.c1_f1); ln3.c2 = u->at<float>(w.c2_f1);
+    Tn g = ex.linear(h3, u->at<bf16>(w.wf1), 8 * C, nullptr, nullptr, true, nullptr, &ln3);
+    ex.drop(st3.buf);
     Tn h4 = ex.linear(g, u->at<bf16>(w.wf2), C, u->at<float>(w.bf2), &h3, false);
     ex.drop(g); ex.drop(h3);
     Tn y = ex.linear(h4, u->at<bf16>(w.wpo), C, u->at<float>(w.bpo), &x, false);
