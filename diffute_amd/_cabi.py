@@ -7,7 +7,8 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffute_hip.so")
+# DIFFUTE_HIP_LIB: A/B builds of the same library (kernel experiments); the default is the in-tree build
+_LIB_PATH = os.environ.get("DIFFUTE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffute_hip.so")
 _lib = None
 
 
@@ -20,7 +21,7 @@ class GemmDesc(ctypes.Structure):
         ("w", c_void_p), ("ldw", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
         ("bias", c_void_p), ("rowbias", c_void_p), ("rows_per_group", c_int), ("ldrb", c_int),
         ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("geglu", c_int),
-        ("force_tn", c_int), ("force_splitk", c_int), ("group_m", c_int), ("timing", c_void_p),
+        ("force_tn", c_int), ("force_splitk", c_int), ("group_m", c_int), ("timing", c_void_p), ("dbg", c_int),
     ]
 
 

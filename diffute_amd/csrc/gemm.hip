@@ -39,13 +39,23 @@ struct RowSrc {          // per-thread state for one staged activation row
 //   <2,2,32>  128x128x32, 256 thr, 4-stage ring  64 KB -> 2 blocks/CU   (mid-size GEMMs)
 //   <2,1,32>  128x 64x32, 256 thr, 4-stage ring  48 KB -> 3 blocks/CU   (N <= 64, small grids)
 //   <4,2,64>  256x128x64, 512 thr, 3-stage ring 144 KB -> 1 block/CU    (large GEMMs: 128-byte DMA rows, 85 FLOP/B)
-template <int WM, int TN, int BKT, int NSTAGE>
-__global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p) {
-  constexpr int BM = 64 * WM, BN = 64 * TN, NT = 128 * WM;
+//   <2,2,64,3,TM=4,NP=4>  warp-specialised 256x128x64: waves 0-3 are consumers (each a 128x64 MFMA sub-tile), waves 4-7
+//             only issue the LDS-DMA refills - a DMA instruction stalls its wave ~100 cycles, so keeping them off the
+//             MFMA waves lets the matrix pipe and the DMA queue run concurrently.
+// measurement aid: 100 MHz wall ticks, or (dbg bit 2) shader-clock cycles - their ratio is the effective clock
+__device__ __forceinline__ long long dmx_now(int dbg) {
+  return (dbg & 4) ? (long long)__builtin_amdgcn_s_memtime() : (long long)__builtin_amdgcn_s_memrealtime();
+}
+template <int WM, int TN, int BKT, int NSTAGE, int TM = 2, int NP = 0>
+__global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const GemmArgs p) {
+  constexpr int BM = 32 * TM * WM, BN = 64 * TN;
+  constexpr int NC = 2 * WM;                           // consumer (MFMA) waves: WM along m x 2 along n
+  constexpr int NT = 64 * (NC + NP);                   // block threads
+  constexpr int NL = NP ? 64 * NP : NT;                // threads that stage tiles (all of them unless warp-specialised)
   constexpr int CPR = BKT / 8;                         // 16-byte chunks per LDS row
   constexpr int ROWB = BKT * 2;                        // LDS row bytes
-  constexpr int RSTEP = NT / CPR;                      // row distance between a thread's consecutive chunks
-  constexpr int XL = BM * CPR / NT, WL = BN * CPR / NT; // DMA loads per thread per K-tile (activations, weights)
+  constexpr int RSTEP = NL / CPR;                      // row distance between a thread's consecutive chunks
+  constexpr int XL = BM * CPR / NL, WL = BN * CPR / NL; // DMA loads per thread per K-tile (activations, weights)
   constexpr int NLOADS = XL + WL;
   constexpr int X_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = X_BYTES + W_BYTES;
   constexpr int KSTEPS = BKT / 16;
@@ -57,8 +67,11 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   long long tm0 = 0, tm1 = 0, tm2 = 0;
-  if (p.timing) tm0 = (long long)__builtin_amdgcn_s_memrealtime();
-  const int wm = wave % WM, wn = wave / WM;
+  if (p.timing) tm0 = dmx_now(p.dbg);
+  const bool is_loader = (NP == 0) || wave >= NC, is_consumer = (NP == 0) || wave < NC;
+  const int lt = NP ? t - 64 * NC : t;                 // index among the staging threads (loaders only)
+  const int lwave = NP ? wave - NC : wave;
+  const int wm = wave % WM, wn = (wave / WM) & 1;
 
   // ---- block -> tile mapping.  Blocks are dealt round-robin to the 8 XCDs, so first give every XCD a contiguous
   // range of tile ids, then rasterise that range in GROUP_M x tiles_n super-tiles: the blocks resident on one XCD at
@@ -87,13 +100,13 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
     kt_end = min(kt_begin + p.kt_per_split, nkt_total);
   }
 
-  // ---- per-thread staging rows: 16-byte chunk q = t + NT*i -> row q/CPR, slot q%CPR
-  const int slot = t % CPR;
+  // ---- per-thread staging rows (loader threads): 16-byte chunk q = lt + NL*i -> row q/CPR, slot q%CPR
+  const int slot = lt % CPR;
   RowSrc xr[XL];
   int kcx[XL];
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
-    const int r = t / CPR + RSTEP * i;
+    const int r = lt / CPR + RSTEP * i;
     const int m = m0 + r;
     kcx[i] = (slot ^ swz(r)) * 8;
     xr[i].valid = m < p.M;
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   const char* wp[WL]; int winc[WL];
 #pragma unroll
   for (int i = 0; i < WL; ++i) {
-    const int r = t / CPR + RSTEP * i;
+    const int r = lt / CPR + RSTEP * i;
     const int n = n0 + r;
     const int kc = (slot ^ swz(r)) * 8;
     if (n < p.N) { wp[i] = (const char*)(p.w + (size_t)n * p.ldw + (size_t)kt_begin * BKT + kc); winc[i] = ROWB; }
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
         if (p.direct) {
           g = src + (size_t)xr[i].bbase * ld;
         } else if (sc) {       // shortcut: 1x1 at the output pixel (shortcut source has the output grid)
-          g = src + (size_t)(m0 + t / CPR + RSTEP * i) * ld;
+          g = src + (size_t)(m0 + lt / CPR + RSTEP * i) * ld;
         } else {
           const int iy = xr[i].iy0 + dy, ix = xr[i].ix0 + dx;
           if (iy >= 0 && iy < eh && ix >= 0 && ix < ew) {
@@ -159,44 +172,47 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
     }
   };
   // Issues exactly NLOADS global_load_lds per thread; past the end: dummy loads of the zero page into a buffer
-  // nobody reads, so the counted vmcnt below stays uniform through the pipeline tail.
+  // nobody reads, so the counted vmcnt below stays uniform through the pipeline tail.  The (rare, bulky) segment
+  // switch is kept out of this hot helper: callers run `advance_segment()` once per K-tile before it.
+  auto advance_segment = [&]() {
+    if (p_left == 0 && p_kt < kt_end) segment_setup(p_kt * BKT);
+  };
   auto produce = [&](int buf) {
     char* xs = smem + buf * STAGE;
     char* ws = xs + X_BYTES;
     if (p_kt < kt_end) {
-      if (p_left == 0) segment_setup(p_kt * BKT);
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)xp[i], (lptr_t)(xs + (wave * 64 + NT * i) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)xp[i], (lptr_t)(xs + (lwave * 64 + NL * i) * 16), 16, 0, 0);
         xp[i] += xinc[i];
       }
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(ws + (wave * 64 + NT * i) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(ws + (lwave * 64 + NL * i) * 16), 16, 0, 0);
         wp[i] += winc[i];
       }
       ++p_kt; --p_left;
     } else {
 #pragma unroll
       for (int i = 0; i < NLOADS; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)p.zeros, (lptr_t)(xs + (wave * 64 + NT * (i % XL)) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)p.zeros, (lptr_t)(xs + (lwave * 64 + NL * (i % XL)) * 16), 16, 0, 0);
     }
   };
 
-  f32x16 acc[TN][2];
+  f32x16 acc[TN][TM];
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TM; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   // fragment read addresses for this lane (stage offset is an immediate: the loop is unrolled over the ring)
   const int lr = lane & 31, lh = lane >> 5;
-  int xad[2][KSTEPS], wad[TN][KSTEPS];
+  int xad[TM][KSTEPS], wad[TN][KSTEPS];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int r = wm * 64 + b * 32 + lr;
+  for (int b = 0; b < TM; ++b) {
+    const int r = wm * (32 * TM) + b * 32 + lr;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) xad[b][kk] = r * ROWB + (((2 * kk + lh) ^ swz(r)) << 4);
   }
@@ -210,35 +226,52 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   // before the MFMAs of k-step kk, so LDS latency hides under the matrix pipe instead of serialising with it.
   auto compute = [&](const int J) {
     const char* st = smem + J * STAGE;
-    bf16x8 xf[2][2], wf[2][TN];
+    if constexpr (TN <= 2) {
+      bf16x8 xf[2][TM], wf[2][TN];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) xf[0][b] = *(const bf16x8*)(st + xad[b][0]);
+      for (int b = 0; b < TM; ++b) xf[0][b] = *(const bf16x8*)(st + xad[b][0]);
 #pragma unroll
-    for (int a = 0; a < TN; ++a) wf[0][a] = *(const bf16x8*)(st + wad[a][0]);
+      for (int a = 0; a < TN; ++a) wf[0][a] = *(const bf16x8*)(st + wad[a][0]);
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk + 1 < KSTEPS) {
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < KSTEPS) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) xf[nxt][b] = *(const bf16x8*)(st + xad[b][kk + 1]);
+          for (int b = 0; b < TM; ++b) xf[nxt][b] = *(const bf16x8*)(st + xad[b][kk + 1]);
 #pragma unroll
-        for (int a = 0; a < TN; ++a) wf[nxt][a] = *(const bf16x8*)(st + wad[a][kk + 1]);
+          for (int a = 0; a < TN; ++a) wf[nxt][a] = *(const bf16x8*)(st + wad[a][kk + 1]);
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][a], xf[cur][b], acc[a][b], 0, 0, 0);
+        // pin the issue order the scheduler would otherwise undo: [ds_reads of k-step kk+1] then [MFMAs of kk]
+        if (kk + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
       }
+    } else {                                           // wide wave tile (64 x 128): 128 accumulator registers, single-buffered fragments
 #pragma unroll
-      for (int a = 0; a < TN; ++a)
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        bf16x8 xf[TM], wf[TN];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][a], xf[cur][b], acc[a][b], 0, 0, 0);
-      // pin the issue order the scheduler would otherwise undo: [ds_reads of k-step kk+1] then [MFMAs of kk]
-      if (kk + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2 + TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
+        for (int b = 0; b < TM; ++b) xf[b] = *(const bf16x8*)(st + xad[b][kk]);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[a] = *(const bf16x8*)(st + wad[a][kk]);
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+      }
     }
   };
 
   // ---- folded LayerNorm (consumer side): the GEMM runs on the RAW rows x with W' = W*diag(gamma); the epilogue
   // applies y = rstd*(acc - mean*c1[n]) + c2[n].  Row mean / rstd come from the producer's per-n-tile partial sums.
-  constexpr int EPI_BYTES = BM * (BN + 4) * 4;
-  constexpr int LN_OFF = (NSTAGE * STAGE > EPI_BYTES) ? NSTAGE * STAGE : EPI_BYTES;
+  constexpr int EPI_BYTES = BM * (BN + 4) * 4;                                  // whole-tile fp32 staging (epilogue)
+  constexpr int EPI_PASS = (EPI_BYTES <= 152 * 1024) ? EPI_BYTES : EPI_BYTES / WM;  // or one 64-row slab per pass
+  constexpr int LN_OFF = (NSTAGE * STAGE > EPI_PASS) ? NSTAGE * STAGE : EPI_PASS;
   float* lnst = (float*)(smem + LN_OFF);               // [BM][2] = (mean, rstd); only allocated when ln_stats != null
   if (p.ln_stats) {
     for (int r = t; r < BM; r += NT) {
@@ -255,37 +288,123 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   }
 
   // ---- NSTAGE-deep LDS ring, NSTAGE-1 K-tiles of DMA in flight, counted vmcnt (never drained to 0 in the loop)
+  if constexpr (NP > 0) {
+    // warp-specialised: loader waves and MFMA waves run separate loops that meet at one s_barrier per K-tile
+    // (separate loops keep the loaders' pointer state and the consumers' accumulators out of each other's live ranges)
+    if (is_loader) {
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s) produce(s);
-  if (p.timing) tm1 = (long long)__builtin_amdgcn_s_memrealtime();
-  int kt = kt_begin;
+      for (int s = 0; s < NSTAGE - 1; ++s) { advance_segment(); produce(s); }
+      int kt = kt_begin;
+#define DMX_LSUB(J)                                                                          \
+  {                                                                                          \
+    advance_segment();                                                                       \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLOADS) : "memory");             \
+    __builtin_amdgcn_s_barrier();                                                            \
+    if (!(p.dbg & 2)) produce((J + NSTAGE - 1) % NSTAGE);   /* dbg bit1: ablation, no DMA */   \
+    if (++kt >= kt_end) break;                                                               \
+  }
+      for (;;) {
+        DMX_LSUB(0) DMX_LSUB(1) DMX_LSUB(2)
+        if constexpr (NSTAGE >= 4) DMX_LSUB(3)
+      }
+#undef DMX_LSUB
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      // MFMA waves: software-pipelined over k-steps AND K-tiles.  Two register fragment sets; the ds_reads of the
+      // next k-step (or of k-step 0 of the NEXT tile, right after its barrier) are always issued before the 8 MFMAs
+      // of the current one, so the matrix pipe never waits for LDS latency.  The barrier for tile kt+1 is taken once
+      // tile kt is completely in registers (lgkmcnt(0)), which is also what lets the loaders refill its buffer.
+      static_assert(NP == 0 || KSTEPS == 4, "warp-specialised MFMA loop is written for 4 k-steps per tile");
+      if (p.timing) tm1 = dmx_now(p.dbg);
+      bf16x8 xf[2][TM], wf[2][TN];
+      auto rd = [&](const int buf, const int J, const int kk) {
+        const char* st = smem + J * STAGE;
+        wf[buf][0] = *(const bf16x8*)(st + wad[0][kk]);          // in the order the MFMAs consume them
+#pragma unroll
+        for (int b = 0; b < TM; ++b) xf[buf][b] = *(const bf16x8*)(st + xad[b][kk]);
+#pragma unroll
+        for (int a = 1; a < TN; ++a) wf[buf][a] = *(const bf16x8*)(st + wad[a][kk]);
+      };
+      auto mm = [&](const int buf) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][a], xf[buf][b], acc[a][b], 0, 0, 0);
+      };
+#define DMX_SB __builtin_amdgcn_sched_barrier(0)
+      // one scheduling region = [TM+TN ds_reads of the next fragment set] interleaved, two per gap, behind the first
+      // MFMAs of the current one (a ds_read issued in an MFMA's shadow is free; clustered between MFMA groups
+      // they cost ~100 cycles per group)
+#define DMX_PHASE(RB, RJ, RK, MB)                                                            \
+  {                                                                                          \
+    DMX_SB; rd(RB, RJ, RK); mm(MB);                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < (TM + TN) / 2; ++q_) {                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                     \
+    }                                                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN) / 2, 0);                 \
+    DMX_SB;                                                                                  \
+  }
+      int kt = kt_begin;
+      __builtin_amdgcn_s_barrier();
+      rd(0, 0, 0);
+#define DMX_CSUB(J)                                                                          \
+  {                                                                                          \
+    DMX_PHASE(1, J, 1, 0)                                                                    \
+    DMX_PHASE(0, J, 2, 1)                                                                    \
+    DMX_PHASE(1, J, 3, 0)                                                                    \
+    ++kt;                                                                                    \
+    if (kt < kt_end) {                                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+      __builtin_amdgcn_s_barrier();                                                          \
+    }                                                                                        \
+    DMX_PHASE(0, (J + 1) % NSTAGE, 0, 1)  /* after the last tile: a harmless read of a dead buffer */ \
+    if (kt >= kt_end) break;                                                                 \
+  }
+      for (;;) {
+        DMX_CSUB(0) DMX_CSUB(1) DMX_CSUB(2)
+        if constexpr (NSTAGE >= 4) DMX_CSUB(3)
+      }
+#undef DMX_PHASE
+#undef DMX_CSUB
+#undef DMX_SB
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) { advance_segment(); produce(s); }
+    if (p.timing) tm1 = dmx_now(p.dbg);
+    int kt = kt_begin;
 #define DMX_SUBITER(J)                                                                      \
   {                                                                                         \
+    advance_segment();                                                                      \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * NLOADS) : "memory");            \
     __builtin_amdgcn_s_barrier(); /* tile kt is in LDS for every wave; tile kt-1's buffer is free */ \
-    produce((J + NSTAGE - 1) % NSTAGE);                                                     \
-    compute(J);                                                                             \
+    if (!(p.dbg & 2)) produce((J + NSTAGE - 1) % NSTAGE);                                   \
+    if (!(p.dbg & 1)) compute(J);                                                           \
     if (++kt >= kt_end) break;                                                              \
   }
-  for (;;) {
-    DMX_SUBITER(0) DMX_SUBITER(1) DMX_SUBITER(2)
-    if constexpr (NSTAGE >= 4) DMX_SUBITER(3)
-    if constexpr (NSTAGE >= 5) DMX_SUBITER(4)
-    if constexpr (NSTAGE >= 6) DMX_SUBITER(5)
-  }
+    for (;;) {
+      DMX_SUBITER(0) DMX_SUBITER(1) DMX_SUBITER(2)
+      if constexpr (NSTAGE >= 4) DMX_SUBITER(3)
+      if constexpr (NSTAGE >= 5) DMX_SUBITER(4)
+      if constexpr (NSTAGE >= 6) DMX_SUBITER(5)
+    }
 #undef DMX_SUBITER
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the dummy tail loads before LDS is released
-  if (p.timing) tm2 = (long long)__builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the dummy tail loads before LDS is released
+  }
+  if (p.timing) tm2 = dmx_now(p.dbg);
 
   // ---------------------------------------------------------------- epilogue
   // acc[a][b][4g+e] = out[m = m0 + wm*64 + b*32 + lr][n = n0 + wn*32*TN + a*32 + 8g + 4lh + e]
   if (p.splitk > 1) {
     float* part = p.partial + (size_t)blockIdx.y * p.M * p.N;
+    if (is_consumer)
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int m = m0 + wm * 64 + b * 32 + lr;
+      for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wm * (32 * TM) + b * 32 + lr;
         if (m >= p.M) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -308,144 +427,160 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
     // every global load is issued before the first store for the same reason.
     constexpr int LDT = BN + 4;                        // padded row stride (floats): conflict-free b128 writes
     constexpr int OC = BN / 8;                         // output octets per tile row (NT % OC == 0: o fixed per thread)
-    constexpr int OCT = BM * OC / NT;                  // (row, octet) items per thread: 4*TN
+    constexpr int EP = (EPI_BYTES <= 152 * 1024) ? 1 : WM;   // passes: the 256x256 tile stages 64 rows (one wm) at a time
+    constexpr int RPP = BM / EP;                       // tile rows per pass
+    constexpr int OCT = RPP * OC / NT;                 // (row, octet) items per thread per pass
     float* tile = (float*)smem;
     const bool geglu = p.geglu != 0;
-    if (p.rowbias) {                                   // uniform branch; columns past N are clamped (never stored)
+    if (p.rowbias && is_consumer) {                    // uniform branch; columns past N are clamped (never stored)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        int m = m0 + wm * 64 + b * 32 + lr; if (m >= p.M) m = p.M - 1;
+      for (int b = 0; b < TM; ++b) {
+        int m = m0 + wm * (32 * TM) + b * 32 + lr; if (m >= p.M) m = p.M - 1;
         const float* rb = p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb;
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < TN; ++a) {
+          if (TN * TM > 4) asm volatile("" ::: "memory");   // wide tiles: do not hoist all 8 x 4 row-bias loads at once (VGPRs)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             int nn = n0 + wn * 32 * TN + a * 32 + 8 * g + 4 * lh; if (nn > p.N - 4) nn = p.N - 4;
             const f32x4 bv = *(const f32x4*)(rb + nn);
             acc[a][b][4 * g] += bv[0]; acc[a][b][4 * g + 1] += bv[1]; acc[a][b][4 * g + 2] += bv[2]; acc[a][b][4 * g + 3] += bv[3];
           }
+        }
       }
     }
-    __builtin_amdgcn_s_barrier();                      // every wave has left the K loop: the ring can be reused
+    // per-thread column data (the octet is the same for every item of a thread)
+    const int og = t % (BN / 16), Gg = og >> 2, jjg = (og & 3) * 8;      // GEGLU: output octet -> packed 64-col group
+    const int o = t % OC;
+    const bool nvalid = geglu ? (n0 + 64 * Gg + jjg < p.N) : (n0 + o * 8 < p.N);
+    const int n = nvalid ? n0 + o * 8 : 0;             // clamped: loads stay in range, nothing is stored
+    const int na = nvalid ? n0 + 64 * Gg + jjg : 0;
+    float bs[8], c1[8], bg[8], cg[8];
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int r = wm * 64 + b * 32 + lr;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-          *(f32x4*)(tile + r * LDT + wn * 32 * TN + a * 32 + 8 * g + 4 * lh) = v;
-        }
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (geglu) {
-      if constexpr (TN == 2) {
-        // 64 output columns per tile: octet o -> packed group G = o>>2 ('a' rows 64G.., gate rows 64G+32..)
-        const int o = t & 7, G = o >> 2, jj = (o & 3) * 8;
-        const int na = n0 + 64 * G + jj;
-        float ba[8], bg[8], ca[8], cg[8];
-        const float* bsrc = p.ln_stats ? p.ln_c2 : p.bias;     // LN fold: c2 already contains the bias
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const f32x4 x0 = *(const f32x4*)(bsrc + na + 4 * q), x1 = *(const f32x4*)(bsrc + na + 32 + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { ba[4 * q + e] = x0[e]; bg[4 * q + e] = x1[e]; ca[4 * q + e] = 0.f; cg[4 * q + e] = 0.f; }
-          if (p.ln_stats) {
-            const f32x4 y0 = *(const f32x4*)(p.ln_c1 + na + 4 * q), y1 = *(const f32x4*)(p.ln_c1 + na + 32 + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { ca[4 * q + e] = y0[e]; cg[4 * q + e] = y1[e]; }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < BM * 8 / NT; ++k) {
-          asm volatile("" ::: "memory");
-          const int r = (t >> 3) + (NT / 8) * k;
-          const int m = m0 + r;
-          if (m >= p.M) continue;
-          const float* ta = tile + r * LDT + 64 * G + jj;
-          float mean = 0.f, rstd = 1.f;
-          if (p.ln_stats) { mean = lnst[2 * r]; rstd = lnst[2 * r + 1]; }
-          float v[8];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const f32x4 av = *(const f32x4*)(ta + 4 * q), gv = *(const f32x4*)(ta + 32 + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float a_ = rstd * (av[e] - mean * ca[4 * q + e]) + ba[4 * q + e];
-              const float g_ = rstd * (gv[e] - mean * cg[4 * q + e]) + bg[4 * q + e];
-              v[4 * q + e] = a_ * gelu_erf_f(g_);
-            }
-          }
-          *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + (n0 >> 1) + 32 * G + jj) = pack_bf8(v);
-        }
-      }
-    } else {
-      const int o = t % OC;
-      const bool nvalid = n0 + o * 8 < p.N;
-      const int n = nvalid ? n0 + o * 8 : 0;             // clamped: loads stay in range, nothing is stored
-      float bs[8], c1[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { bs[e] = 0.f; c1[e] = 0.f; }
-      const float* bsrc = p.ln_stats ? p.ln_c2 : p.bias;
+    for (int e = 0; e < 8; ++e) { bs[e] = 0.f; c1[e] = 0.f; bg[e] = 0.f; cg[e] = 0.f; }
+    auto load_cols = [&]() {
+      const float* bsrc = p.ln_stats ? p.ln_c2 : p.bias;     // folded LayerNorm: c2 already contains the bias
+      const int nb = geglu ? na : n;
       if (bsrc) {
-        const f32x4 b0 = *(const f32x4*)(bsrc + n), b1 = *(const f32x4*)(bsrc + n + 4);
+        const f32x4 b0 = *(const f32x4*)(bsrc + nb), b1 = *(const f32x4*)(bsrc + nb + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
+        if (geglu) {
+          const f32x4 g0 = *(const f32x4*)(bsrc + nb + 32), g1 = *(const f32x4*)(bsrc + nb + 36);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bg[e] = g0[e]; bg[4 + e] = g1[e]; }
+        }
       }
       if (p.ln_stats) {
-        const f32x4 y0 = *(const f32x4*)(p.ln_c1 + n), y1 = *(const f32x4*)(p.ln_c1 + n + 4);
+        const f32x4 y0 = *(const f32x4*)(p.ln_c1 + nb), y1 = *(const f32x4*)(p.ln_c1 + nb + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { c1[e] = y0[e]; c1[4 + e] = y1[e]; }
+        if (geglu) {
+          const f32x4 g0 = *(const f32x4*)(p.ln_c1 + nb + 32), g1 = *(const f32x4*)(p.ln_c1 + nb + 36);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { cg[e] = g0[e]; cg[4 + e] = g1[e]; }
+        }
       }
-      u32x4 rv[OCT];
-      if (p.res) {
+    };
+    // 128-accumulator wave tiles: fetch the column vectors only after the accumulators are staged (VGPR budget - a
+    // spill reload after the first global store would wait for that store: vmcnt counts stores)
+    constexpr bool LATE_COLS = (TN * TM > 4);
+    if constexpr (!LATE_COLS) load_cols();
+#pragma unroll
+    for (int ep = 0; ep < EP; ++ep) {
+      __builtin_amdgcn_s_barrier();                    // K loop / previous pass is done with this LDS
+      if (is_consumer && (EP == 1 || wm == ep)) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) {
+            const int r = (EP == 1 ? wm * (32 * TM) : 0) + b * 32 + lr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+              *(f32x4*)(tile + r * LDT + wn * 32 * TN + a * 32 + 8 * g + 4 * lh) = v;
+            }
+          }
+      }
+      if constexpr (LATE_COLS) { if (ep == 0) load_cols(); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int rbase = ep * RPP;                      // first tile row of this pass
+      if (geglu) {
+        if constexpr (TN >= 2) {
+          // BN/2 output columns per tile row: octet og -> packed group Gg ('a' rows 64Gg.., gate rows 64Gg+32..)
+          constexpr int GI = RPP * (BN / 16) / NT;
+#pragma unroll
+          for (int k = 0; k < GI; ++k) {
+            asm volatile("" ::: "memory");
+            const int r = t / (BN / 16) + (NT / (BN / 16)) * k;
+            const int m = m0 + rbase + r;
+            const float* ta = tile + r * LDT + 64 * Gg + jjg;
+            float mean = 0.f, rstd = 1.f;
+            if (p.ln_stats) { mean = lnst[2 * (rbase + r)]; rstd = lnst[2 * (rbase + r) + 1]; }
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 av = *(const f32x4*)(ta + 4 * q), gv = *(const f32x4*)(ta + 32 + 4 * q);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float a_ = rstd * (av[e] - mean * c1[4 * q + e]) + bs[4 * q + e];
+                const float g_ = rstd * (gv[e] - mean * cg[4 * q + e]) + bg[4 * q + e];
+                v[4 * q + e] = a_ * gelu_erf_f(g_);
+              }
+            }
+            if (nvalid && m < p.M) *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + (n0 >> 1) + 32 * Gg + jjg) = pack_bf8(v);
+          }
+        }
+      } else {
+        u32x4 rv[OCT];
+        if (p.res) {
+#pragma unroll
+          for (int k = 0; k < OCT; ++k) {
+            int m = m0 + rbase + t / OC + (NT / OC) * k; if (m >= p.M) m = p.M - 1;
+            rv[k] = *(const u32x4*)(p.res + (size_t)m * p.ldres + n);
+          }
+        }
 #pragma unroll
         for (int k = 0; k < OCT; ++k) {
-          int m = m0 + t / OC + (NT / OC) * k; if (m >= p.M) m = p.M - 1;
-          rv[k] = *(const u32x4*)(p.res + (size_t)m * p.ldres + n);
-        }
-      }
+          asm volatile("" ::: "memory");               // keep each item's LDS reads in its own iteration (VGPR pressure)
+          const int r = t / OC + (NT / OC) * k;
+          const int m = m0 + rbase + r;
+          const bool live = nvalid && m < p.M;
+          const f32x4 v0 = *(const f32x4*)(tile + r * LDT + o * 8), v1 = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
+          float v[8];
+          if (p.ln_stats) {
+            const float mean = lnst[2 * (rbase + r)], rstd = lnst[2 * (rbase + r) + 1];
 #pragma unroll
-      for (int k = 0; k < OCT; ++k) {
-        asm volatile("" ::: "memory");               // keep each item's LDS reads in its own iteration (VGPR pressure)
-        const int r = t / OC + (NT / OC) * k;
-        const int m = m0 + r;
-        const bool live = nvalid && m < p.M;
-        const f32x4 v0 = *(const f32x4*)(tile + r * LDT + o * 8), v1 = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
-        float v[8];
-        if (p.ln_stats) {
-          const float mean = lnst[2 * r], rstd = lnst[2 * r + 1];
+            for (int e = 0; e < 4; ++e) {
+              v[e] = rstd * (v0[e] - mean * c1[e]) + bs[e];
+              v[4 + e] = rstd * (v1[e] - mean * c1[4 + e]) + bs[4 + e];
+            }
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = rstd * (v0[e] - mean * c1[e]) + bs[e];
-            v[4 + e] = rstd * (v1[e] - mean * c1[4 + e]) + bs[4 + e];
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bs[e]; v[4 + e] = v1[e] + bs[4 + e]; }
           }
-        } else {
+          if (p.res) {
+            float rf[8]; unpack_bf8(rv[k], rf);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bs[e]; v[4 + e] = v1[e] + bs[4 + e]; }
-        }
-        if (p.res) {
-          float rf[8]; unpack_bf8(rv[k], rf);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rf[e];
-        }
-        const u32x4 pk = pack_bf8(v);
-        if (live) *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + n) = pk;
-        if (p.rowstats_out) {
-          // per-row (sum, sumsq) of the rounded outputs over this n-tile: the OC lanes of a row are adjacent lanes
-          float f[8]; unpack_bf8(pk, f);
-          float sa = 0.f, sq = 0.f;
-          if (live) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { sa += f[e]; sq += f[e] * f[e]; }
+            for (int e = 0; e < 8; ++e) v[e] += rf[e];
           }
+          const u32x4 pk = pack_bf8(v);
+          if (live) *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + n) = pk;
+          if (p.rowstats_out) {
+            // per-row (sum, sumsq) of the rounded outputs over this n-tile: the OC lanes of a row are adjacent lanes
+            float f[8]; unpack_bf8(pk, f);
+            float sa = 0.f, sq = 0.f;
+            if (live) {
 #pragma unroll
-          for (int d = 1; d < OC; d <<= 1) { sa += __shfl_xor(sa, d); sq += __shfl_xor(sq, d); }
-          if (o == 0 && m < p.M) {
-            float* q = p.rowstats_out + ((size_t)tile_n * p.M + m) * 2;
-            q[0] = sa; q[1] = sq;
+              for (int e = 0; e < 8; ++e) { sa += f[e]; sq += f[e] * f[e]; }
+            }
+#pragma unroll
+            for (int d = 1; d < OC; d <<= 1) { sa += __shfl_xor(sa, d); sq += __shfl_xor(sq, d); }
+            if (o == 0 && m < p.M) {
+              float* q = p.rowstats_out + ((size_t)tile_n * p.M + m) * 2;
+              q[0] = sa; q[1] = sq;
+            }
           }
         }
       }
@@ -453,11 +588,12 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   } else {
     // ---- generic epilogue (fp32 output, channel counts that are not multiples of 8): per-lane 4-channel groups
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldo & 3) == 0);
+    if (is_consumer)
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int m = m0 + wm * 64 + b * 32 + lr;
+      for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wm * (32 * TM) + b * 32 + lr;
         if (m >= p.M) continue;
         const float* rb = p.rowbias ? (p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb) : nullptr;
 #pragma unroll
@@ -480,7 +616,7 @@ __global__ __launch_bounds__(128 * WM, 2) void dmx_gemm_kernel(const GemmArgs p)
   }
   if (p.timing && t == 0) {        // measurement aid: per-block timeline in 10 ns ticks (s_memrealtime)
     long long* o = p.timing + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-    o[0] = tm0; o[1] = tm1; o[2] = tm2; o[3] = (long long)__builtin_amdgcn_s_memrealtime();
+    o[0] = tm0; o[1] = tm1; o[2] = tm2; o[3] = dmx_now(p.dbg);
   }
 }
 
@@ -534,11 +670,14 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[4] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[7] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
-    {256, 128, 32, 256, 1.20, 10.0},        // experimental: 6-stage ring of 32-deep tiles (only via force_tn = 4)
+    {128, 64, 64, 256, 0.55, 6.0},          // deep ring (6 x 24 KB, 1 block/CU): small grids whose K loop is DMA-latency-bound
+    {128, 128, 64, 256, 1.00, 7.0},         // deep ring (4 x 32 KB, 1 block/CU)
+    {256, 256, 32, 256, 2.40, 16.0},        // 128 FLOP/B (experimental, force_tn = 6 only)
+    {256, 128, 64, 256, 1.90, 11.0},        // warp-specialised 256x128x64: 4 MFMA waves + 4 DMA waves (~0.85 us per K-tile)
 };
 
 static double plan_cost(const GemmArgs& a, int c, int sk) {
@@ -563,32 +702,37 @@ static double plan_cost(const GemmArgs& a, int c, int sk) {
 
 void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_out) {
   int best_c = 0, best_sk = 1; double best = 1e300;
-  if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0 && !a.rowstats_out && !a.ln_stats) {
+  if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
+    const bool no_split = a.rowstats_out || a.ln_stats || a.geglu;
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == a.ups &&
-          !(a.geglu && (tp.cfg == 1 || tp.sk > 1))) {
+          !(a.geglu && (tp.cfg == 1 || tp.cfg == 3)) && !(no_split && tp.sk > 1)) {
         const int nkt = a.K / kCfg[tp.cfg].bk;
         int ktps = cdiv(nkt, tp.sk);
         *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
         return;
       }
   }
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < 7; ++c) {
     const TileCfg& T = kCfg[c];
-    if (c == 3 && a.force_tn != 4) continue;
+    if ((c == 3 || c == 4 || c == 5) && !a.force_tn) continue;   // deep rings / 256x256: no gain inside the UNet pass; kept for experiments
     if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
-    if (a.geglu && c == 1) continue;
+    if (a.geglu && (c == 1 || c == 3)) continue;
     if (a.force_tn == 1 && c != 1) continue;
     if (a.force_tn == 2 && c != 0) continue;
     if (a.force_tn == 3 && c != 2) continue;
     if (a.force_tn == 4 && c != 3) continue;
-    if (!a.force_tn && c != 1 && a.N <= 64) continue;
-    if (!a.force_tn && c == 2 && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
+    if (a.force_tn == 5 && c != 4) continue;
+    if (a.force_tn == 6 && c != 5) continue;
+    if (a.force_tn == 7 && c != 6) continue;
+    if (!a.force_tn && c != 1 && c != 3 && a.N <= 64) continue;
+    if (!a.force_tn && (c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
     const int nkt = a.K / T.bk;
     const int max_sk = (a.geglu || (a.N % 4) != 0 || a.rowstats_out || a.ln_stats) ? 1 : 16;   // those epilogues live in the GEMM kernel
     for (int sk = 1; sk <= max_sk; ++sk) {
       if (a.force_splitk && sk != a.force_splitk) continue;
       if (sk > 1 && nkt / sk < (T.bk == 64 ? 4 : 8)) break;
+      if (c == 6 && !a.force_tn && nkt / sk < 40) break;      // the warp-specialised loop pays off from ~2.5k of K per block
       const double cst = plan_cost(a, c, sk);
       if (cst < best) { best = cst; best_c = c; best_sk = sk; }
     }
@@ -611,16 +755,17 @@ size_t dmx_gemm_workspace_bytes(const GemmArgs& a) {
   return sk > 1 ? (size_t)sk * a.M * a.N * sizeof(float) : 0;
 }
 
-template <int WM, int TN, int BKT, int NST>
+template <int WM, int TN, int BKT, int NST, int TM = 2, int NP = 0>
 static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-  constexpr int BM = 64 * WM, BN = 64 * TN;
+  constexpr int BM = 32 * TM * WM, BN = 64 * TN;
   size_t lds = (size_t)NST * (BM + BN) * BKT * 2;
-  const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);       // fp32 staging tile of the coalesced epilogue
+  size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);             // fp32 staging tile of the coalesced epilogue
+  if (lds_epi > 152 * 1024) lds_epi /= WM;                            // (only the experimental 256x256 tile)                            // staged one 64-row slab at a time
   if (lds_epi > lds) lds = lds_epi;
   if (a.ln_stats) lds += (size_t)BM * 2 * sizeof(float);               // (mean, rstd) per row of the folded LayerNorm
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float))); attr = true; }
-  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST>), grid, dim3(128 * WM), lds, stream, a);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float))); attr = true; }
+  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP>), grid, dim3(64 * (2 * WM + NP)), lds, stream, a);
 }
 
 int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -654,11 +799,14 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   char tag[96];
   snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, c == 0 ? 2 : (c == 1 ? 1 : c + 1), sk);
   {
-    ProfScope ps(c == 0 ? PROF_GEMM128 : (c == 1 ? PROF_GEMM64 : PROF_GEMM256), stream, flops, bytes, tag);
+    ProfScope ps((c == 0 || c == 4) ? PROF_GEMM128 : ((c == 1 || c == 3) ? PROF_GEMM64 : PROF_GEMM256), stream, flops, bytes, tag);
     if (c == 0) launch_cfg<2, 2, 32, 4>(a, grid, stream);
     else if (c == 1) launch_cfg<2, 1, 32, 4>(a, grid, stream);
     else if (c == 2) launch_cfg<4, 2, 64, 3>(a, grid, stream);
-    else launch_cfg<4, 2, 32, 6>(a, grid, stream);
+    else if (c == 3) launch_cfg<2, 1, 64, 6>(a, grid, stream);
+    else if (c == 4) launch_cfg<2, 2, 64, 4>(a, grid, stream);
+    else if (c == 5) launch_cfg<4, 4, 32, 4>(a, grid, stream);
+    else launch_cfg<2, 2, 64, 3, 4, 4>(a, grid, stream);
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;

@@ -41,6 +41,7 @@ struct GemmArgs {
   const float* ln_c1; const float* ln_c2;      // [N]: c1 = sum_k W'[n][k] ; c2 = sum_k beta[k]*W[n][k] (+ bias[n])
   int ln_C; float ln_eps;                      // normalised feature count (= K) and epsilon
   long long* timing;                           // optional per-block timeline (probe builds), normally null
+  int dbg;                                     // measurement aid: bit0 skip the MFMA phase, bit1 skip the DMA refills (results invalid)
   float* partial; int splitk, kt_per_split;   // filled by the launcher
   const bf16* zeros;                           // filled by the launcher
 };

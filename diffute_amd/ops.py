@@ -62,7 +62,7 @@ def pack_geglu_bias(b):
 
 
 def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=None, rowbias=None,
-              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0):
+              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0, dbg=0):
     """Fused conv / linear.  x0 (and x1) NHWC bf16; w packed bf16 [N][K].  Returns NHWC (bf16 or fp32)."""
     B, H, W, C0 = x0.shape
     Cin = C0 + (x1.shape[-1] if x1 is not None else 0)
@@ -96,7 +96,7 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
     Nout = N // 2 if geglu else N
     out = torch.empty(B, OH, OW, Nout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x0.device)
     d.out = out.data_ptr(); d.ldo = Nout; d.out_f32 = int(out_f32); d.geglu = int(geglu)
-    d.force_tn = force_tn; d.force_splitk = force_splitk; d.group_m = group_m
+    d.force_tn = force_tn; d.force_splitk = force_splitk; d.group_m = group_m; d.dbg = dbg
     if timing is not None:
         d.timing = timing.data_ptr()
     wsb = lib().dmx_conv_gemm_workspace_bytes(ctypes.byref(d))

@@ -72,6 +72,7 @@ typedef struct dmx_gemm_desc {
   int group_m;                      /* m-tiles per L2 super-tile of the block rasterisation (0 = default) */
   long long* timing;                /* optional device buffer [blocks][4]: per-block start / prologue / loop / end
                                        timestamps in 10 ns ticks (measurement aid), normally NULL */
+  int dbg;                          /* measurement aid, must be 0: bit0 skips the MFMA phase, bit1 the DMA refills */
 } dmx_gemm_desc;
 size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d);
 int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);

@@ -11,14 +11,29 @@ sys.path.insert(0, ".")
 from diffute_amd import ops  # noqa: E402
 
 
-def time_it(fn, reps=20):
-    fn(); torch.cuda.synchronize()
+def time_it(fn, reps=12, replays=3):
+    """us per call of fn(i).  The calls are captured into one graph (no host launch overhead: the python/ctypes path
+    costs ~25 us per call, more than the small GEMMs) and fn rotates its weights (i) so they stream from HBM as in the
+    UNet pass instead of sitting in L2 / MALL."""
+    fn(0); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for i in range(reps):
+                fn(i)
+    g.replay(); torch.cuda.synchronize()
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(replays):
+        g.replay()
     b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps * 1e3     # us
+    return a.elapsed_time(b) / (reps * replays) * 1e3     # us
+
+
+def weights(N, K, total=384 << 20):
+    n = max(2, min(12, total // (N * K * 2)))
+    return [(torch.randn(N, K, device='cuda') / math.sqrt(K)).to(torch.bfloat16) for _ in range(n)]
 
 
 def main(path):
@@ -31,8 +46,9 @@ def main(path):
         shapes[key] = shapes.get(key, 0) + 1
     dev = torch.device("cuda")
     tot_auto = tot_best = 0.0
-    floor = time_it(lambda: ops.conv_gemm(torch.zeros(1, 1, 128, 64, device=dev, dtype=torch.bfloat16), torch.zeros(64, 64, device=dev, dtype=torch.bfloat16), 64, ksize=1, pad=0))
-    print(f'host/launch floor of this harness: {floor:.1f} us per call')
+    zx = torch.zeros(1, 1, 128, 64, device=dev, dtype=torch.bfloat16); zw = torch.zeros(64, 64, device=dev, dtype=torch.bfloat16)
+    floor = time_it(lambda i: ops.conv_gemm(zx, zw, 64, ksize=1, pad=0))
+    print(f'per-launch floor of this harness: {floor:.1f} us')
     for (M, N, K, ks, st, ups), cnt in sorted(shapes.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
         B = 4 if M % 4 == 0 else 1
         if ks == 3:
@@ -42,20 +58,22 @@ def main(path):
         if ks == 3:
             H = OH // 2 if ups else (OH * 2 if st == 2 else OH)
             x = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16)
-            w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
-            run = lambda tn, sk: ops.conv_gemm(x, w, N, ksize=3, stride=st, pad=1, ups=bool(ups), force_tn=tn, force_splitk=sk)
+            ws = weights(N, K)
+            run = lambda tn, sk, i=0: ops.conv_gemm(x, ws[i % len(ws)], N, ksize=3, stride=st, pad=1, ups=bool(ups), force_tn=tn, force_splitk=sk)
         else:
             x = torch.randn(1, 1, M, K, device=dev).to(torch.bfloat16)
-            w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
-            run = lambda tn, sk: ops.conv_gemm(x, w, N, ksize=1, pad=0, force_tn=tn, force_splitk=sk)
-        t_auto = time_it(lambda: run(0, 0))
+            ws = weights(N, K)
+            run = lambda tn, sk, i=0: ops.conv_gemm(x, ws[i % len(ws)], N, ksize=1, pad=0, force_tn=tn, force_splitk=sk)
+        t_auto = time_it(lambda i: run(0, 0, i))
         res = []
-        for tn in (3, 2, 1):
+        for tn in (7, 5, 4, 3, 2, 1):
             for sk in (1, 2, 3, 4, 6, 8, 12, 16):
-                if sk > 1 and (K // (64 if tn == 3 else 32)) // sk < (4 if tn == 3 else 8):
+                if K % (64 if tn in (3, 4, 5, 7) else 32):
+                    continue
+                if sk > 1 and (K // (64 if tn in (3, 4, 5, 7) else 32)) // sk < (4 if tn in (3, 4, 5, 7) else 8):
                     continue
                 try:
-                    res.append((time_it(lambda: run(tn, sk)), tn, sk))
+                    res.append((time_it(lambda i: run(tn, sk, i)), tn, sk))
                 except RuntimeError:
                     pass
         res.sort()
