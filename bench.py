@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROF_CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128"]
+PROF_CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128", "wgrad"]
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 

@@ -42,6 +42,10 @@ _PROTOS = {
     "dmx_last_error": (c_char_p, []),
     "dmx_conv_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "dmx_conv_gemm": (c_int, [POINTER(GemmDesc), _P, c_size_t, _P]),
+    "dmx_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(GemmDesc), c_int]),
+    "dmx_conv_wgrad": (c_int, [POINTER(GemmDesc), _P, c_int, _P, c_int, _P, c_size_t, _P]),
+    "dmx_colsum_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dmx_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     "dmx_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dmx_groupnorm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, c_int, _P, c_size_t, _P]),
     "dmx_layernorm": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P]),

@@ -27,6 +27,31 @@ extern "C" int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t wor
   return dmx_gemm_launch(to_args(d), workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+static WgradArgs to_wgrad(const dmx_gemm_desc* d, const void* dy, int lddy, float* dw, int accumulate) {
+  WgradArgs a{};
+  a.dy = (const bf16*)dy; a.lddy = lddy;
+  a.x0 = (const bf16*)d->x0; a.x1 = d->x1 ? (const bf16*)d->x1 : (const bf16*)d->x0;
+  a.ldx0 = d->ldx0; a.ldx1 = d->x1 ? d->ldx1 : d->ldx0; a.cx0 = d->cx0; a.direct = d->direct;
+  a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW;
+  a.stride = d->stride; a.pad = d->pad; a.ups = d->ups; a.ksize = d->ksize > 0 ? d->ksize : 1; a.Cin = d->Cin;
+  a.M = d->M; a.N = d->N; a.K = d->Ktaps; a.out = dw; a.accumulate = accumulate;
+  return a;
+}
+extern "C" size_t dmx_conv_wgrad_workspace_bytes(const dmx_gemm_desc* d, int accumulate) {
+  return d ? dmx_wgrad_workspace_bytes(to_wgrad(d, nullptr, 0, nullptr, accumulate)) : 0;
+}
+extern "C" int dmx_conv_wgrad(const dmx_gemm_desc* d, const void* dy, int lddy, float* dw, int accumulate,
+                              void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(d && d->x0 && dy && dw, "conv_wgrad: null argument");
+  return dmx_wgrad_launch(to_wgrad(d, dy, lddy, dw, accumulate), workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" size_t dmx_colsum_workspace_bytes(int groups, int rows_per_group, int N) { return dmx_colsum_ws_bytes(groups, rows_per_group, N); }
+extern "C" int dmx_colsum(const void* dy, int lddy, int groups, int rows_per_group, int N, float* out, int ldo, int accumulate,
+                          void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(dy && out, "colsum: null argument");
+  return dmx_colsum_launch((const bf16*)dy, lddy, groups, rows_per_group, N, out, ldo, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" int dmx_groupnorm(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
                              int B, int HW, const float* gamma, const float* beta, float eps, int silu,
                              void* y, int ldy, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {

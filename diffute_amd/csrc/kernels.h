@@ -5,7 +5,7 @@
 // ------------------------------------------------------------------ profiler (exec.hip)
 // Optional per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg).
 enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN = 3, PROF_GNORM = 4, PROF_LNORM = 5,
-                 PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_NCLASS = 8 };
+                 PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_WGRAD = 8, PROF_NCLASS = 9 };
 struct ProfScope {
   ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag = nullptr);
   ~ProfScope();
@@ -53,6 +53,25 @@ int dmx_gemm_tiles_n(const GemmArgs& a);       // n-tiles of the plan that dmx_g
 // W' = bf16(W*gamma) and the c1 / c2 vectors of the folded LayerNorm, from the raw bf16 weights (rows may be GEGLU-packed)
 int dmx_ln_fold_launch(const bf16* w_raw, bf16* w_out, const float* gamma, const float* beta, const float* bias,
                        float* c1, float* c2, int N, int K, hipStream_t stream);
+
+// ------------------------------------------------------------------ wgrad.hip (training)
+struct WgradArgs {
+  const bf16* dy; int lddy;      // output gradient [M][N] (NHWC rows = output pixels)
+  // the forward GEMM's activation operand, same gather semantics as GemmArgs (two sources, conv taps, upsample, stride)
+  const bf16* x0; const bf16* x1; int ldx0, ldx1, cx0;
+  int direct;
+  int IH, IW, OH, OW, stride, pad, ups, ksize, Cin;
+  int M, N, K;                   // K = ksize*ksize*Cin (conv) or the plain feature count (direct)
+  float* out;                    // dW [N][K] fp32, packed k order (tap-major, channel-minor)
+  int accumulate;                // out += instead of out =
+  int splits, rows_per_split;    // filled by the launcher
+  const bf16* zeros;             // filled by the launcher
+};
+size_t dmx_wgrad_workspace_bytes(const WgradArgs& a);
+int dmx_wgrad_launch(WgradArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
+size_t dmx_colsum_ws_bytes(int groups, int rows_per_group, int N);
+int dmx_colsum_launch(const bf16* dy, int lddy, int groups, int rows_per_group, int N, float* out, int ldo, int accumulate,
+                      void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 // ------------------------------------------------------------------ norm.hip
 struct GroupNormArgs {

@@ -105,6 +105,50 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
     return out
 
 
+def _gather_desc(x0, x1, ksize, stride, pad, ups, direct):
+    B, H, W, C0 = x0.shape
+    Cin = C0 + (x1.shape[-1] if x1 is not None else 0)
+    OH, OW = (2 * H, 2 * W) if ups else (H, W)
+    if stride == 2:
+        OH, OW = OH // 2, OW // 2
+    d = GemmDesc()
+    d.x0 = x0.data_ptr(); d.ldx0 = _ld(x0); d.cx0 = C0
+    if x1 is not None:
+        d.x1 = x1.data_ptr(); d.ldx1 = _ld(x1)
+    d.direct = int(ksize == 1 and stride == 1 and not ups) if direct is None else int(direct)
+    d.IH, d.IW, d.OH, d.OW = H, W, OH, OW
+    d.stride, d.pad, d.ups, d.ksize, d.Cin = stride, pad, int(ups), ksize, Cin
+    d.Ktaps = ksize * ksize * Cin
+    d.M = B * OH * OW; d.K = d.Ktaps
+    return d
+
+
+def conv_wgrad(x0, dy, *, x1=None, ksize=3, stride=1, pad=1, ups=False, direct=None, into=None):
+    """dW[N][K] fp32 (packed tap-major k) = sum over output pixels of dy[m][n] * gathered x[m][k]; `into` accumulates."""
+    d = _gather_desc(x0, x1, ksize, stride, pad, ups, direct)
+    N = dy.shape[-1]
+    d.N = N
+    assert dy.numel() == d.M * N, "dy must be [B, OH, OW, N]"
+    out = into if into is not None else torch.empty(N, d.K, dtype=torch.float32, device=x0.device)
+    acc = int(into is not None)
+    wsb = lib().dmx_conv_wgrad_workspace_bytes(ctypes.byref(d), acc)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x0.device)
+    check(lib().dmx_conv_wgrad(ctypes.byref(d), ptr(dy), _ld(dy), ptr(out), acc, ptr(ws), wsb, current_stream()), "conv_wgrad")
+    return out
+
+
+def colsum(dy, groups=1, into=None):
+    """column sums of dy viewed as [groups][rows/groups][N] -> [groups][N] fp32 (bias / row-bias gradients)."""
+    N = dy.shape[-1]
+    rows = dy.numel() // N
+    rpg = rows // groups
+    out = into if into is not None else torch.empty(groups, N, dtype=torch.float32, device=dy.device)
+    wsb = lib().dmx_colsum_workspace_bytes(groups, rpg, N)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dy.device)
+    check(lib().dmx_colsum(ptr(dy), _ld(dy), groups, rpg, N, ptr(out), N, int(into is not None), ptr(ws), wsb, current_stream()), "colsum")
+    return out
+
+
 def linear(x, w, bias=None, res=None, geglu=False, out_f32=False):
     """x [..., K] bf16 (2-D view [rows][K]) @ w[N][K]^T."""
     K = x.shape[-1]

@@ -77,6 +77,19 @@ typedef struct dmx_gemm_desc {
 size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d);
 int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* Training: weight gradient of the conv / linear that `d` describes (the forward call's gather
+ * fields x0/x1/cx0/direct/IH.../ksize/Cin and M, N; K taken as Ktaps - the fused shortcut is a separate direct call):
+ *   dw[n][k] (+)= sum_m dy[m][n] * X[m][k]   fp32, k in the packed (tap, channel) order of the forward weights.
+ * Replaces the conv/linear weight-gradient kernels autograd runs under `accelerator.backward(loss)`
+ * (train_diffute_v1.py:925).  dmx_colsum gives the bias gradient (groups = 1) and the per-image gradient of the
+ * time-embedding row bias (groups = B, rows_per_group = OH*OW). */
+size_t dmx_conv_wgrad_workspace_bytes(const dmx_gemm_desc* d, int accumulate);
+int dmx_conv_wgrad(const dmx_gemm_desc* d, const void* dy, int lddy, float* dw, int accumulate,
+                   void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+size_t dmx_colsum_workspace_bytes(int groups, int rows_per_group, int N);
+int dmx_colsum(const void* dy, int lddy, int groups, int rows_per_group, int N, float* out, int ldo, int accumulate,
+               void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
 /* K3: GroupNorm (+SiLU) over NHWC bf16; optional virtual channel concat of (x0 | x1).
  * Replaces torch.nn.GroupNorm + SiLU in ResnetBlock2D / Transformer2DModel / VAE blocks. */
 size_t dmx_groupnorm_workspace_bytes(int B, int HW, int groups);

@@ -1,0 +1,76 @@
+"""GPU parity of the training (backward) kernels against torch autograd on the CPU oracle ops.
+
+Inputs are rounded to bf16 first, so the only differences are fp32 accumulation order (and, where a kernel rounds an
+intermediate to bf16, that rounding): tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, bf, seeded
+
+pytestmark = pytest.mark.gpu
+TOL_W = 2e-3      # fp32 accumulation of bf16 products over up to 16k rows
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def nhwc(x, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+
+
+def unpack_dw(dw, Cout, Cin, ks):
+    """packed [N][tap*Cin + c] -> [Cout][Cin][ks][ks]"""
+    return dw.view(Cout, ks, ks, Cin).permute(0, 3, 1, 2).contiguous()
+
+
+WGRAD_CASES = [
+    # name, B, H, W, Cin, Cout, kwargs
+    ("3x3_64_128", 2, 16, 16, 64, 128, {}),
+    ("3x3_320_320", 1, 32, 32, 320, 320, {}),
+    ("3x3_tailN_40", 2, 8, 8, 128, 40, {}),
+    ("3x3_ragged_rows", 3, 5, 7, 64, 64, {}),
+    ("3x3_s2", 2, 16, 16, 64, 64, dict(stride=2)),
+    ("3x3_ups", 2, 8, 8, 64, 128, dict(ups=True)),
+    ("3x3_concat", 2, 8, 8, 192, 64, dict(split=128)),
+    ("1x1_direct", 2, 8, 8, 256, 192, dict(ksize=1, pad=0)),
+    ("linear_big_rows", 1, 64, 64, 128, 320, dict(ksize=1, pad=0)),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_wgrad(cuda, case):
+    from diffute_amd import ops
+    name, B, H, W, Cin, Cout, kw = case
+    ks = kw.get("ksize", 3); st = kw.get("stride", 1); pad = kw.get("pad", 1); ups = kw.get("ups", False)
+    x = bf(seeded((B, Cin, H, W), 1))
+    w = bf(seeded((Cout, Cin, ks, ks), 2, 1.0 / math.sqrt(Cin * ks * ks))).requires_grad_(True)
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    y = F.conv2d(xi, w, None, stride=st, padding=pad)
+    dy = bf(seeded(tuple(y.shape), 3))
+    y.backward(dy)
+    split = kw.get("split")
+    if split:
+        x0, x1 = nhwc(x[:, :split], cuda), nhwc(x[:, split:], cuda)
+    else:
+        x0, x1 = nhwc(x, cuda), None
+    dw = ops.conv_wgrad(x0, nhwc(dy, cuda), x1=x1, ksize=ks, stride=st, pad=pad, ups=ups)
+    assert_close(unpack_dw(dw, Cout, Cin, ks), w.grad, TOL_W, name)
+    # accumulate=1 adds onto an existing gradient (gradient accumulation, train_diffute_v1.py:874)
+    dw2 = ops.conv_wgrad(x0, nhwc(dy, cuda), x1=x1, ksize=ks, stride=st, pad=pad, ups=ups, into=dw.clone())
+    assert_close(dw2, 2.0 * dw.cpu(), 1e-6, name + " accumulate")
+
+
+def test_colsum(cuda):
+    from diffute_amd import ops
+    dy = bf(seeded((4, 24, 24, 200), 5))
+    got = ops.colsum(dy.to(cuda).to(torch.bfloat16), groups=1)
+    assert_close(got, dy.reshape(-1, 200).sum(0, keepdim=True), 1e-5, "bias grad")
+    got = ops.colsum(dy.to(cuda).to(torch.bfloat16), groups=4)
+    assert_close(got, dy.reshape(4, -1, 200).sum(1), 1e-5, "row-bias grad")
