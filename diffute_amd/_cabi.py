@@ -57,6 +57,10 @@ _PROTOS = {
     "dmx_pack_conv_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dmx_pack_linear_weight": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "dmx_pack_geglu_bias": (c_int, [_P, _P, c_int, _P]),
+    "dmx_pack_conv_weight_t": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dmx_pack_linear_weight_t": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "dmx_zero_insert2": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "dmx_sumpool2": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dmx_cast_f32_to_bf16": (c_int, [_P, _P, c_size_t, _P]),
     "dmx_nhwc_bf16_to_nchw_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "dmx_nhwc_f32_to_nchw_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),

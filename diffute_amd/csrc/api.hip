@@ -112,6 +112,22 @@ extern "C" int dmx_pack_linear_weight(const float* w, void* out, int rows, int c
   DMX_REQUIRE(w && out, "pack_linear_weight: null argument");
   return dmx_pack_rows_launch(w, (bf16*)out, rows, cols, ldo, geglu, (hipStream_t)stream);
 }
+extern "C" int dmx_pack_conv_weight_t(const float* w, void* out, int Cout, int Cin, int ksize, int ldk, int koff, dmx_stream_t stream) {
+  DMX_REQUIRE(w && out, "pack_conv_weight_t: null argument");
+  return dmx_pack_conv_weight_t_launch(w, (bf16*)out, Cout, Cin, ksize, ldk, koff, (hipStream_t)stream);
+}
+extern "C" int dmx_pack_linear_weight_t(const float* w, void* out, int rows, int cols, int ldo, dmx_stream_t stream) {
+  DMX_REQUIRE(w && out, "pack_linear_weight_t: null argument");
+  return dmx_pack_rows_t_launch(w, (bf16*)out, rows, cols, ldo, (hipStream_t)stream);
+}
+extern "C" int dmx_zero_insert2(const void* dy, int lddy, void* z, int B, int OH, int OW, int C, dmx_stream_t stream) {
+  DMX_REQUIRE(dy && z, "zero_insert2: null argument");
+  return dmx_zero_insert2_launch((const bf16*)dy, lddy, (bf16*)z, B, OH, OW, C, (hipStream_t)stream);
+}
+extern "C" int dmx_sumpool2(const void* du, int lddu, int du_f32, void* dx, int lddx, int B, int H, int W, int C, int accumulate, dmx_stream_t stream) {
+  DMX_REQUIRE(du && dx, "sumpool2: null argument");
+  return dmx_sumpool2_launch(du, lddu, du_f32, (bf16*)dx, lddx, B, H, W, C, accumulate, (hipStream_t)stream);
+}
 extern "C" int dmx_pack_geglu_bias(const float* b, float* out, int n, dmx_stream_t stream) {
   DMX_REQUIRE(b && out, "pack_geglu_bias: null argument");
   return dmx_pack_geglu_bias_launch(b, out, n, (hipStream_t)stream);

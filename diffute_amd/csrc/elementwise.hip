@@ -136,6 +136,114 @@ int dmx_pack_conv_weight_launch(const float* w, bf16* out, int Cout, int Cin, in
   hipLaunchKernelGGL(dmx_pack_conv_w_kernel, dim3(blocks), dim3(256), 0, stream, w, out, Cout, Cin, ks, ldk, koff);
   return dmx_check_launch("dmx_pack_conv_w_kernel");
 }
+// ---- training: transposed packs for the data-gradient GEMMs (dX = dY * W runs through the forward kernel with the
+// roles of the channel axes swapped), conv [Cout][Cin][ks][ks] -> out[ci][koff + flip(tap)*Cout + n]: the data
+// gradient of a stride-1 conv is the conv of dY with the spatially flipped, channel-transposed filter.
+__global__ __launch_bounds__(256) void dmx_pack_conv_w_t_kernel(const float* w, bf16* out, int Cout, int Cin, int ks, int ldk, int koff) {
+  const size_t total = (size_t)Cout * Cin * ks * ks;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = ks * ks;
+    const int n = (int)(i % Cout);
+    const size_t r = i / Cout;
+    const int tapf = (int)(r % kk);
+    const int ci = (int)(r / kk);
+    const float v = w[((size_t)n * Cin + ci) * kk + (kk - 1 - tapf)];
+    ((unsigned short*)out)[(size_t)ci * ldk + koff + (size_t)tapf * Cout + n] = f2bf_bits(v);
+  }
+}
+int dmx_pack_conv_weight_t_launch(const float* w, bf16* out, int Cout, int Cin, int ks, int ldk, int koff, hipStream_t stream) {
+  const size_t total = (size_t)Cout * Cin * ks * ks;
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dmx_pack_conv_w_t_kernel, dim3(blocks), dim3(256), 0, stream, w, out, Cout, Cin, ks, ldk, koff);
+  return dmx_check_launch("dmx_pack_conv_w_t_kernel");
+}
+// linear [rows][cols] -> bf16 [cols][ldo] (transpose), 32x32 tiles through LDS so both sides are coalesced
+__global__ __launch_bounds__(256) void dmx_pack_rows_t_kernel(const float* w, bf16* out, int rows, int cols, int ldo) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    tile[ty + 8 * j][tx] = (r < rows && c < cols) ? w[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (c < cols && r < rows) ((unsigned short*)out)[(size_t)c * ldo + r] = f2bf_bits(tile[tx][ty + 8 * j]);
+  }
+}
+int dmx_pack_rows_t_launch(const float* w, bf16* out, int rows, int cols, int ldo, hipStream_t stream) {
+  hipLaunchKernelGGL(dmx_pack_rows_t_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, stream, w, out, rows, cols, ldo);
+  return dmx_check_launch("dmx_pack_rows_t_kernel");
+}
+// stride-2 conv data gradient: dX = conv_s1(zero-inserted dY, flipped filter); z[b][2y][2x] = dy[b][y][x], 0 elsewhere
+__global__ __launch_bounds__(256) void dmx_zero_insert2_kernel(const bf16* dy, int lddy, bf16* z, int B, int OH, int OW, int C) {
+  const int c8 = C / 8;
+  const size_t total = (size_t)B * 4 * OH * OW * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8);
+    size_t r = i / c8;
+    const int x = (int)(r % (2 * OW)); r /= 2 * OW;
+    const int y = (int)(r % (2 * OH));
+    const int b = (int)(r / (2 * OH));
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (!(x & 1) && !(y & 1)) v = *(const u32x4*)(dy + ((size_t)(b * OH + (y >> 1)) * OW + (x >> 1)) * lddy + c * 8);
+    *(u32x4*)(z + i * 8) = v;
+  }
+}
+int dmx_zero_insert2_launch(const bf16* dy, int lddy, bf16* z, int B, int OH, int OW, int C, hipStream_t stream) {
+  DMX_REQUIRE(C % 8 == 0 && lddy % 8 == 0, "zero_insert2: C %% 8");
+  const size_t total = (size_t)B * 4 * OH * OW * (C / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dmx_zero_insert2_kernel, dim3(blocks), dim3(256), 0, stream, dy, lddy, z, B, OH, OW, C);
+  return dmx_check_launch("dmx_zero_insert2_kernel");
+}
+// nearest x2 upsample backward: dx[b][y][x] (+)= sum of the 2x2 block of du (bf16 or fp32 in; fp32 sum, one rounding)
+template <bool F32IN>
+__global__ __launch_bounds__(256) void dmx_sumpool2_kernel(const void* du_, int lddu, bf16* dx, int lddx, int B, int H, int W, int C, int accumulate) {
+  const int c8 = C / 8;
+  const size_t total = (size_t)B * H * W * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8);
+    size_t r = i / c8;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t off = ((size_t)(b * 2 * H + 2 * y + (q >> 1)) * (2 * W) + 2 * x + (q & 1)) * lddu + c * 8;
+      float f[8];
+      if (F32IN) {
+        const f32x4 a = *(const f32x4*)((const float*)du_ + off), bq = *(const f32x4*)((const float*)du_ + off + 4);
+        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = bq[0]; f[5] = bq[1]; f[6] = bq[2]; f[7] = bq[3];
+      } else {
+        unpack_bf8(*(const u32x4*)((const bf16*)du_ + off), f);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+    bf16* o = dx + ((size_t)(b * H + y) * W + x) * lddx + c * 8;
+    if (accumulate) {
+      float f[8]; unpack_bf8(*(const u32x4*)o, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+    *(u32x4*)o = pack_bf8(s);
+  }
+}
+int dmx_sumpool2_launch(const void* du, int lddu, int du_f32, bf16* dx, int lddx, int B, int H, int W, int C, int accumulate, hipStream_t stream) {
+  DMX_REQUIRE(C % 8 == 0 && lddu % 8 == 0 && lddx % 8 == 0, "sumpool2: C %% 8");
+  const size_t total = (size_t)B * H * W * (C / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  if (du_f32) hipLaunchKernelGGL(dmx_sumpool2_kernel<true>, dim3(blocks), dim3(256), 0, stream, du, lddu, dx, lddx, B, H, W, C, accumulate);
+  else hipLaunchKernelGGL(dmx_sumpool2_kernel<false>, dim3(blocks), dim3(256), 0, stream, du, lddu, dx, lddx, B, H, W, C, accumulate);
+  return dmx_check_launch("dmx_sumpool2_kernel");
+}
 // linear [rows][cols] -> bf16 [rows][ldo]; geglu=1 interleaves 32-row groups of the value and
 // gate halves ([a0..a31 | b0..b31 | a32..a63 | ...]) so a 64-row MFMA wave tile holds matching pairs.
 __device__ __forceinline__ int geglu_src_row(int r, int rows) {

@@ -121,6 +121,11 @@ int dmx_cast_f32_to_bf16_launch(const float* in, bf16* out, size_t n, hipStream_
 int dmx_pack_conv_weight_launch(const float* w, bf16* out, int Cout, int Cin, int ks, int ldk, int koff, hipStream_t stream);
 int dmx_pack_rows_launch(const float* w, bf16* out, int rows, int cols, int ldo, int geglu, hipStream_t stream);
 int dmx_pack_geglu_bias_launch(const float* b, float* out, int n, hipStream_t stream);
+// training: transposed packs for data-gradient GEMMs, stride-2 / upsample adjoints
+int dmx_pack_conv_weight_t_launch(const float* w, bf16* out, int Cout, int Cin, int ks, int ldk, int koff, hipStream_t stream);
+int dmx_pack_rows_t_launch(const float* w, bf16* out, int rows, int cols, int ldo, hipStream_t stream);
+int dmx_zero_insert2_launch(const bf16* dy, int lddy, bf16* z, int B, int OH, int OW, int C, hipStream_t stream);
+int dmx_sumpool2_launch(const void* du, int lddu, int du_f32, bf16* dx, int lddx, int B, int H, int W, int C, int accumulate, hipStream_t stream);
 int dmx_cast_pad_rows_launch(const void* in, int in_is_bf16, bf16* out, int B, int S, int Spad, int C, hipStream_t stream);
 
 // ------------------------------------------------------------------ temb.hip

@@ -54,6 +54,41 @@ def pack_linear_weight(w, geglu=False):
     return out
 
 
+def pack_conv_weight_t(w):
+    """[Cout,Cin,k,k] fp32 -> bf16 [Cin][k*k*Cout]: flipped taps, channel roles swapped (data-gradient filter)."""
+    w = w.to(torch.float32).contiguous()
+    Cout, Cin, k, _ = w.shape
+    out = torch.empty(Cin, k * k * Cout, dtype=torch.bfloat16, device=w.device)
+    check(lib().dmx_pack_conv_weight_t(ptr(w), ptr(out), Cout, Cin, k, k * k * Cout, 0, current_stream()), "pack_conv_weight_t")
+    return out
+
+
+def pack_linear_weight_t(w):
+    """[N,K] fp32 -> bf16 [K][N]"""
+    w = w.to(torch.float32).contiguous()
+    out = torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=w.device)
+    check(lib().dmx_pack_linear_weight_t(ptr(w), ptr(out), w.shape[0], w.shape[1], w.shape[0], current_stream()), "pack_linear_weight_t")
+    return out
+
+
+def conv_dgrad(dy, wt, Cin, *, ksize=3, stride=1, ups=False, res=None):
+    """dX [B,IH,IW,Cin] bf16 of a pad-(k//2) conv from dy [B,OH,OW,Cout] and the transposed pack of its filter.
+    stride 2: dY is zero-inserted onto the input grid first; ups: the gradient on the upsampled grid is sum-pooled.
+    `res` (bf16, input-shaped) is added: the gradient arriving over a residual / second consumer."""
+    B, OH, OW, Cout = dy.shape
+    g = dy
+    if stride == 2:
+        g = torch.empty(B, 2 * OH, 2 * OW, Cout, dtype=torch.bfloat16, device=dy.device)
+        check(lib().dmx_zero_insert2(ptr(dy), _ld(dy), ptr(g), B, OH, OW, Cout, current_stream()), "zero_insert2")
+    du = conv_gemm(g, wt, Cin, ksize=ksize, stride=1, pad=ksize // 2, res=None if ups else res, out_f32=ups)
+    if not ups:
+        return du
+    H, W = du.shape[1] // 2, du.shape[2] // 2
+    dx = res.clone() if res is not None else torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dy.device)
+    check(lib().dmx_sumpool2(ptr(du), _ld(du), 1, ptr(dx), _ld(dx), B, H, W, Cin, int(res is not None), current_stream()), "sumpool2")
+    return dx
+
+
 def pack_geglu_bias(b):
     b = b.to(torch.float32).contiguous()
     out = torch.empty_like(b)

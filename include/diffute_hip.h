@@ -131,6 +131,14 @@ int dmx_im2col_small(const float* f0, int c0, const float* f1, int c1, const flo
 int dmx_pack_conv_weight(const float* w, void* out, int Cout, int Cin, int ksize, int ldk, int koff, dmx_stream_t stream);
 int dmx_pack_linear_weight(const float* w, void* out, int rows, int cols, int ldo, int geglu, dmx_stream_t stream);
 int dmx_pack_geglu_bias(const float* b, float* out, int n, dmx_stream_t stream);
+/* training: the data gradient dX = dY * W runs through dmx_conv_gemm with a transposed pack of W
+ * (conv: out[ci][flip(tap)*Cout + n], linear: out[k][n]); a stride-2 conv first zero-inserts dY to the input grid,
+ * a conv behind a nearest x2 upsample sum-pools its data gradient 2x2.  (autograd conv/linear backward,
+ * train_diffute_v1.py:925) */
+int dmx_pack_conv_weight_t(const float* w, void* out, int Cout, int Cin, int ksize, int ldk, int koff, dmx_stream_t stream);
+int dmx_pack_linear_weight_t(const float* w, void* out, int rows, int cols, int ldo, dmx_stream_t stream);
+int dmx_zero_insert2(const void* dy, int lddy, void* z, int B, int OH, int OW, int C, dmx_stream_t stream);
+int dmx_sumpool2(const void* du, int lddu, int du_f32, void* dx, int lddx, int B, int H, int W, int C, int accumulate, dmx_stream_t stream);
 
 /* layout helpers */
 int dmx_cast_f32_to_bf16(const float* in, void* out, size_t n, dmx_stream_t stream);

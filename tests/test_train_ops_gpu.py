@@ -74,3 +74,47 @@ def test_colsum(cuda):
     assert_close(got, dy.reshape(-1, 200).sum(0, keepdim=True), 1e-5, "bias grad")
     got = ops.colsum(dy.to(cuda).to(torch.bfloat16), groups=4)
     assert_close(got, dy.reshape(4, -1, 200).sum(1), 1e-5, "row-bias grad")
+
+
+TOL_D = 1e-3      # one bf16 rounding of the fp32-accumulated result
+DGRAD_CASES = [
+    ("3x3_64_128", 2, 16, 16, 64, 128, {}),
+    ("3x3_320_640", 1, 16, 16, 320, 640, {}),
+    ("3x3_s2", 2, 16, 16, 64, 128, dict(stride=2)),
+    ("3x3_ups", 2, 8, 8, 64, 128, dict(ups=True)),
+    ("1x1", 2, 8, 8, 256, 192, dict(ksize=1)),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+def test_conv_dgrad(cuda, case):
+    from diffute_amd import ops
+    name, B, H, W, Cin, Cout, kw = case
+    ks = kw.get("ksize", 3); st = kw.get("stride", 1); ups = kw.get("ups", False)
+    x = bf(seeded((B, Cin, H, W), 1)).requires_grad_(True)
+    w = bf(seeded((Cout, Cin, ks, ks), 2, 1.0 / math.sqrt(Cin * ks * ks)))
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    y = F.conv2d(xi, w, None, stride=st, padding=ks // 2)
+    dy = bf(seeded(tuple(y.shape), 3))
+    y.backward(dy)
+    wt = ops.pack_conv_weight_t(w.to(cuda))
+    dx = ops.conv_dgrad(nhwc(dy, cuda), wt, Cin, ksize=ks, stride=st, ups=ups)
+    assert_close(dx.permute(0, 3, 1, 2), bf(x.grad), TOL_D, name)
+    r = bf(seeded((B, Cin, H, W), 4))
+    dx2 = ops.conv_dgrad(nhwc(dy, cuda), wt, Cin, ksize=ks, stride=st, ups=ups, res=nhwc(r, cuda))
+    assert_close(dx2.permute(0, 3, 1, 2), bf(x.grad + r), 2 * TOL_D, name + " +res")
+
+
+def test_linear_dgrad_and_wgrad(cuda):
+    from diffute_amd import ops
+    M, K, N = 1000, 320, 1280
+    x = bf(seeded((M, K), 1)).requires_grad_(True)
+    w = bf(seeded((N, K), 2, 1.0 / math.sqrt(K))).requires_grad_(True)
+    y = x @ w.t()
+    dy = bf(seeded((M, N), 3))
+    y.backward(dy)
+    dyd = dy.to(cuda).to(torch.bfloat16)
+    dx = ops.linear(dyd, ops.pack_linear_weight_t(w.detach().to(cuda)))
+    assert_close(dx, bf(x.grad), TOL_D, "linear dgrad")
+    dw = ops.conv_wgrad(x.detach().to(cuda).to(torch.bfloat16).view(1, 1, M, K), dyd.view(1, 1, M, N), ksize=1, pad=0)
+    assert_close(dw, w.grad, TOL_W, "linear wgrad")
