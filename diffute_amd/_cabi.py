@@ -48,6 +48,14 @@ _PROTOS = {
     "dmx_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     "dmx_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dmx_groupnorm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, c_int, _P, c_size_t, _P]),
+    "dmx_groupnorm_train": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, c_int, _P, _P, c_size_t, _P]),
+    "dmx_groupnorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dmx_groupnorm_bwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P,
+                                  _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_size_t, _P]),
+    "dmx_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dmx_layernorm_bwd": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    "dmx_geglu_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
+    "dmx_geglu_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P]),
     "dmx_layernorm": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P]),
     "dmx_attention_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "dmx_attention_fwd_v": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),

@@ -63,6 +63,50 @@ extern "C" int dmx_groupnorm(const void* x0, int ldx0, const void* x1, int ldx1,
   a.y = (bf16*)y; a.ldy = ldy; a.partial = (float*)workspace;
   return dmx_groupnorm_launch(a, (hipStream_t)stream);
 }
+extern "C" int dmx_groupnorm_train(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
+                                   int B, int HW, const float* gamma, const float* beta, float eps, int silu,
+                                   void* y, int ldy, float* stats, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(x0 && y && gamma && beta && stats, "groupnorm_train: null argument");
+  DMX_REQUIRE(workspace && workspace_bytes >= dmx_gn_workspace_bytes(B, HW, groups), "groupnorm_train: workspace too small");
+  GroupNormArgs a{};
+  a.x0 = (const bf16*)x0; a.ldx0 = ldx0; a.x1 = (const bf16*)x1; a.ldx1 = ldx1; a.c0 = x1 ? c0 : C;
+  a.C = C; a.groups = groups; a.B = B; a.HW = HW; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
+  a.y = (bf16*)y; a.ldy = ldy; a.partial = (float*)workspace; a.stats_out = stats;
+  return dmx_groupnorm_launch(a, (hipStream_t)stream);
+}
+extern "C" size_t dmx_groupnorm_bwd_workspace_bytes(int B, int HW, int C) { return dmx_gn_bwd_workspace_bytes(B, HW, C); }
+extern "C" int dmx_groupnorm_bwd(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups, int B, int HW,
+                                 const float* gamma, const float* beta, int silu, const float* stats,
+                                 const void* dy, int lddy, void* dx0, int lddx0, void* dx1, int lddx1,
+                                 const void* res0, int ldres0, const void* res1, int ldres1,
+                                 float* dgamma, float* dbeta, int accumulate,
+                                 void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(x0 && dy && dx0 && gamma && beta && stats, "groupnorm_bwd: null argument");
+  DMX_REQUIRE(workspace && workspace_bytes >= dmx_gn_bwd_workspace_bytes(B, HW, C), "groupnorm_bwd: workspace too small");
+  GroupNormBwdArgs a{};
+  a.x0 = (const bf16*)x0; a.ldx0 = ldx0; a.x1 = (const bf16*)x1; a.ldx1 = ldx1; a.c0 = x1 ? c0 : C;
+  a.C = C; a.groups = groups; a.B = B; a.HW = HW; a.gamma = gamma; a.beta = beta; a.silu = silu; a.stats = stats;
+  a.dy = (const bf16*)dy; a.lddy = lddy; a.dx0 = (bf16*)dx0; a.lddx0 = lddx0; a.dx1 = (bf16*)dx1; a.lddx1 = lddx1;
+  a.res0 = (const bf16*)res0; a.ldres0 = ldres0; a.res1 = (const bf16*)res1; a.ldres1 = ldres1;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate; a.part = (float*)workspace;
+  return dmx_groupnorm_bwd_launch(a, (hipStream_t)stream);
+}
+extern "C" size_t dmx_layernorm_bwd_workspace_bytes(int rows, int C) { return dmx_ln_bwd_workspace_bytes(rows, C); }
+extern "C" int dmx_layernorm_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, void* dx, int lddx,
+                                 const void* res, int ldres, float* dgamma, float* dbeta, int accumulate,
+                                 int rows, int C, float eps, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(x && dy && gamma && dx, "layernorm_bwd: null argument");
+  return dmx_layernorm_bwd_launch((const bf16*)x, ldx, (const bf16*)dy, lddy, gamma, (bf16*)dx, lddx, (const bf16*)res, ldres,
+                                  dgamma, dbeta, accumulate, rows, C, eps, workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int dmx_geglu_fwd(const void* h, int ldh, void* y, int ldy, int rows, int C2, dmx_stream_t stream) {
+  DMX_REQUIRE(h && y, "geglu_fwd: null argument");
+  return dmx_geglu_fwd_launch((const bf16*)h, ldh, (bf16*)y, ldy, rows, C2, (hipStream_t)stream);
+}
+extern "C" int dmx_geglu_bwd(const void* h, int ldh, const void* dy, int lddy, void* dh, int lddh, int rows, int C2, dmx_stream_t stream) {
+  DMX_REQUIRE(h && dy && dh, "geglu_bwd: null argument");
+  return dmx_geglu_bwd_launch((const bf16*)h, ldh, (const bf16*)dy, lddy, (bf16*)dh, lddh, rows, C2, (hipStream_t)stream);
+}
 extern "C" int dmx_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                              int rows, int C, float eps, dmx_stream_t stream) {
   DMX_REQUIRE(x && y && gamma && beta, "layernorm: null argument");

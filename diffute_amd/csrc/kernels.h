@@ -80,6 +80,7 @@ struct GroupNormArgs {
   const float* gamma; const float* beta; float eps; int silu;
   bf16* y; int ldy;
   float* partial;     // [B][nchunk][groups][2]
+  float* stats_out;   // optional [B][groups][2] = (mean, rstd), kept for the backward pass (training)
   float* coef;        // [B][C][2] (filled by the launcher: lives behind partial in the workspace)
   int nchunk, rows_per_chunk;
 };
@@ -87,6 +88,28 @@ size_t dmx_gn_workspace_bytes(int B, int HW, int groups);
 int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream);
 int dmx_layernorm_launch(const bf16* x, int ldx, bf16* y, int ldy, const float* gamma, const float* beta,
                          int rows, int C, float eps, hipStream_t stream);
+
+// ------------------------------------------------------------------ norm_bwd.hip (training)
+struct GroupNormBwdArgs {
+  const bf16* x0; const bf16* x1; int ldx0, ldx1; int c0;   // forward input (two-source concat on channels)
+  int C, groups; int B, HW;
+  const float* gamma; const float* beta; int silu;
+  const float* stats;            // [B][groups][2] = (mean, rstd) saved by the forward
+  const bf16* dy; int lddy;
+  bf16* dx0; int lddx0; bf16* dx1; int lddx1;               // input gradient, split like the input
+  const bf16* res0; int ldres0; const bf16* res1; int ldres1;   // optional gradients to add (other consumers of x)
+  float* dgamma; float* dbeta; int accumulate;
+  float* part;                   // workspace, dmx_gn_bwd_workspace_bytes
+  float* ab; int nchunk, rows_per_chunk;                    // filled by the launcher
+};
+size_t dmx_gn_bwd_workspace_bytes(int B, int HW, int C);
+int dmx_groupnorm_bwd_launch(GroupNormBwdArgs a, hipStream_t stream);
+size_t dmx_ln_bwd_workspace_bytes(int rows, int C);
+int dmx_layernorm_bwd_launch(const bf16* x, int ldx, const bf16* dy, int lddy, const float* gamma, bf16* dx, int lddx,
+                             const bf16* res, int ldres, float* dgamma, float* dbeta, int accumulate,
+                             int rows, int C, float eps, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int dmx_geglu_fwd_launch(const bf16* h, int ldh, bf16* y, int ldy, int rows, int C2, hipStream_t stream);
+int dmx_geglu_bwd_launch(const bf16* h, int ldh, const bf16* dy, int lddy, bf16* dh, int lddh, int rows, int C2, hipStream_t stream);
 
 int dmx_softmax_rows_launch(const float* s, int lds_, bf16* p, int ldp, int rows, int n, float scale, hipStream_t stream);
 

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(1024) void dmx_gn_apply_kernel(const GroupNormArgs 
       float var = q * inv_n - mean * mean;
       var = var < 0.f ? 0.f : var;
       MEAN[t] = mean; RSTD[t] = rsqrtf(var + p.eps);
+      if (p.stats_out && blockIdx.x == 0) { p.stats_out[((size_t)b * G + t) * 2] = mean; p.stats_out[((size_t)b * G + t) * 2 + 1] = RSTD[t]; }
     }
     __syncthreads();
   }

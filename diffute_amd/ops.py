@@ -204,6 +204,65 @@ def groupnorm(x0, gamma, beta, groups, eps, silu, x1=None):
     return y
 
 
+def groupnorm_train(x0, gamma, beta, groups, eps, silu, x1=None):
+    """forward GroupNorm that also returns the saved (mean, rstd) [B][groups][2]"""
+    B, H, W, C0 = x0.shape
+    C = C0 + (x1.shape[-1] if x1 is not None else 0)
+    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x0.device)
+    stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x0.device)
+    wsb = lib().dmx_groupnorm_workspace_bytes(B, H * W, groups)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x0.device)
+    check(lib().dmx_groupnorm_train(ptr(x0), _ld(x0), ptr(x1), _ld(x1) if x1 is not None else 0, C0, C, groups, B, H * W,
+                                    ptr(gamma), ptr(beta), float(eps), int(silu), ptr(y), C, ptr(stats), ptr(ws), wsb, current_stream()),
+          "groupnorm_train")
+    return y, stats
+
+
+def groupnorm_bwd(x0, dy, gamma, beta, groups, silu, stats, x1=None, res0=None, res1=None):
+    """-> (dx0, dx1 or None, dgamma, dbeta)"""
+    B, H, W, C0 = x0.shape
+    C = C0 + (x1.shape[-1] if x1 is not None else 0)
+    dx0 = torch.empty_like(x0)
+    dx1 = torch.empty_like(x1) if x1 is not None else None
+    dg = torch.empty(C, dtype=torch.float32, device=x0.device); db = torch.empty_like(dg)
+    wsb = lib().dmx_groupnorm_bwd_workspace_bytes(B, H * W, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x0.device)
+    check(lib().dmx_groupnorm_bwd(ptr(x0), _ld(x0), ptr(x1), _ld(x1) if x1 is not None else 0, C0, C, groups, B, H * W,
+                                  ptr(gamma), ptr(beta), int(silu), ptr(stats), ptr(dy), _ld(dy),
+                                  ptr(dx0), _ld(dx0), ptr(dx1), _ld(dx1) if dx1 is not None else 0,
+                                  ptr(res0), _ld(res0) if res0 is not None else 0, ptr(res1), _ld(res1) if res1 is not None else 0,
+                                  ptr(dg), ptr(db), 0, ptr(ws), wsb, current_stream()), "groupnorm_bwd")
+    return dx0, dx1, dg, db
+
+
+def layernorm_bwd(x, dy, gamma, eps=1e-5, res=None):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device); db = torch.empty_like(dg)
+    wsb = lib().dmx_layernorm_bwd_workspace_bytes(rows, C)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
+    check(lib().dmx_layernorm_bwd(ptr(x), C, ptr(dy), C, ptr(gamma), ptr(dx), C, ptr(res), C if res is not None else 0,
+                                  ptr(dg), ptr(db), 0, rows, C, float(eps), ptr(ws), wsb, current_stream()), "layernorm_bwd")
+    return dx, dg, db
+
+
+def geglu_fwd(h):
+    C2 = h.shape[-1] // 2
+    rows = h.numel() // (2 * C2)
+    y = torch.empty(*h.shape[:-1], C2, dtype=torch.bfloat16, device=h.device)
+    check(lib().dmx_geglu_fwd(ptr(h), 2 * C2, ptr(y), C2, rows, C2, current_stream()), "geglu_fwd")
+    return y
+
+
+def geglu_bwd(h, dy):
+    C2 = h.shape[-1] // 2
+    rows = h.numel() // (2 * C2)
+    dh = torch.empty_like(h)
+    check(lib().dmx_geglu_bwd(ptr(h), 2 * C2, ptr(dy), C2, ptr(dh), 2 * C2, rows, C2, current_stream()), "geglu_bwd")
+    return dh
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     C = x.shape[-1]
     rows = x.numel() // C

@@ -97,6 +97,28 @@ int dmx_groupnorm(const void* x0, int ldx0, const void* x1, int ldx1, int c0, in
                   int B, int HW, const float* gamma, const float* beta, float eps, int silu,
                   void* y, int ldy, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* Training (P5 over K3/K4/K8): forward GroupNorm that also keeps (mean, rstd) per (image, group), and the backward
+ * kernels of GroupNorm(+SiLU), LayerNorm and the unfused GEGLU.  All deterministic.  `res*` is an optional gradient
+ * added into dx (the tensor's other consumer, e.g. the residual branch); dgamma/dbeta fp32, `accumulate` adds.
+ * Replace autograd's native_group_norm_backward / native_layer_norm_backward / gelu_backward under
+ * accelerator.backward (train_diffute_v1.py:925). */
+int dmx_groupnorm_train(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
+                        int B, int HW, const float* gamma, const float* beta, float eps, int silu,
+                        void* y, int ldy, float* stats, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+size_t dmx_groupnorm_bwd_workspace_bytes(int B, int HW, int C);
+int dmx_groupnorm_bwd(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups, int B, int HW,
+                      const float* gamma, const float* beta, int silu, const float* stats,
+                      const void* dy, int lddy, void* dx0, int lddx0, void* dx1, int lddx1,
+                      const void* res0, int ldres0, const void* res1, int ldres1,
+                      float* dgamma, float* dbeta, int accumulate,
+                      void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+size_t dmx_layernorm_bwd_workspace_bytes(int rows, int C);
+int dmx_layernorm_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, void* dx, int lddx,
+                      const void* res, int ldres, float* dgamma, float* dbeta, int accumulate,
+                      int rows, int C, float eps, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+int dmx_geglu_fwd(const void* h, int ldh, void* y, int ldy, int rows, int C2, dmx_stream_t stream);
+int dmx_geglu_bwd(const void* h, int ldh, const void* dy, int lddy, void* dh, int lddh, int rows, int C2, dmx_stream_t stream);
+
 /* K4: LayerNorm over the channel axis of [rows][C] bf16 (BasicTransformerBlock norm1/2/3). */
 int dmx_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, float eps, dmx_stream_t stream);

@@ -118,3 +118,67 @@ def test_linear_dgrad_and_wgrad(cuda):
     assert_close(dx, bf(x.grad), TOL_D, "linear dgrad")
     dw = ops.conv_wgrad(x.detach().to(cuda).to(torch.bfloat16).view(1, 1, M, K), dyd.view(1, 1, M, N), ksize=1, pad=0)
     assert_close(dw, w.grad, TOL_W, "linear wgrad")
+
+
+TOL_N = 4e-3      # dx is rounded to bf16 once; du / xhat are recomputed from bf16 x in fp32
+GN_CASES = [
+    # name, B, H, W, C, groups, silu, split (None or c0)
+    ("320_silu", 2, 16, 16, 320, 32, True, None),
+    ("960_concat_silu", 2, 8, 8, 960, 32, True, 640),
+    ("1280_plain", 1, 8, 8, 1280, 32, False, None),
+    ("2560_concat", 2, 4, 4, 2560, 32, True, 1280),
+    ("64_rows_4096", 1, 64, 64, 64, 32, True, None),
+]
+
+
+@pytest.mark.parametrize("case", GN_CASES, ids=[c[0] for c in GN_CASES])
+def test_groupnorm_bwd(cuda, case):
+    from diffute_amd import ops
+    name, B, H, W, C, G, silu, split = case
+    x = bf(seeded((B, C, H, W), 1) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1.0 + 0.1 * seeded((C,), 2)).requires_grad_(True)
+    beta = (0.1 * seeded((C,), 3)).requires_grad_(True)
+    u = F.group_norm(x, G, gamma, beta, eps=1e-5)
+    y = F.silu(u) if silu else u
+    dy = bf(seeded((B, C, H, W), 4))
+    r = bf(seeded((B, C, H, W), 5))
+    y.backward(dy)
+    xs = [nhwc(x.detach()[:, :split], cuda), nhwc(x.detach()[:, split:], cuda)] if split else [nhwc(x.detach(), cuda), None]
+    yh, stats = ops.groupnorm_train(xs[0], gamma.detach().to(cuda), beta.detach().to(cuda), G, 1e-5, silu, x1=xs[1])
+    assert_close(yh.permute(0, 3, 1, 2), bf(y.detach()), 4e-3, name + " fwd")
+    rs = [nhwc(r[:, :split], cuda), nhwc(r[:, split:], cuda)] if split else [nhwc(r, cuda), None]
+    dx0, dx1, dg, db = ops.groupnorm_bwd(xs[0], nhwc(dy, cuda), gamma.detach().to(cuda), beta.detach().to(cuda), G, silu, stats,
+                                         x1=xs[1], res0=rs[0], res1=rs[1])
+    dx = torch.cat([dx0, dx1], dim=-1) if split else dx0
+    assert_close(dx.permute(0, 3, 1, 2), bf(x.grad + r), TOL_N, name + " dx")
+    assert_close(dg, gamma.grad, TOL_N, name + " dgamma")
+    assert_close(db, beta.grad, TOL_N, name + " dbeta")
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (256, 1280), (70, 640), (33, 2048)])
+def test_layernorm_bwd(cuda, rows, C):
+    from diffute_amd import ops
+    x = bf(seeded((rows, C), 1) * 2.0 + 0.5).requires_grad_(True)
+    gamma = (1.0 + 0.1 * seeded((C,), 2)).requires_grad_(True)
+    beta = (0.1 * seeded((C,), 3)).requires_grad_(True)
+    y = F.layer_norm(x, (C,), gamma, beta, eps=1e-5)
+    dy = bf(seeded((rows, C), 4)); r = bf(seeded((rows, C), 5))
+    y.backward(dy)
+    xd = x.detach().to(cuda).to(torch.bfloat16)
+    dx, dg, db = ops.layernorm_bwd(xd, dy.to(cuda).to(torch.bfloat16), gamma.detach().to(cuda), res=r.to(cuda).to(torch.bfloat16))
+    assert_close(dx, bf(x.grad + r), TOL_N, "ln dx")
+    assert_close(dg, gamma.grad, TOL_N, "ln dgamma")
+    assert_close(db, beta.grad, TOL_N, "ln dbeta")
+
+
+def test_geglu_fwd_bwd(cuda):
+    from diffute_amd import ops
+    rows, C2 = 300, 1280
+    h = bf(seeded((rows, 2 * C2), 1) * 1.5).requires_grad_(True)
+    a, g = h.chunk(2, dim=-1)
+    y = a * F.gelu(g)
+    dy = bf(seeded((rows, C2), 2))
+    y.backward(dy)
+    hd = h.detach().to(cuda).to(torch.bfloat16)
+    assert_close(ops.geglu_fwd(hd), bf(y.detach()), 4e-3, "geglu fwd")
+    assert_close(ops.geglu_bwd(hd, dy.to(cuda).to(torch.bfloat16)), bf(h.grad), 4e-3, "geglu bwd")
