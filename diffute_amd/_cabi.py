@@ -59,6 +59,10 @@ _PROTOS = {
     "dmx_layernorm": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P]),
     "dmx_attention_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "dmx_attention_fwd_v": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "dmx_attention_fwd_train": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "dmx_attention_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dmx_attention_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int,
+                                  c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
     "dmx_timestep_embedding": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "dmx_linear_small": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dmx_im2col_small": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

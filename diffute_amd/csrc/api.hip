@@ -130,6 +130,29 @@ extern "C" int dmx_attention_fwd_v(const void* q, int ldq, const void* k, int ld
   a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
   return dmx_attention_launch(a, (hipStream_t)stream);
 }
+extern "C" int dmx_attention_fwd_train(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                                       void* o, int ldo, float* lse, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream) {
+  DMX_REQUIRE(q && k && v && o && lse, "attention_fwd_train: null argument");
+  AttnArgs a{};
+  a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.kv_rows = kv_rows;
+  a.v = (const bf16*)v; a.ldv = ldv; a.o = (bf16*)o; a.ldo = ldo; a.lse = lse;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  return dmx_attention_launch(a, (hipStream_t)stream);
+}
+extern "C" size_t dmx_attention_bwd_workspace_bytes(int B, int H, int Sq) { return dmx_attn_bwd_ws_bytes(B, H, Sq); }
+extern "C" int dmx_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                                 const void* o, const void* d_o, int ldo, const float* lse,
+                                 void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
+                                 int B, int H, int Sq, int Skv, float scale,
+                                 void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(workspace && workspace_bytes >= dmx_attn_bwd_ws_bytes(B, H, Sq), "attention_bwd: workspace too small");
+  AttnBwdArgs a{};
+  a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.v = (const bf16*)v; a.ldv = ldv; a.kv_rows = kv_rows;
+  a.o = (const bf16*)o; a.dout = (const bf16*)d_o; a.ldo = ldo; a.lse = lse; a.delta = (float*)workspace;
+  a.dq = (bf16*)dq; a.lddq = lddq; a.dk = (bf16*)dk; a.lddk = lddk; a.dv = (bf16*)dv; a.lddv = lddv;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  return dmx_attention_bwd_launch(a, (hipStream_t)stream);
+}
 extern "C" int dmx_timestep_embedding(const int64_t* t, int t_count, const float* freq, int B, int dim, float* out, dmx_stream_t stream) {
   DMX_REQUIRE(t && freq && out, "timestep_embedding: null argument");
   return dmx_timestep_embedding_launch((const long long*)t, t_count, freq, B, dim, out, (hipStream_t)stream);

@@ -206,6 +206,8 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + lr;
+  // training: keep the row's log2-sum-exp of the scaled scores, P = exp2(s*scale*log2e - lse)
+  if (p.lse && qrow < p.Sq && lh == 0) p.lse[((size_t)b * p.H + h) * p.Sq + qrow] = m_run * sl2 + log2f(l_tot);
   if (qrow < p.Sq) {
     bf16* op = p.o + ((size_t)b * p.Sq + qrow) * p.ldo + h * 64 + 4 * lh;
 #pragma unroll

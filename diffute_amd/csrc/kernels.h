@@ -124,8 +124,21 @@ struct AttnArgs {
   bf16* o; int ldo;
   int B, H, Sq, Skv;
   float scale;
+  float* lse;                    // optional [B][H][Sq]: log2-sum-exp of the scaled scores (kept for the backward pass)
 };
 int dmx_attention_launch(const AttnArgs& a, hipStream_t stream);
+
+// ------------------------------------------------------------------ attention_bwd.hip (training)
+struct AttnBwdArgs {
+  const bf16* q; int ldq; const bf16* k; int ldk; const bf16* v; int ldv; int kv_rows;   // as the forward (row-major V)
+  const bf16* o; const bf16* dout; int ldo;      // forward output and its gradient, same layout
+  const float* lse;                              // [B][H][Sq] from the forward
+  float* delta;                                  // workspace [B][H][Sq]: rowsum(dO * O)
+  bf16* dq; int lddq; bf16* dk; int lddk; bf16* dv; int lddv;
+  int B, H, Sq, Skv; float scale;
+};
+size_t dmx_attn_bwd_ws_bytes(int B, int H, int Sq);
+int dmx_attention_bwd_launch(const AttnBwdArgs& a, hipStream_t stream);
 
 // ------------------------------------------------------------------ elementwise.hip
 struct Im2colArgs {

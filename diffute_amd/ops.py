@@ -290,6 +290,25 @@ def attention_v(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
     return o
 
 
+def attention_train(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
+    """forward with row-major V that also returns lse [B,H,Sq] (log2 domain)"""
+    o = torch.empty(B * Sq, H * 64, dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+    check(lib().dmx_attention_fwd_train(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), kv_rows or Skv,
+                                        ptr(o), H * 64, ptr(lse), B, H, Sq, Skv, float(scale), current_stream()), "attention_fwd_train")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, B, H, Sq, Skv, scale, kv_rows=None):
+    dq = torch.empty_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+    wsb = lib().dmx_attention_bwd_workspace_bytes(B, H, Sq)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+    check(lib().dmx_attention_bwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), kv_rows or Skv,
+                                  ptr(o), ptr(do), o.stride(0), ptr(lse), ptr(dq), dq.stride(0), ptr(dk), dk.stride(0), ptr(dv), dv.stride(0),
+                                  B, H, Sq, Skv, float(scale), ptr(ws), wsb, current_stream()), "attention_bwd")
+    return dq, dk, dv
+
+
 def im2col_small(sources=None, nhwc=None, ksize=3, stride=1, pad=1, Kpad=64):
     if nhwc is not None:
         B, H, W, C = nhwc.shape

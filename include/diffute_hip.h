@@ -136,6 +136,18 @@ int dmx_attention_fwd(const void* q, int ldq, const void* k, int ldk, int kv_row
 int dmx_attention_fwd_v(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
                         void* o, int ldo, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream);
 
+/* Training (P5 over K5/K6): forward that also keeps each row's log2-sum-exp, and the flash-style backward (dQ, dK, dV;
+ * deterministic, nothing of size Sq x Skv is stored).  workspace: [B][H][Sq] floats.  Replace autograd's scaled-dot-
+ * product-attention backward under accelerator.backward (train_diffute_v1.py:925). */
+int dmx_attention_fwd_train(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                            void* o, int ldo, float* lse, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream);
+size_t dmx_attention_bwd_workspace_bytes(int B, int H, int Sq);
+int dmx_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                      const void* o, const void* d_o, int ldo, const float* lse,
+                      void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
+                      int B, int H, int Sq, int Skv, float scale,
+                      void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
 /* K9: sinusoidal timestep embedding (flip_sin_to_cos) and the small-M fp32 linear used by the
  * time-embedding MLP.  t: int64 [t_count] (t_count 1 or B); freq: fp32 [dim/2] table. */
 int dmx_timestep_embedding(const int64_t* t, int t_count, const float* freq, int B, int dim, float* out, dmx_stream_t stream);

@@ -182,3 +182,32 @@ def test_geglu_fwd_bwd(cuda):
     hd = h.detach().to(cuda).to(torch.bfloat16)
     assert_close(ops.geglu_fwd(hd), bf(y.detach()), 4e-3, "geglu fwd")
     assert_close(ops.geglu_bwd(hd, dy.to(cuda).to(torch.bfloat16)), bf(h.grad), 4e-3, "geglu bwd")
+
+
+TOL_A = 1.5e-2    # P and dS pass through bf16 (rel 2^-9 each) before the second MFMA, like the forward kernel
+ATTN_CASES = [("self_256", 2, 5, 256, 256), ("self_1024", 1, 10, 1024, 1024), ("cross_577", 2, 5, 256, 577),
+              ("tiny_64", 2, 20, 64, 64), ("ragged_200_150", 1, 3, 200, 150)]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention_bwd(cuda, case):
+    from diffute_amd import ops
+    name, B, H, Sq, Skv = case
+    D = 64
+    q = bf(seeded((B, Sq, H * D), 1)).requires_grad_(True)
+    k = bf(seeded((B, Skv, H * D), 2)).requires_grad_(True)
+    v = bf(seeded((B, Skv, H * D), 3)).requires_grad_(True)
+    def heads(x, S):
+        return x.view(B, S, H, D).transpose(1, 2)
+    o = F.scaled_dot_product_attention(heads(q, Sq), heads(k, Skv), heads(v, Skv), scale=0.125)
+    o = o.transpose(1, 2).reshape(B, Sq, H * D)
+    do = bf(seeded((B, Sq, H * D), 4))
+    o.backward(do)
+    dev = lambda x, S: x.detach().reshape(B * S, H * D).to(cuda).to(torch.bfloat16)
+    qd, kd, vd = dev(q, Sq), dev(k, Skv), dev(v, Skv)
+    oh, lse = ops.attention_train(qd, kd, vd, B, H, Sq, Skv, 0.125)
+    assert_close(oh.view(B, Sq, H * D), bf(o.detach()), 4e-3, name + " fwd")
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, oh, dev(do, Sq), lse, B, H, Sq, Skv, 0.125)
+    assert_close(dq.view(B, Sq, H * D), q.grad, TOL_A, name + " dq")
+    assert_close(dk.view(B, Skv, H * D), k.grad, TOL_A, name + " dk")
+    assert_close(dv.view(B, Skv, H * D), v.grad, TOL_A, name + " dv")
