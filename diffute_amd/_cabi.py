@@ -95,6 +95,19 @@ _PROTOS = {
     "dmx_unet_set_context": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_size_t, _P, c_size_t, _P]),
     "dmx_unet_forward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "dmx_unet_forward_graph": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_unet_train_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
+    "dmx_unet_train_wt_bytes": (c_size_t, [_P]),
+    "dmx_unet_train_prepare": (c_int, [_P, _P, c_size_t, _P]),
+    "dmx_unet_grad_bytes": (c_size_t, [_P]),
+    "dmx_unet_train_forward": (c_int, [_P, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_unet_train_bucket_count": (c_int, [_P]),
+    "dmx_unet_train_bucket_range": (c_int, [_P, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "dmx_unet_train_tail_range": (c_int, [_P, POINTER(c_size_t), POINTER(c_size_t)]),
+    "dmx_unet_train_backward": (c_int, [_P, _P, _P, _P, c_int, _P]),
+    "dmx_unet_grad_export": (c_int, [_P, _P, c_char_p, _P, _P]),
+    "dmx_unet_grad_range": (c_int, [_P, c_char_p, POINTER(c_size_t), POINTER(c_size_t)]),
+    "dmx_mse_loss_workspace_bytes": (c_size_t, []),
+    "dmx_mse_loss": (c_int, [_P, _P, c_size_t, _P, _P, c_float, _P, c_size_t, _P]),
     "dmx_profile_begin": (c_int, []),
     "dmx_profile_end": (c_int, [POINTER(ctypes.c_double), c_int]),
     "dmx_profile_dump_path": (c_int, [c_char_p]),

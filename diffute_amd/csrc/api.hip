@@ -101,11 +101,11 @@ extern "C" int dmx_layernorm_bwd(const void* x, int ldx, const void* dy, int ldd
 }
 extern "C" int dmx_geglu_fwd(const void* h, int ldh, void* y, int ldy, int rows, int C2, dmx_stream_t stream) {
   DMX_REQUIRE(h && y, "geglu_fwd: null argument");
-  return dmx_geglu_fwd_launch((const bf16*)h, ldh, (bf16*)y, ldy, rows, C2, (hipStream_t)stream);
+  return dmx_geglu_fwd_launch((const bf16*)h, ldh, (bf16*)y, ldy, rows, C2, 0, (hipStream_t)stream);
 }
 extern "C" int dmx_geglu_bwd(const void* h, int ldh, const void* dy, int lddy, void* dh, int lddh, int rows, int C2, dmx_stream_t stream) {
   DMX_REQUIRE(h && dy && dh, "geglu_bwd: null argument");
-  return dmx_geglu_bwd_launch((const bf16*)h, ldh, (const bf16*)dy, lddy, (bf16*)dh, lddh, rows, C2, (hipStream_t)stream);
+  return dmx_geglu_bwd_launch((const bf16*)h, ldh, (const bf16*)dy, lddy, (bf16*)dh, lddh, rows, C2, 0, (hipStream_t)stream);
 }
 extern "C" int dmx_layernorm(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                              int rows, int C, float eps, dmx_stream_t stream) {

@@ -62,7 +62,7 @@ struct WgradArgs {
   int direct;
   int IH, IW, OH, OW, stride, pad, ups, ksize, Cin;
   int M, N, K;                   // K = ksize*ksize*Cin (conv) or the plain feature count (direct)
-  float* out;                    // dW [N][K] fp32, packed k order (tap-major, channel-minor)
+  float* out; int ldout;         // dW [N][ldout] fp32 (ldout 0 = K), packed k order (tap-major, channel-minor)
   int accumulate;                // out += instead of out =
   int splits, rows_per_split;    // filled by the launcher
   const bf16* zeros;             // filled by the launcher
@@ -108,8 +108,9 @@ size_t dmx_ln_bwd_workspace_bytes(int rows, int C);
 int dmx_layernorm_bwd_launch(const bf16* x, int ldx, const bf16* dy, int lddy, const float* gamma, bf16* dx, int lddx,
                              const bf16* res, int ldres, float* dgamma, float* dbeta, int accumulate,
                              int rows, int C, float eps, void* workspace, size_t workspace_bytes, hipStream_t stream);
-int dmx_geglu_fwd_launch(const bf16* h, int ldh, bf16* y, int ldy, int rows, int C2, hipStream_t stream);
-int dmx_geglu_bwd_launch(const bf16* h, int ldh, const bf16* dy, int lddy, bf16* dh, int lddh, int rows, int C2, hipStream_t stream);
+// packed = 1: h columns in the GEGLU weight-pack order (32 value columns, 32 gate columns, alternating)
+int dmx_geglu_fwd_launch(const bf16* h, int ldh, bf16* y, int ldy, int rows, int C2, int packed, hipStream_t stream);
+int dmx_geglu_bwd_launch(const bf16* h, int ldh, const bf16* dy, int lddy, bf16* dh, int lddh, int rows, int C2, int packed, hipStream_t stream);
 
 int dmx_softmax_rows_launch(const float* s, int lds_, bf16* p, int ldp, int rows, int n, float scale, hipStream_t stream);
 
@@ -163,6 +164,17 @@ int dmx_pack_rows_t_launch(const float* w, bf16* out, int rows, int cols, int ld
 int dmx_zero_insert2_launch(const bf16* dy, int lddy, bf16* z, int B, int OH, int OW, int C, hipStream_t stream);
 int dmx_sumpool2_launch(const void* du, int lddu, int du_f32, bf16* dx, int lddx, int B, int H, int W, int C, int accumulate, hipStream_t stream);
 int dmx_cast_pad_rows_launch(const void* in, int in_is_bf16, bf16* out, int B, int S, int Spad, int C, hipStream_t stream);
+
+// ------------------------------------------------------------------ train_small.hip (training)
+int dmx_transpose_bf16_launch(const bf16* in, int ldin, bf16* out, int ldout, int R, int C, hipStream_t stream);
+int dmx_add_bf16_launch(const bf16* a, int lda, const bf16* b, int ldb, bf16* o, int ldo, int rows, int C, hipStream_t stream);
+size_t dmx_mse_workspace_bytes();
+int dmx_mse_loss_launch(const float* pred, const float* target, size_t n, float* loss, float* dpred, float grad_scale,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream);
+// y = W act(x) + b with act = SiLU when silu_in (dmx_linear_small): dw (+)= dy^T act(x), db (+)= colsum(dy), dx = act'(x) * (dy W)
+int dmx_linear_small_bwd_launch(const float* x, int ldx, const float* dy, int lddy, const bf16* w, int ldw,
+                                float* dw, int lddw, float* db, int db_stride, float* dx, int lddx,
+                                int B, int N, int K, int silu_in, int accumulate, hipStream_t stream);
 
 // ------------------------------------------------------------------ temb.hip
 int dmx_timestep_embedding_launch(const long long* t, int t_count, const float* freq, int B, int dim, float* out, hipStream_t stream);

@@ -253,30 +253,32 @@ __device__ __forceinline__ float gelu_exact_f(float x) { return 0.5f * x * (1.0f
 __device__ __forceinline__ float dgelu_exact_f(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
-__global__ __launch_bounds__(256) void dmx_geglu_fwd_kernel(const bf16* h, int ldh, bf16* y, int ldy, int rows, int C2) {
+__global__ __launch_bounds__(256) void dmx_geglu_fwd_kernel(const bf16* h, int ldh, bf16* y, int ldy, int rows, int C2, int packed) {
   const int c8 = C2 / 8;
   const size_t total = (size_t)rows * c8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % c8) * 8; const size_t r = i / c8;
-    float a[8], g[8]; unpack_bf8(*(const u32x4*)(h + r * ldh + c), a); unpack_bf8(*(const u32x4*)(h + r * ldh + C2 + c), g);
+    const int ac = packed ? 64 * (c >> 5) + (c & 31) : c, gc = packed ? ac + 32 : C2 + c;
+    float a[8], g[8]; unpack_bf8(*(const u32x4*)(h + r * ldh + ac), a); unpack_bf8(*(const u32x4*)(h + r * ldh + gc), g);
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] *= gelu_exact_f(g[e]);
     *(u32x4*)(y + r * ldy + c) = pack_bf8(a);
   }
 }
-__global__ __launch_bounds__(256) void dmx_geglu_bwd_kernel(const bf16* h, int ldh, const bf16* dy, int lddy, bf16* dh, int lddh, int rows, int C2) {
+__global__ __launch_bounds__(256) void dmx_geglu_bwd_kernel(const bf16* h, int ldh, const bf16* dy, int lddy, bf16* dh, int lddh, int rows, int C2, int packed) {
   const int c8 = C2 / 8;
   const size_t total = (size_t)rows * c8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % c8) * 8; const size_t r = i / c8;
+    const int ac = packed ? 64 * (c >> 5) + (c & 31) : c, gc = packed ? ac + 32 : C2 + c;
     float a[8], g[8], d[8];
-    unpack_bf8(*(const u32x4*)(h + r * ldh + c), a); unpack_bf8(*(const u32x4*)(h + r * ldh + C2 + c), g);
+    unpack_bf8(*(const u32x4*)(h + r * ldh + ac), a); unpack_bf8(*(const u32x4*)(h + r * ldh + gc), g);
     unpack_bf8(*(const u32x4*)(dy + r * lddy + c), d);
     float da[8], dg[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { da[e] = d[e] * gelu_exact_f(g[e]); dg[e] = d[e] * a[e] * dgelu_exact_f(g[e]); }
-    *(u32x4*)(dh + r * lddh + c) = pack_bf8(da);
-    *(u32x4*)(dh + r * lddh + C2 + c) = pack_bf8(dg);
+    *(u32x4*)(dh + r * lddh + ac) = pack_bf8(da);
+    *(u32x4*)(dh + r * lddh + gc) = pack_bf8(dg);
   }
 }
 }  // namespace
@@ -335,17 +337,17 @@ int dmx_layernorm_bwd_launch(const bf16* x, int ldx, const bf16* dy, int lddy, c
   return dmx_check_launch("dmx_ln_bwd_params_kernel");
 }
 
-int dmx_geglu_fwd_launch(const bf16* h, int ldh, bf16* y, int ldy, int rows, int C2, hipStream_t stream) {
-  DMX_REQUIRE(C2 % 8 == 0 && ldh % 8 == 0 && ldy % 8 == 0, "geglu: C2 %% 8");
+int dmx_geglu_fwd_launch(const bf16* h, int ldh, bf16* y, int ldy, int rows, int C2, int packed, hipStream_t stream) {
+  DMX_REQUIRE(C2 % 8 == 0 && ldh % 8 == 0 && ldy % 8 == 0 && (!packed || C2 % 32 == 0), "geglu: C2 %% 8 (%% 32 when packed)");
   const size_t total = (size_t)rows * (C2 / 8);
   int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(dmx_geglu_fwd_kernel, dim3(blocks), dim3(256), 0, stream, h, ldh, y, ldy, rows, C2);
+  hipLaunchKernelGGL(dmx_geglu_fwd_kernel, dim3(blocks), dim3(256), 0, stream, h, ldh, y, ldy, rows, C2, packed);
   return dmx_check_launch("dmx_geglu_fwd_kernel");
 }
-int dmx_geglu_bwd_launch(const bf16* h, int ldh, const bf16* dy, int lddy, bf16* dh, int lddh, int rows, int C2, hipStream_t stream) {
+int dmx_geglu_bwd_launch(const bf16* h, int ldh, const bf16* dy, int lddy, bf16* dh, int lddh, int rows, int C2, int packed, hipStream_t stream) {
   DMX_REQUIRE(C2 % 8 == 0 && ldh % 8 == 0 && lddy % 8 == 0 && lddh % 8 == 0, "geglu_bwd: C2 %% 8");
   const size_t total = (size_t)rows * (C2 / 8);
   int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(dmx_geglu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, h, ldh, dy, lddy, dh, lddh, rows, C2);
+  hipLaunchKernelGGL(dmx_geglu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, h, ldh, dy, lddy, dh, lddh, rows, C2, packed);
   return dmx_check_launch("dmx_geglu_bwd_kernel");
 }

@@ -1,0 +1,129 @@
+// Small helpers of the training path: bf16 transposes (the data-gradient GEMMs read W^T),
+// elementwise gradient adds, the MSE loss (train_diffute_v1.py:918) with its gradient, and the backward of the tiny
+// fp32 time-embedding linears (M = batch).  Everything deterministic.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+// out[c][r] = in[r][c], 32x32 tiles through LDS (both sides coalesced)
+__global__ __launch_bounds__(256) void dmx_transpose_bf16_kernel(const unsigned short* in, int ldin, unsigned short* out, int ldout, int R, int C) {
+  __shared__ unsigned short tile[32][34];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    tile[ty + 8 * j][tx] = (r < R && c < C) ? in[(size_t)r * ldin + c] : (unsigned short)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (c < C && r < R) out[(size_t)c * ldout + r] = tile[tx][ty + 8 * j];
+  }
+}
+
+__global__ __launch_bounds__(256) void dmx_add_bf16_kernel(const bf16* a, int lda, const bf16* b, int ldb, bf16* o, int ldo, int rows, int C) {
+  const int c8 = C / 8;
+  const size_t total = (size_t)rows * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8) * 8; const size_t r = i / c8;
+    float x[8], y[8]; unpack_bf8(*(const u32x4*)(a + r * lda + c), x); unpack_bf8(*(const u32x4*)(b + r * ldb + c), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += y[e];
+    *(u32x4*)(o + r * ldo + c) = pack_bf8(x);
+  }
+}
+
+// loss = mean((p - t)^2) ; dp = 2 (p - t) / n * gscale.  Stage 1: per-block partial sums; stage 2: one block, fixed order.
+__global__ __launch_bounds__(256) void dmx_mse_part_kernel(const float* p, const float* t, float* dp, float* part, size_t n, float gs) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = p[i] - t[i];
+    s += d * d;
+    if (dp) dp[i] = d * gs;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void dmx_mse_final_kernel(const float* part, int nb, float* loss, float inv_n) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) *loss = red[0] * inv_n;
+}
+
+__device__ __forceinline__ float silu1(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dsilu1(float u) { const float s = 1.0f / (1.0f + __expf(-u)); return s * (1.0f + u * (1.0f - s)); }
+// y = W * act(x) + b  (act = SiLU when silu_in):  dW[n][k] (+)= sum_b dy[b][n] act(x[b][k]) ; db[n] (+)= sum_b dy[b][n]
+__global__ __launch_bounds__(256) void dmx_linear_small_bwd_w_kernel(const float* x, int ldx, const float* dy, int lddy, float* dw, int lddw,
+                                                                     float* db, int db_stride, int B, int N, int K, int silu_in, int accumulate) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (k < K) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) { const float v = x[(size_t)b * ldx + k]; s += dy[(size_t)b * lddy + n] * (silu_in ? silu1(v) : v); }
+    float* o = dw + (size_t)n * lddw + k;
+    *o = accumulate ? *o + s : s;
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dy[(size_t)b * lddy + n];
+    db[(size_t)n * db_stride] = accumulate ? db[(size_t)n * db_stride] + s : s;
+  }
+}
+// dx[b][k] = act'(x[b][k]) * sum_n dy[b][n] W[n][k]
+__global__ __launch_bounds__(256) void dmx_linear_small_bwd_x_kernel(const float* dy, int lddy, const bf16* w, int ldw, const float* x, int ldx,
+                                                                     float* dx, int lddx, int B, int N, int K, int silu_in) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dy[(size_t)b * lddy + n] * (float)w[(size_t)n * ldw + k];
+  if (silu_in) s *= dsilu1(x[(size_t)b * ldx + k]);
+  dx[(size_t)b * lddx + k] = s;
+}
+}  // namespace
+
+int dmx_transpose_bf16_launch(const bf16* in, int ldin, bf16* out, int ldout, int R, int C, hipStream_t stream) {
+  hipLaunchKernelGGL(dmx_transpose_bf16_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, stream,
+                     (const unsigned short*)in, ldin, (unsigned short*)out, ldout, R, C);
+  return dmx_check_launch("dmx_transpose_bf16_kernel");
+}
+int dmx_add_bf16_launch(const bf16* a, int lda, const bf16* b, int ldb, bf16* o, int ldo, int rows, int C, hipStream_t stream) {
+  DMX_REQUIRE(C % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "add_bf16: C %% 8");
+  const size_t total = (size_t)rows * (C / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dmx_add_bf16_kernel, dim3(blocks), dim3(256), 0, stream, a, lda, b, ldb, o, ldo, rows, C);
+  return dmx_check_launch("dmx_add_bf16_kernel");
+}
+size_t dmx_mse_workspace_bytes() { return 1024 * sizeof(float); }
+int dmx_mse_loss_launch(const float* pred, const float* target, size_t n, float* loss, float* dpred, float grad_scale,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  DMX_REQUIRE(pred && target && loss && n > 0, "mse_loss: null argument");
+  DMX_REQUIRE(workspace && workspace_bytes >= dmx_mse_workspace_bytes(), "mse_loss: workspace too small");
+  int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(dmx_mse_part_kernel, dim3(nb), dim3(256), 0, stream, pred, target, dpred, (float*)workspace, n, 2.0f * grad_scale / (float)n);
+  int rc = dmx_check_launch("dmx_mse_part_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dmx_mse_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, nb, loss, 1.0f / (float)n);
+  return dmx_check_launch("dmx_mse_final_kernel");
+}
+int dmx_linear_small_bwd_launch(const float* x, int ldx, const float* dy, int lddy, const bf16* w, int ldw,
+                                float* dw, int lddw, float* db, int db_stride, float* dx, int lddx,
+                                int B, int N, int K, int silu_in, int accumulate, hipStream_t stream) {
+  if (dw) {
+    hipLaunchKernelGGL(dmx_linear_small_bwd_w_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, stream, x, ldx, dy, lddy, dw, lddw, db, db_stride, B, N, K, silu_in, accumulate);
+    int rc = dmx_check_launch("dmx_linear_small_bwd_w_kernel");
+    if (rc) return rc;
+  }
+  if (dx) {
+    hipLaunchKernelGGL(dmx_linear_small_bwd_x_kernel, dim3(cdiv(K, 256), B), dim3(256), 0, stream, dy, lddy, w, ldw, x, ldx, dx, lddx, B, N, K, silu_in);
+    return dmx_check_launch("dmx_linear_small_bwd_x_kernel");
+  }
+  return DMX_OK;
+}

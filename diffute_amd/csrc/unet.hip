@@ -14,48 +14,7 @@
 //   - all 22 time_emb_proj Linear layers: one GEMV launch
 //   - cross-attention K / V^T of the glyph context computed once per image (set_context)
 #include <math.h>
-#include <map>
-#include <memory>
-#include <tuple>
-#include "exec.h"
-#include "../../include/diffute_hip.h"
-
-namespace {
-
-struct XfW {
-  int C = 0, heads = 0, ctx_slot = -1;
-  size_t ng, nb, wpi, bpi, l1g, l1b, l2g, l2b, l3g, l3b;
-  size_t wqkv, wo1, bo1, wq2, wkv2, wo2, bo2, wf1, bf1, wf2, bf2, wpo, bpo;
-  // folded LayerNorm: raw (as loaded) copies of the three LN-consuming weights + the derived c1 / c2 vectors
-  size_t wqkv_raw, wq2_raw, wf1_raw, c1_qkv, c2_qkv, c1_q2, c2_q2, c1_f1, c2_f1;
-};
-struct ConvW { size_t w, b; int c; };
-
-}  // namespace
-
-struct dmx_unet {
-  dmx_unet_config cfg;
-  ParamTable pt;
-  char* arena = nullptr;
-  int temb_dim = 0, tproj_total = 0;
-  size_t te_w1, te_b1, te_w2, te_b2, tp_w, tp_b, freq;
-  size_t ci_w, ci_b; int ci_kpad = 0;
-  size_t co_w, co_b, cno_g, cno_b;
-  std::vector<ResW> down_res[4], up_res[4]; std::vector<XfW> down_xf[4], up_xf[4];
-  ConvW down_ds[4], up_us[4];
-  ResW mid_res[2]; XfW mid_xf;
-  std::vector<XfW*> xf_all;          // cross-attention layers in graph order (context cache slots)
-  bool finalized = false;
-  // hipGraph cache: one captured UNet step per distinct argument tuple (pointers are baked into the nodes)
-  typedef std::tuple<const void*, const void*, const void*, const void*, const void*, const void*, const void*,
-                     int, int, int, int, int, int, int, int> GraphKey;
-  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
-  std::map<GraphKey, GraphEntry> graphs;
-  void drop_graphs() { for (auto& kv : graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); graphs.clear(); }
-  ~dmx_unet() { drop_graphs(); }
-
-  template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
-};
+#include "unet_model.h"
 
 namespace {
 
@@ -235,7 +194,7 @@ extern "C" int dmx_unet_finalize(dmx_unet* u, const float* h_freq, dmx_stream_t 
 }
 
 // ----------------------------------------------------------------------------- context
-static int ctx_pad(int ctx_len) { return (int)align_up((size_t)ctx_len, 64); }
+static int ctx_pad(int ctx_len) { return dmx_ctx_pad(ctx_len); }
 
 extern "C" size_t dmx_unet_context_bytes(const dmx_unet* u, int B, int ctx_len) {
   if (!u) return 0;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void dmx_wgrad_kernel(const WgradArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- store: acc[nb][4g+e] = dW[n = n0 + 64wn + 32nb + (lane&31)][k = k0 + 32wc + 8g + 4(lane>>5) + e]
-  float* out = p.out + (size_t)blockIdx.z * p.N * p.K;
+  float* out = p.out + (size_t)blockIdx.z * p.N * p.ldout;
   const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
@@ -155,21 +155,25 @@ __global__ __launch_bounds__(256, 2) void dmx_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 v = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
-      *(f32x4*)(out + (size_t)n * p.K + k0 + 32 * wc + 8 * g + 4 * lh) = v;
+      *(f32x4*)(out + (size_t)n * p.ldout + k0 + 32 * wc + 8 * g + 4 * lh) = v;
     }
   }
 }
 
-// out[i] (+)= sum_s partial[s][i], fixed order
-__global__ void dmx_sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n4, int splits, int accumulate) {
+// out[n][k] (+)= sum_s partial[s][n][k], fixed order; partials are compact [N][K], out has row stride ldo
+__global__ void dmx_sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int K, int ldo, int splits, int accumulate) {
+  const int k4 = K / 4;
+  const size_t n4 = (size_t)N * k4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 s = ((const f32x4*)part)[i];
     for (int k = 1; k < splits; ++k) {
       const f32x4 v = ((const f32x4*)part)[(size_t)k * n4 + i];
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
-    if (accumulate) { const f32x4 o = ((f32x4*)out)[i]; s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3]; }
-    ((f32x4*)out)[i] = s;
+    const size_t n = i / k4, c = (i - n * k4) * 4;
+    f32x4* o = (f32x4*)(out + n * ldo + c);
+    if (accumulate) { const f32x4 ov = *o; s[0] += ov[0]; s[1] += ov[1]; s[2] += ov[2]; s[3] += ov[3]; }
+    *o = s;
   }
 }
 
@@ -218,7 +222,7 @@ size_t dmx_wgrad_workspace_bytes(const WgradArgs& a) {
 
 int dmx_wgrad_launch(WgradArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   DMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "wgrad: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-  DMX_REQUIRE(a.K % BCW == 0 && a.N % 8 == 0 && a.lddy % 8 == 0 && a.ldx0 % 8 == 0, "wgrad: K %% 64, N %% 8 and leading dimensions %% 8 required (N=%d K=%d)", a.N, a.K);
+  DMX_REQUIRE(a.K % BCW == 0 && a.N % 8 == 0 && a.lddy % 8 == 0 && a.ldx0 % 8 == 0 && a.ldout % 4 == 0, "wgrad: K %% 64, N %% 8 and leading dimensions %% 8 required (N=%d K=%d)", a.N, a.K);
   if (!a.direct) DMX_REQUIRE(a.Cin % BCW == 0 && a.cx0 % BCW == 0 && a.K == a.ksize * a.ksize * a.Cin, "wgrad: conv channel splits must be multiples of 64 (Cin=%d cx0=%d)", a.Cin, a.cx0);
   else DMX_REQUIRE(a.cx0 % BCW == 0 || a.cx0 >= a.K, "wgrad: source split must be a multiple of 64");
   if (a.cx0 < (a.direct ? a.K : a.Cin)) DMX_REQUIRE(a.x1 != nullptr && a.ldx1 % 8 == 0, "wgrad: second source missing");
@@ -235,6 +239,8 @@ int dmx_wgrad_launch(WgradArgs a, void* workspace, size_t workspace_bytes, hipSt
     a.out = (float*)workspace;
   }
   a.splits = splits;
+  const int ld_final = a.ldout > 0 ? a.ldout : a.K;
+  a.ldout = need ? a.K : ld_final;
   a.rows_per_split = cdiv(cdiv(a.M, splits), MC) * MC;
   dim3 grid(cdiv(a.N, BNW), a.K / BCW, cdiv(a.M, a.rows_per_split));
   a.splits = grid.z;
@@ -249,7 +255,7 @@ int dmx_wgrad_launch(WgradArgs a, void* workspace, size_t workspace_bytes, hipSt
   if (need) {
     const size_t n4 = (size_t)a.N * a.K / 4;
     int blocks = (int)((n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dmx_sum_partials_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, final_out, n4, a.splits, a.accumulate);
+    hipLaunchKernelGGL(dmx_sum_partials_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, final_out, a.N, a.K, ld_final, a.splits, a.accumulate);
     rc = dmx_check_launch("dmx_sum_partials_kernel");
   }
   return rc;

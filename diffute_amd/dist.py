@@ -45,3 +45,72 @@ def whole_job_throughput(dist, elapsed_s, units_this_rank, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item()) / float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training: gradient exchange over the packed fp32 gradient arena.
+#
+# The backward (dmx_unet_train_backward) writes every parameter gradient into one flat fp32 arena and completes it in
+# 11 buckets (conv_out, up_blocks 3..0, mid, down_blocks 3..0, conv_in + time embedding), recording an event per bucket.
+# Each bucket is reduced on a side stream as soon as its event fires, so the exchange runs under the rest of the
+# backward; the ranges are contiguous slices of the arena (no flattening copies).  RCCL picks ring / direct algorithms
+# per message size over the xGMI links; the ranges skip the arena regions that hold derived (non-trainable) data.
+
+def merge_ranges(ranges, gap=0):
+    """Sorted union of [begin, end) ranges; ranges closer than `gap` are fused."""
+    out = []
+    for b, e in sorted(ranges):
+        if out and b <= out[-1][1] + gap:
+            out[-1][1] = max(out[-1][1], e)
+        else:
+            out.append([b, e])
+    return [(b, e) for b, e in out]
+
+
+def clip_ranges(ranges, lo, hi):
+    """Parts of the ranges that lie inside [lo, hi)."""
+    out = []
+    for b, e in ranges:
+        b2, e2 = max(b, lo), min(e, hi)
+        if b2 < e2:
+            out.append((b2, e2))
+    return out
+
+
+def plan_buckets(param_ranges, bucket_ranges, itemsize=4, gap=4096):
+    """param_ranges: byte ranges of the trainable gradients; bucket_ranges: list (in completion order) of lists of byte
+    ranges.  Returns, per bucket, the element ranges to all-reduce (merged, clipped, multiples of itemsize)."""
+    merged = merge_ranges(param_ranges, gap)
+    plan = []
+    for spans in bucket_ranges:
+        rs = []
+        for lo, hi in spans:
+            rs += clip_ranges(merged, lo, hi)
+        plan.append([(b // itemsize, (e + itemsize - 1) // itemsize) for b, e in rs])
+    return plan
+
+
+def reduce_buckets(flat, plan, dist, group=None, wait_bucket=None, average_by=None):
+    """All-reduce (sum) the planned ranges of the 1-D tensor `flat`, bucket by bucket in completion order;
+    wait_bucket(i) is called before bucket i is touched (GPU: make the side stream wait for the bucket's event)."""
+    for i, ranges in enumerate(plan):
+        if wait_bucket is not None:
+            wait_bucket(i)
+        for b, e in ranges:
+            v = flat[b:e]
+            dist.all_reduce(v, group=group)
+            if average_by:
+                v.div_(average_by)
+
+
+def broadcast_parameters(params, dist, src=0, group=None):
+    """D3 (accelerator.prepare, train_diffute_v1.py:780): every rank starts from rank `src`'s parameters."""
+    for p in params:
+        dist.broadcast(p.data, src=src, group=group)
+
+
+def gather_scalar(value, dist, world, device=None):
+    """D2 (accelerator.gather(loss.repeat(bs)).mean(), train_diffute_v1.py:921): mean of a per-rank scalar."""
+    t = torch.tensor([float(value)], dtype=torch.float32, device=device if device is not None else torch.device("cpu"))
+    dist.all_reduce(t)
+    return float(t.item()) / world

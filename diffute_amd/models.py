@@ -321,13 +321,120 @@ class UNet2DConditionModel(_HipModel):
                         _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_forward")
         return out
 
+    # ---- training (train_diffute_v1.py:913-925): forward that keeps activations + hand-written HIP backward
+    def _train_buffers(self):
+        """transposed-weights arena (data-gradient operands, refreshed when the weights change) and the fp32 gradient arena"""
+        lib = _cabi.lib()
+        tb = getattr(self, "_tb", None)
+        if tb is None or tb["wt"].device != self.device:
+            tb = self._tb = dict(wt=torch.empty(lib.dmx_unet_train_wt_bytes(self._h), dtype=torch.uint8, device=self.device),
+                                 grads=torch.empty(lib.dmx_unet_grad_bytes(self._h) // 4, dtype=torch.float32, device=self.device),
+                                 wt_sig=None, ws=None, events=None, plan=None)
+        if tb["wt_sig"] != self._packed_sig:
+            _cabi.check(lib.dmx_unet_train_prepare(self._h, _cabi.ptr(tb["wt"]), tb["wt"].numel(), _cabi.current_stream()), "unet_train_prepare")
+            tb["wt_sig"] = self._packed_sig
+        return tb
+
+    def set_gradient_sync(self, dist=None, group=None):
+        """Average gradients over the ranks of `dist` (torch.distributed; RCCL on GPUs) INSIDE the backward: each of the
+        11 gradient buckets is all-reduced on a side stream as soon as the backward has finished it.
+        dist=None switches the exchange off (single GPU, or a wrapping torch DDP does it)."""
+        self._sync = None if dist is None else dict(dist=dist, group=group, world=dist.get_world_size(group), stream=None)
+
+    def _sync_plan(self, tb):
+        if tb["plan"] is None:
+            from .dist import plan_buckets
+            lib = _cabi.lib()
+            b, e = ctypes.c_size_t(), ctypes.c_size_t()
+            prs = []
+            for k in self._keys:
+                _cabi.check(lib.dmx_unet_grad_range(self._h, k.encode(), ctypes.byref(b), ctypes.byref(e)), "grad_range")
+                prs.append((b.value, e.value))
+            nb = lib.dmx_unet_train_bucket_count(self._h)
+            spans = []
+            for i in range(nb):
+                _cabi.check(lib.dmx_unet_train_bucket_range(self._h, i, ctypes.byref(b), ctypes.byref(e)), "bucket_range")
+                spans.append([(b.value, e.value)])
+            _cabi.check(lib.dmx_unet_train_tail_range(self._h, ctypes.byref(b), ctypes.byref(e)), "tail_range")
+            spans[-1].append((b.value, e.value))
+            tb["plan"] = plan_buckets(prs, spans)
+        return tb["plan"]
+
+    def _train_forward(self, sample, timestep, ctx):
+        lib = _cabi.lib()
+        self._ensure_packed()
+        tb = self._train_buffers()
+        B, _, H, W = sample.shape
+        S = ctx.shape[1]
+        need = lib.dmx_unet_train_workspace_bytes(self._h, B, H, W, S)
+        if tb["ws"] is None or tb["ws"].numel() < need:
+            tb["ws"] = None
+            tb["ws"] = torch.empty(int(need), dtype=torch.uint8, device=sample.device)
+        pred = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=sample.device)
+        _cabi.check(lib.dmx_unet_train_forward(self._h, _cabi.ptr(tb["wt"]), _cabi.ptr(sample), sample.shape[1], None, 0, None, 0,
+                                               _cabi.ptr(timestep), timestep.numel(), _cabi.ptr(ctx), int(ctx.dtype == torch.bfloat16), S,
+                                               _cabi.ptr(pred), B, H, W, _cabi.ptr(tb["ws"]), tb["ws"].numel(), _cabi.current_stream()),
+                    "unet_train_forward")
+        tb["fwd_stream"] = torch.cuda.current_stream(sample.device)
+        return pred
+
+    def _train_backward(self, dpred):
+        """-> list of parameter gradients (torch layouts, fp32) in self._keys order"""
+        lib = _cabi.lib()
+        tb = self._tb
+        sync = getattr(self, "_sync", None)
+        if sync is not None:
+            dpred = dpred / sync["world"]                      # SUM over ranks below -> mean gradient
+        dpred = dpred.to(torch.float32).contiguous()
+        ev_arr, n_ev = None, 0
+        if sync is not None:
+            n_ev = lib.dmx_unet_train_bucket_count(self._h)
+            if tb["events"] is None:
+                tb["events"] = [torch.cuda.Event() for _ in range(n_ev)]
+                for ev in tb["events"]:
+                    ev.record()                                # materialise the hipEvent_t handles
+            ev_arr = (ctypes.c_void_p * n_ev)(*[ev.cuda_event for ev in tb["events"]])
+        with torch.cuda.stream(tb["fwd_stream"]):
+            _cabi.check(lib.dmx_unet_train_backward(self._h, _cabi.ptr(tb["grads"]), _cabi.ptr(dpred), ev_arr, n_ev, _cabi.current_stream()),
+                        "unet_train_backward")
+        if sync is not None:
+            from .dist import reduce_buckets
+            if sync["stream"] is None:
+                sync["stream"] = torch.cuda.Stream(device=dpred.device)
+            side = sync["stream"]
+            with torch.cuda.stream(side):
+                reduce_buckets(tb["grads"], self._sync_plan(tb), sync["dist"], group=sync["group"],
+                               wait_bucket=lambda i: side.wait_event(tb["events"][i]))
+            tb["fwd_stream"].wait_stream(side)
+        out = []
+        with torch.cuda.stream(tb["fwd_stream"]):
+            st = _cabi.current_stream()
+            for k, p in zip(self._keys, self._param_list()):
+                g = torch.empty(p.shape, dtype=torch.float32, device=dpred.device)
+                _cabi.check(lib.dmx_unet_grad_export(self._h, _cabi.ptr(tb["grads"]), k.encode(), _cabi.ptr(g), st), "grad_export")
+                out.append(g if p.dtype == torch.float32 else g.to(p.dtype))
+        torch.cuda.current_stream(dpred.device).wait_stream(tb["fwd_stream"])
+        return out
+
+    def _param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in self._keys]
+
     def forward(self, sample, timestep, encoder_hidden_states, return_dict=True, **unused):
         """unet(sample[B,9,h,w], timestep (int / 0-d / [B] tensor), encoder_hidden_states[B,S,1024])."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "diffute_amd: the HIP UNet is forward-only in this build (no backward kernels yet); "
-                "call it under torch.no_grad() / after requires_grad_(False)")
         _cabi.require_cuda(sample, encoder_hidden_states)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            B = sample.shape[0]
+            if not torch.is_tensor(timestep):
+                timestep = torch.tensor([int(timestep)], dtype=torch.int64)
+            t = timestep.reshape(-1).to(device=sample.device, dtype=torch.int64)
+            if t.numel() not in (1, B):
+                raise ValueError(f"timestep must have 1 or {B} elements, got {t.numel()}")
+            ctx = encoder_hidden_states if encoder_hidden_states.dtype in (torch.float32, torch.bfloat16) else encoder_hidden_states.float()
+            out = _UNetTrainFn.apply(self, sample.detach().to(torch.float32).contiguous(), t, ctx.detach().contiguous(), *self._param_list())
+            if self._dtype != torch.float32 and sample.dtype != torch.float32:
+                out = out.to(sample.dtype)
+            return UNet2DConditionOutput(sample=out) if return_dict else (out,)
         self._ensure_packed()
         key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
                encoder_hidden_states.dtype)
@@ -344,6 +451,48 @@ class UNet2DConditionModel(_HipModel):
         if self._dtype != torch.float32 and sample.dtype != torch.float32:
             out = out.to(sample.dtype)
         return UNet2DConditionOutput(sample=out) if return_dict else (out,)
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """Glue between torch autograd (loss.backward(), DDP hooks on the parameters) and the HIP training graph: the
+    parameters are inputs so that their .grad is filled by autograd from the gradients the HIP backward exports."""
+
+    @staticmethod
+    def forward(ctx, model, sample, t, ehs, *params):
+        ctx.model = model
+        return model._train_forward(sample, t, ehs)
+
+    @staticmethod
+    def backward(ctx, dpred):
+        grads = ctx.model._train_backward(dpred)
+        return (None, None, None, None) + tuple(grads)
+
+
+def mse_loss(pred, target):
+    """F.mse_loss(pred.float(), target.float(), reduction="mean") (train_diffute_v1.py:918) as a HIP kernel with its
+    gradient: two-stage fixed-order fp32 reduction."""
+    return _MSEFn.apply(pred, target)
+
+
+class _MSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        lib = _cabi.lib()
+        p = pred.detach().to(torch.float32).contiguous(); t = target.detach().to(torch.float32).contiguous()
+        _cabi.require_cuda(p, t)
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        dp = torch.empty_like(p)
+        ws = torch.empty(lib.dmx_mse_loss_workspace_bytes(), dtype=torch.uint8, device=p.device)
+        _cabi.check(lib.dmx_mse_loss(_cabi.ptr(p), _cabi.ptr(t), p.numel(), _cabi.ptr(loss), _cabi.ptr(dp), 1.0,
+                                     _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "mse_loss")
+        ctx.save_for_backward(dp)
+        ctx.in_dtype = pred.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return (dp * g).to(ctx.in_dtype), None
 
 
 class AutoencoderKL(_HipModel):

@@ -245,6 +245,34 @@ int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, const float* f1
                            const int64_t* timesteps, int t_count, const void* context_cache, int ctx_len,
                            float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Training of the denoiser: train_diffute_v1.py:913-925.
+ *   dmx_unet_train_prepare   W^T copies of every GEMM weight (data-gradient operands) into `wt`; after each weight update
+ *   dmx_unet_train_forward   pred = unet(cat(f0,f1,f2), t, ctx), keeping what the backward needs inside `workspace`
+ *   dmx_unet_train_backward  all parameter gradients (fp32, packed like the weights arena: the gradient of the element
+ *                            at arena byte offset o sits at byte offset 2*o of `grads`); records event i when gradient
+ *                            bucket i is final, so the gradient exchange (RCCL) can overlap the rest of the backward
+ *   dmx_unet_grad_export     one parameter's gradient in its torch layout
+ *   dmx_mse_loss             loss = mean((pred - target)^2) and dpred = 2 (pred - target) / n * grad_scale
+ * ---------------------------------------------------------------------------------- */
+size_t dmx_unet_train_workspace_bytes(dmx_unet* u, int B, int H, int W, int ctx_len);
+size_t dmx_unet_train_wt_bytes(const dmx_unet* u);
+int dmx_unet_train_prepare(dmx_unet* u, void* wt_arena, size_t wt_bytes, dmx_stream_t stream);
+size_t dmx_unet_grad_bytes(const dmx_unet* u);
+int dmx_unet_train_forward(dmx_unet* u, const void* wt_arena,
+                           const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                           const int64_t* timesteps, int t_count, const void* ctx, int ctx_is_bf16, int ctx_len,
+                           float* pred, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+int dmx_unet_train_bucket_count(const dmx_unet* u);
+int dmx_unet_train_bucket_range(const dmx_unet* u, int i, size_t* begin, size_t* end);
+int dmx_unet_train_tail_range(const dmx_unet* u, size_t* begin, size_t* end);
+int dmx_unet_train_backward(dmx_unet* u, void* grads, const float* dpred, void* const* events, int n_events, dmx_stream_t stream);
+int dmx_unet_grad_export(const dmx_unet* u, const void* grads, const char* name, float* dst, dmx_stream_t stream);
+int dmx_unet_grad_range(const dmx_unet* u, const char* name, size_t* begin, size_t* end);
+size_t dmx_mse_loss_workspace_bytes(void);
+int dmx_mse_loss(const float* pred, const float* target, size_t n, float* loss, float* dpred, float grad_scale,
+                 void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
 typedef struct dmx_vae_config {
   int in_channels, out_channels, latent_channels;
   int block_out_channels[4];

@@ -175,3 +175,74 @@ def test_full_size_properties(cuda):
     unet.set_context(ctx[2:3].contiguous())
     y1 = unet.forward_parts([lat[2:3].contiguous(), mask[2:3].contiguous(), mlat[2:3].contiguous()], t)
     assert rel_l2(y1, y[2:3]) < 2e-2        # different split-K / tile choices at B=1 change rounding only
+
+
+# ------------------------------------------------------------------------------------------------ training (P5 / P6)
+def _oracle_train_grads(model, cfg_oracle, x, t, ctx, target, emulate_bf16=False):
+    """loss and parameter gradients of the oracle (torch autograd on the CPU restatement; with emulate_bf16 the forward
+    rounds where the HIP path materialises bf16, the backward stays fp32 - casts are straight-through)"""
+    from oracle import unet as OU
+    P = {k: v.detach().cpu().float().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    with torch.enable_grad():
+        pred = OU.unet_forward.__wrapped__(P, cfg_oracle, x.cpu(), t.cpu(), ctx.cpu(), emulate_bf16=emulate_bf16)
+        loss = torch.mean((pred.float() - target.cpu().float()) ** 2)
+        loss.backward()
+    return float(loss.detach()), pred.detach(), {k: p.grad for k, p in P.items()}
+
+
+def test_tiny_unet_train_step(cuda):
+    """P5/P6: one training step of the tiny UNet through the product classes (HIP forward that keeps activations, HIP
+    MSE loss, hand-written HIP backward) vs torch autograd on the oracle.  Tolerances (bf16 activations AND bf16
+    activation gradients against an fp32 backward): loss within 2 %, the whole gradient vector within 4e-2 rel-L2 of the
+    fp32 oracle and of the bf16-emulating oracle (measured 2.5e-2 / 2.4e-2), no single parameter worse than 1e-1 (5e-2)."""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from diffute_amd.synthetic import synth_inputs
+    from oracle import unet as OU
+    model = D.UNet2DConditionModel(**TINY_UNET).cuda()
+    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1)
+    t = torch.tensor([981, 17], device=cuda)
+    g = torch.Generator().manual_seed(11)
+    target = torch.randn(2, 4, 16, 16, generator=g).to(cuda)
+    pred = model(x, t, ctx).sample
+    loss = mse_loss(pred, target)
+    loss.backward()
+    for em in (False, True):
+        ref_loss, ref_pred, ref_g = _oracle_train_grads(model, OU.TINY_UNET, x, t, ctx, target, emulate_bf16=em)
+        assert_close(pred.detach(), ref_pred, 5e-2, "train forward vs oracle")
+        assert abs(float(loss) - ref_loss) <= 2e-2 * abs(ref_loss), f"loss {float(loss)} vs oracle {ref_loss}"
+        errs = []
+        num = den = 0.0
+        for k, p in model.named_parameters():
+            assert p.grad is not None, f"no gradient for {k}"
+            gh = p.grad.detach().float().cpu(); gr = ref_g[k]
+            assert torch.isfinite(gh).all(), f"{k}: non-finite gradient"
+            errs.append((rel_l2(gh, gr), k))
+            num += float((gh - gr).pow(2).sum()); den += float(gr.pow(2).sum())
+        tot = (num / den) ** 0.5
+        errs.sort(reverse=True)
+        print(f"tiny train step vs {'bf16-emulating' if em else 'fp32'} oracle: loss {float(loss):.6f} (oracle {ref_loss:.6f}); "
+              f"whole-gradient rel-L2 {tot:.2e}; median {errs[len(errs) // 2][0]:.2e}; worst: " + ", ".join(f"{k} {e:.2e}" for e, k in errs[:4]))
+        assert tot <= 4e-2, f"whole-gradient rel-L2 {tot:.3e}"
+        assert errs[0][0] <= 1e-1, f"gradient of {errs[0][1]}: rel-L2 {errs[0][0]:.3e}"
+
+
+def test_train_step_deterministic_and_accumulates(cuda):
+    """the backward has no atomics: two identical steps give bit-identical gradients; a second backward accumulates into .grad"""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from diffute_amd.synthetic import synth_inputs
+    model = D.UNet2DConditionModel(**TINY_UNET).cuda()
+    lat, mask, mlat, ctx = synth_inputs(1, 8, 8, 20, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1); t = torch.tensor([500], device=cuda); target = torch.zeros(1, 4, 8, 8, device=cuda)
+    def grads():
+        model.zero_grad(set_to_none=True)
+        mse_loss(model(x, t, ctx).sample, target).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}
+    a = grads(); b = grads()
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: gradients differ between identical steps"
+    mse_loss(model(x, t, ctx).sample, target).backward()          # accumulate on top of b
+    k = "mid_block.resnets.0.conv1.weight"
+    assert torch.allclose(dict(model.named_parameters())[k].grad, 2 * a[k], rtol=1e-6, atol=0)
