@@ -1,0 +1,60 @@
+"""The DiffUTE training step (train_diffute_v1.py:859-935) on the product classes.
+
+    latents / masked latents  : frozen VAE encode -> latent_dist.sample() * scaling_factor      (:875-887)
+    mask                      : nearest downsample to the latent grid                             (:880-884)
+    noisy latents             : scheduler.add_noise(latents, noise, timesteps)                    (:889-897)
+    prediction                : unet(cat([noisy, mask, masked_latents], 1), timesteps, ocr_embeddings).sample   (:911-913)
+    loss                      : mse_loss(pred.float(), target.float())                            (:918)
+    backward / clip / AdamW   : loss.backward(); clip_grad_norm_(unet.parameters(), 1.0); optimizer.step()   (:925-930)
+
+Every FLOP of the models runs in the HIP library; torch provides the optimizer arithmetic on the fp32 master
+parameters (the fused multi-tensor AdamW is SURVEY.md 8f N3, not built yet) and the autograd plumbing.  With
+`dist` set, gradients are averaged across ranks inside the backward (bucketed RCCL all-reduce of the packed gradient
+arena on a side stream, UNet2DConditionModel.set_gradient_sync)."""
+import torch
+
+from .models import mse_loss
+from .pipeline import mask_to_latent
+
+
+def encode_latents(vae, images, noise=None, generator=None):
+    """vae.encode(x).latent_dist.sample() * scaling_factor, no gradient (the VAE is frozen, train_diffute_v1.py:639)."""
+    with torch.no_grad():
+        dist = vae.encode(images).latent_dist
+        z = dist.sample(noise=noise) if noise is not None else dist.sample(generator=generator)
+        return z * vae.config.scaling_factor
+
+
+def training_target(scheduler, latents, noise, timesteps):
+    pt = scheduler.config.prediction_type
+    if pt == "epsilon":
+        return noise
+    if pt == "v_prediction":
+        return scheduler.get_velocity(latents, noise, timesteps)
+    raise ValueError(f"Unknown prediction type {pt}")                      # train_diffute_v1.py:909
+
+
+def train_step(unet, vae, scheduler, optimizer, batch, *, noise=None, timesteps=None, enc_noise=None, enc_noise_masked=None,
+               max_grad_norm=1.0, generator=None):
+    """One optimizer step.  batch: dict with pixel_values [B,3,H,W], masked_images [B,3,H,W], masks [B,1,H,W] and
+    ocr_embeddings [B,S,1024] (the frozen TrOCR encoder's output, train_diffute_v1.py:868-871).  The random draws can be
+    injected (tests); otherwise they come from torch's device RNG like the reference.  Returns loss / grad_norm tensors."""
+    pv = batch["pixel_values"]
+    latents = encode_latents(vae, pv, enc_noise, generator)
+    masked_latents = encode_latents(vae, batch["masked_images"], enc_noise_masked, generator)
+    factor = 2 ** (len(vae.config.block_out_channels) - 1)
+    mask = mask_to_latent(batch["masks"], factor).to(latents.dtype)
+    B = latents.shape[0]
+    if noise is None:
+        noise = torch.randn(latents.shape, device=latents.device, dtype=latents.dtype, generator=generator)
+    if timesteps is None:
+        timesteps = torch.randint(0, scheduler.num_train_timesteps, (B,), device=latents.device, generator=generator).long()
+    noisy = scheduler.add_noise(latents, noise, timesteps)
+    target = training_target(scheduler, latents, noise, timesteps)
+    pred = unet(torch.cat([noisy, mask, masked_latents], dim=1), timesteps, batch["ocr_embeddings"]).sample
+    loss = mse_loss(pred.float(), target.float())
+    loss.backward()
+    grad_norm = torch.nn.utils.clip_grad_norm_(unet.parameters(), max_grad_norm) if max_grad_norm else None
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return dict(loss=loss.detach(), grad_norm=grad_norm)

@@ -45,3 +45,60 @@ def test_shard_range_properties():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---------------------------------------------------------------------------------------------- training exchange (D1-D3)
+def test_bucket_planning():
+    from diffute_amd.dist import clip_ranges, merge_ranges, plan_buckets
+    assert merge_ranges([(40, 48), (0, 16), (16, 24), (100, 120)]) == [(0, 24), (40, 48), (100, 120)]
+    assert merge_ranges([(0, 16), (20, 32)], gap=8) == [(0, 32)]
+    assert clip_ranges([(0, 24), (40, 48)], 8, 44) == [(8, 24), (40, 44)]
+    # two buckets in completion order (the second one first in memory), a derived (non-trainable) hole at [64, 128)
+    params = [(0, 64), (128, 192), (192, 200), (512, 600)]
+    plan = plan_buckets(params, [[(256, 1024)], [(0, 256)]], itemsize=4, gap=0)
+    assert plan == [[(128, 150)], [(0, 16), (32, 50)]]
+    assert plan_buckets(params, [[(0, 1024)]], itemsize=4, gap=64) == [[(0, 50), (128, 150)]]
+
+
+def _train_sync_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from diffute_amd import dist as D
+    dist = D.init_from_env("gloo")
+    # a fake gradient arena: trainable ranges get rank-dependent values, the holes a sentinel that must survive
+    n = 4096
+    flat = torch.full((n,), -7.0)
+    params = [(0, 1000 * 4), (1500 * 4, 3000 * 4), (3500 * 4, 4096 * 4)]
+    for b, e in params:
+        flat[b // 4:e // 4] = torch.arange(b // 4, e // 4, dtype=torch.float32) * (rank + 1)
+    buckets = [[(2048 * 4, 4096 * 4)], [(0, 2048 * 4)]]                 # completion order: back half first
+    plan = D.plan_buckets(params, buckets, gap=0)
+    order = []
+    D.reduce_buckets(flat, plan, dist, wait_bucket=order.append, average_by=world)
+    w = [torch.ones(3) * (rank + 5)]
+    D.broadcast_parameters(w, dist, src=0)
+    mean_loss = D.gather_scalar(float(rank + 1), dist, world)
+    q.put((rank, flat.clone(), order, w[0].clone(), mean_loss))
+    D.barrier_sync(dist)
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_all_reduce_gloo_world2():
+    """D1/D2/D3 with gloo, world_size 2: bucket by bucket in completion order, only the trainable ranges are touched,
+    the result is the mean over ranks and identical on every rank; parameters broadcast from rank 0; scalar loss mean."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_train_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    idx = torch.arange(4096, dtype=torch.float32)
+    want = torch.full((4096,), -7.0)
+    for b, e in [(0, 1000), (1500, 3000), (3500, 4096)]:
+        want[b:e] = idx[b:e] * (1 + 2) / 2.0                             # mean of rank-scaled values
+    for rank, flat, order, w, mean_loss in res:
+        assert torch.equal(flat, want), f"rank {rank}: reduced arena differs"
+        assert order == [0, 1]
+        assert torch.equal(w, torch.ones(3) * 5)
+        assert abs(mean_loss - 1.5) < 1e-6
