@@ -62,3 +62,16 @@ def train_forward(Pu, ucfg, Pv, vcfg, pixel_values, masked_images, masks, ctx, t
         raise ValueError(f"Unknown prediction type {prediction_type}")
     pred = unet_forward(Pu, ucfg, torch.cat([noisy, m, mlat], dim=1), timesteps, ctx)
     return torch.mean((pred.float() - target.float()) ** 2), pred
+
+
+def unet_train_grads(P, cfg, inp, timesteps, ctx, target, emulate_bf16=False):
+    """Loss and parameter gradients of one denoiser training step (train_diffute_v1.py:913-925:
+    `model_pred = unet(...).sample; loss = F.mse_loss(model_pred.float(), target.float()); accelerator.backward(loss)`),
+    by torch autograd over the restatement.  With emulate_bf16 the forward rounds where the HIP path materialises bf16
+    (the casts are straight-through), the backward arithmetic stays fp32.  Returns (loss, pred, {name: grad})."""
+    Pg = {k: v.detach().clone().to(torch.float32).requires_grad_(True) for k, v in P.items()}
+    with torch.enable_grad():
+        pred = unet_forward.__wrapped__(Pg, cfg, inp, timesteps, ctx, emulate_bf16=emulate_bf16)
+        loss = torch.mean((pred.float() - target.float()) ** 2)
+        loss.backward()
+    return float(loss.detach()), pred.detach(), {k: p.grad for k, p in Pg.items()}

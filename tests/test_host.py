@@ -172,3 +172,30 @@ def test_flops_formula_matches_oracle():
     u_cfg = D.models._Config(**{**D.SD2_INPAINT_UNET_CONFIG})
     assert unet_flops(u_cfg, 4, 64, 64, 577, True) == OU.unet_flops(OU.SD2_INPAINT_UNET, 4, 64, 64, 577, True)
     assert abs(unet_flops(u_cfg, 1, 64, 64, 577, False) / 1e12 - 0.853) < 0.002
+
+
+def test_oracle_training_step_matches_golden():
+    """P5/P6 oracle (autograd over the restatement) against the committed fixture: loss, global gradient norm, the L2
+    norm of every parameter gradient and a dozen gradients in full (regenerated from the same seeds)."""
+    import os
+    import numpy as np
+    import torch
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    from make_golden import TRAIN_KEYS, synth_inputs
+    from oracle import pipeline as OP, prng, unet as OU
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_train.npz"))
+    cfg = OU.TINY_UNET
+    P = OU.make_params(OU.unet_param_spec(cfg), seed=1234)
+    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, cfg["cross_attention_dim"])
+    inp = torch.cat([lat, mask, mlat], 1)
+    tgt = torch.from_numpy(prng.normal(9, 41, 2 * 4 * 16 * 16).reshape(2, 4, 16, 16))
+    loss, pred, grads = OP.unet_train_grads(P, cfg, inp, torch.tensor([981, 17]), ctx, tgt)
+    assert abs(loss - float(g["loss_fp32"])) <= 1e-5 * abs(loss)
+    assert np.allclose(pred.numpy(), g["pred_fp32"], rtol=1e-4, atol=1e-5)
+    assert str(g["names"]).split("\n") == list(grads.keys())
+    norms = np.array([float(v.double().pow(2).sum().sqrt()) for v in grads.values()])
+    assert np.allclose(norms, g["gnorms_fp32"], rtol=1e-3)
+    for k in TRAIN_KEYS:
+        ref = g["g_fp32_" + k]
+        assert np.linalg.norm(grads[k].numpy() - ref) <= 1e-3 * np.linalg.norm(ref), k
