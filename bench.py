@@ -38,7 +38,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-csv", default="", help="write one row per kernel launch of the profiled pass")
+    ap.add_argument("--mode", choices=("denoise", "train"), default="denoise",
+                    help="denoise = BASELINE configs[1] (the headline metric); train = configs[3] DDP training step (scripts/bench_train.py)")
     args = ap.parse_args()
+    if args.mode == "train":                  # same launcher contract (torchrun env), per-GPU batch 8 at 512 px
+        import runpy
+        sys.argv = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "bench_train.py"),
+                    "--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--batch", str(args.batch)] if args.batch != 4 else [])
+        runpy.run_path(sys.argv[0], run_name="__main__")
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))

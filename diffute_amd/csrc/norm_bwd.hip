@@ -7,7 +7,7 @@
 //   dbeta_c = sum du ; dgamma_c = sum du*xhat  (over batch and pixels)
 //   dx      = rstd_g * (du*gamma_c - m1_g - xhat*m2_g),  m1 = mean_g(du*gamma), m2 = mean_g(du*gamma*xhat)
 //   reduce   : grid (nchunk, B)   per-channel partial (sum du, sum du*xhat) of a row chunk  -> part[b][chunk][C][2]
-//   finalize : grid (C/256)       AB[b][c] = sum over chunks ; dgamma/dbeta (+)= sum over b
+//   finalize : grid (C/256, B)    AB[b][c] = sum over chunks ;  params: dgamma/dbeta (+)= sum over b
 //   apply    : grid (rows, B)     prologue folds AB into m1/m2 per group, then streams rows and writes dx (two-source
 //                                 concat splits into dx0 | dx1; an optional residual gradient is added)
 #include "common.h"
@@ -75,17 +75,19 @@ __global__ __launch_bounds__(1024) void dmx_gn_bwd_reduce_kernel(const GroupNorm
   }
 }
 
-__global__ __launch_bounds__(256) void dmx_gn_bwd_finalize_kernel(const GroupNormBwdArgs p) {
+__global__ __launch_bounds__(256) void dmx_gn_bwd_finalize_kernel(const GroupNormBwdArgs p) {      // grid (C/256, B)
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= p.C) return;
+  float a = 0.f, q = 0.f;
+  const float* pp = p.part + (size_t)b * p.nchunk * p.C * 2 + 2 * c;
+  for (int j = 0; j < p.nchunk; ++j) { a += pp[(size_t)j * p.C * 2]; q += pp[(size_t)j * p.C * 2 + 1]; }
+  p.ab[((size_t)b * p.C + c) * 2] = a; p.ab[((size_t)b * p.C + c) * 2 + 1] = q;
+}
+__global__ __launch_bounds__(256) void dmx_gn_bwd_params_kernel(const GroupNormBwdArgs p) {        // grid (C/256)
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= p.C) return;
   float dg = 0.f, db = 0.f;
-  for (int b = 0; b < p.B; ++b) {
-    float a = 0.f, q = 0.f;
-    const float* pp = p.part + (size_t)b * p.nchunk * p.C * 2 + 2 * c;
-    for (int j = 0; j < p.nchunk; ++j) { a += pp[(size_t)j * p.C * 2]; q += pp[(size_t)j * p.C * 2 + 1]; }
-    p.ab[((size_t)b * p.C + c) * 2] = a; p.ab[((size_t)b * p.C + c) * 2 + 1] = q;
-    db += a; dg += q;
-  }
+  for (int b = 0; b < p.B; ++b) { db += p.ab[((size_t)b * p.C + c) * 2]; dg += p.ab[((size_t)b * p.C + c) * 2 + 1]; }
   if (p.dgamma) p.dgamma[c] = p.accumulate ? p.dgamma[c] + dg : dg;
   if (p.dbeta) p.dbeta[c] = p.accumulate ? p.dbeta[c] + db : db;
 }
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(1024) void dmx_gn_bwd_apply_kernel(const GroupNormB
 //   dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)).
 // Each block walks LNB_ROWS rows per wave and keeps per-lane column partials of dgamma (dy*xhat) / dbeta (dy) in
 // registers; the 4 waves are folded through LDS -> part[block][C][2]; a second kernel sums the blocks in order.
-#define LNB_ROWS 16
+#define LNB_ROWS 4
 __global__ __launch_bounds__(256) void dmx_ln_bwd_kernel(const bf16* x, int ldx, const bf16* dy, int lddy, const float* gamma,
                                                          bf16* dx, int lddx, const bf16* res, int ldres,
                                                          float* part, int rows, int C, float eps) {
@@ -238,11 +240,22 @@ __global__ __launch_bounds__(256) void dmx_ln_bwd_kernel(const bf16* x, int ldx,
   float* o = part + (size_t)blockIdx.x * C * 2;
   for (int c = threadIdx.x; c < 2 * C; c += 256) o[c] = (sm[c] + sm[2 * C + c]) + (sm[4 * C + c] + sm[6 * C + c]);
 }
-__global__ __launch_bounds__(256) void dmx_ln_bwd_params_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta, int accumulate) {
+// part[nblk][C][2] -> dgamma / dbeta, two fixed-order levels (LNP_SLICES partial sums in parallel, then their sum)
+#define LNP_SLICES 32
+__global__ __launch_bounds__(256) void dmx_ln_bwd_params1_kernel(const float* part, int nblk, int C2, float* part2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, sl = blockIdx.y;
+  if (c >= C2) return;
+  const int per = (nblk + LNP_SLICES - 1) / LNP_SLICES;
+  const int j0 = sl * per, j1 = min(j0 + per, nblk);
+  float s = 0.f;
+  for (int j = j0; j < j1; ++j) s += part[(size_t)j * C2 + c];
+  part2[(size_t)sl * C2 + c] = s;
+}
+__global__ __launch_bounds__(256) void dmx_ln_bwd_params2_kernel(const float* part2, int C, float* dgamma, float* dbeta, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float g = 0.f, b = 0.f;
-  for (int j = 0; j < nblk; ++j) { g += part[((size_t)j * C + c) * 2]; b += part[((size_t)j * C + c) * 2 + 1]; }
+  for (int j = 0; j < LNP_SLICES; ++j) { g += part2[((size_t)j * C + c) * 2]; b += part2[((size_t)j * C + c) * 2 + 1]; }
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
@@ -311,8 +324,11 @@ int dmx_groupnorm_bwd_launch(GroupNormBwdArgs a, hipStream_t stream) {
   hipLaunchKernelGGL(dmx_gn_bwd_reduce_kernel, dim3(nchunk, a.B), dim3(threads), lds, stream, a);
   int rc = dmx_check_launch("dmx_gn_bwd_reduce_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(dmx_gn_bwd_finalize_kernel, dim3(cdiv(a.C, 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(dmx_gn_bwd_finalize_kernel, dim3(cdiv(a.C, 256), a.B), dim3(256), 0, stream, a);
   rc = dmx_check_launch("dmx_gn_bwd_finalize_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dmx_gn_bwd_params_kernel, dim3(cdiv(a.C, 256)), dim3(256), 0, stream, a);
+  rc = dmx_check_launch("dmx_gn_bwd_params_kernel");
   if (rc) return rc;
   int rpb = 8 * R;
   while (rpb > R && (long)cdiv(a.HW, rpb) * a.B < 512) rpb -= R;
@@ -320,7 +336,7 @@ int dmx_groupnorm_bwd_launch(GroupNormBwdArgs a, hipStream_t stream) {
   return dmx_check_launch("dmx_gn_bwd_apply_kernel");
 }
 
-size_t dmx_ln_bwd_workspace_bytes(int rows, int C) { return (size_t)cdiv(rows, 4 * LNB_ROWS) * C * 2 * sizeof(float); }
+size_t dmx_ln_bwd_workspace_bytes(int rows, int C) { return ((size_t)cdiv(rows, 4 * LNB_ROWS) + LNP_SLICES) * C * 2 * sizeof(float); }
 int dmx_layernorm_bwd_launch(const bf16* x, int ldx, const bf16* dy, int lddy, const float* gamma, bf16* dx, int lddx,
                              const bf16* res, int ldres, float* dgamma, float* dbeta, int accumulate,
                              int rows, int C, float eps, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -333,8 +349,12 @@ int dmx_layernorm_bwd_launch(const bf16* x, int ldx, const bf16* dy, int lddy, c
                      (float*)workspace, rows, C, eps);
   int rc = dmx_check_launch("dmx_ln_bwd_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(dmx_ln_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)workspace, nblk, C, dgamma, dbeta, accumulate);
-  return dmx_check_launch("dmx_ln_bwd_params_kernel");
+  float* part2 = (float*)workspace + (size_t)nblk * C * 2;
+  hipLaunchKernelGGL(dmx_ln_bwd_params1_kernel, dim3(cdiv(2 * C, 256), LNP_SLICES), dim3(256), 0, stream, (const float*)workspace, nblk, 2 * C, part2);
+  rc = dmx_check_launch("dmx_ln_bwd_params1_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dmx_ln_bwd_params2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)part2, C, dgamma, dbeta, accumulate);
+  return dmx_check_launch("dmx_ln_bwd_params2_kernel");
 }
 
 int dmx_geglu_fwd_launch(const bf16* h, int ldh, bf16* y, int ldy, int rows, int C2, int packed, hipStream_t stream) {

@@ -179,21 +179,38 @@ __global__ void dmx_sum_partials_kernel(const float* __restrict__ part, float* _
 
 // Column sums of dY (bias gradient; per-image groups give the time-embedding row-bias gradient), two deterministic
 // levels: partial[g*cpg + j][n] over CR-row chunks (256 threads = 4 row phases x 64 columns), then a fixed-order sum.
-constexpr int CR = 128;
+constexpr int CR = 256;
 __global__ __launch_bounds__(256) void dmx_colsum_part_kernel(const bf16* __restrict__ dy, int lddy, int rows_per_group, int cpg, int N,
                                                               float* __restrict__ part) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  // 256 threads = 32 row lanes x 8 column octets (64 columns, 16-byte loads); fixed-order fold through LDS
+  __shared__ float red[32][65];
+  const int oc = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 64 + oc * 8;
   const int grp = blockIdx.y / cpg, j = blockIdx.y - grp * cpg;
   const int r0 = j * CR, r1 = min(r0 + CR, rows_per_group);
-  float s = 0.f;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
   if (c < N) {
     const bf16* base = dy + (size_t)grp * rows_per_group * lddy + c;
-    for (int r = r0 + ph; r < r1; r += 4) s += (float)base[(size_t)r * lddy];
+    for (int r = r0 + rl; r < r1; r += 32) {
+      float f[8]; unpack_bf8(*(const u32x4*)(base + (size_t)r * lddy), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
   }
-  red[ph][threadIdx.x & 63] = s;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][oc * 8 + e] = s[e];
   __syncthreads();
-  if (ph == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) v += red[k][threadIdx.x];
+      part[(size_t)blockIdx.y * N + cc] = v;
+    }
+  }
 }
 __global__ void dmx_colsum_final_kernel(const float* __restrict__ part, int cpg, int N, float* __restrict__ out, int ldo, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x, grp = blockIdx.y;
@@ -268,6 +285,7 @@ size_t dmx_colsum_ws_bytes(int groups, int rows_per_group, int N) {
 int dmx_colsum_launch(const bf16* dy, int lddy, int groups, int rows_per_group, int N, float* out, int ldo, int accumulate,
                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
   DMX_REQUIRE(groups > 0 && rows_per_group > 0 && N > 0, "colsum: empty problem");
+  DMX_REQUIRE(N % 8 == 0 && lddy % 8 == 0, "colsum: N=%d and lddy=%d must be multiples of 8", N, lddy);
   const int cpg = cdiv(rows_per_group, CR);
   const size_t need = dmx_colsum_ws_bytes(groups, rows_per_group, N);
   if (workspace == nullptr || workspace_bytes < need) {
