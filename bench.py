@@ -22,8 +22,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROF_CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128", "wgrad"]
+# rocprofv3 names of the GEMM template instances (dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP>)
+KERNEL_NAMES = {"gemm_128x128": "void dmx_gemm_kernel<2, 2, 32, 4, 2, 0>(GemmArgs)", "gemm_128x64": "void dmx_gemm_kernel<2, 1, 32, 4, 2, 0>(GemmArgs)",
+                "gemm_256x128": "void dmx_gemm_kernel<4, 2, 64, 3, 2, 0>(GemmArgs)", "gemm_256x128_ws": "void dmx_gemm_kernel<2, 2, 64, 3, 4, 4>(GemmArgs)"}
+PROF_CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128", "wgrad", "gemm_256x128_ws"]
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def pmc_traffic(kernel_name):
+    """bytes per launch of `kernel_name` from the committed PMC summary (scripts/rocprof_to_profiles.py), or None"""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.csv")
+    if not os.path.exists(path):
+        return None
+    for r in csv.DictReader(open(path)):
+        if r["kernel"] == kernel_name:
+            return float(r["traffic_bytes_per_launch"])
+    return None
 
 
 def main():
@@ -121,11 +136,11 @@ def main():
         n, ms, fl, by = buf[4 * PROF_CLASSES.index(dom):4 * PROF_CLASSES.index(dom) + 4]
         ach = fl / (ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                              "kernel": {"gemm_128x128": "dmx_gemm_kernel<2,2,32>", "gemm_128x64": "dmx_gemm_kernel<2,1,32>", "gemm_256x128": "dmx_gemm_kernel<4,2,64>"}[dom],
+                              "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom]),
+                              "kernel": KERNEL_NAMES[dom],
                               "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
-                              "note": "hipEvent-bracketed launches over one 50-step pass; traffic (PMC) in profiles/"}
+                              "note": "hipEvent-bracketed launches over one 50-step pass; traffic = HBM bytes per launch of this kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed in profiles/r01_pmc_traffic.csv (FETCH x2 per the gfx950 note), null if absent"}
         result["kernel_classes"] = classes
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -15,7 +15,7 @@ from diffute_amd import _cabi                            # noqa: E402
 from diffute_amd.models import mse_loss                  # noqa: E402
 from diffute_amd.synthetic import synth_inputs           # noqa: E402
 
-CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128", "wgrad"]
+CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128", "wgrad", "gemm_256x128_ws"]
 
 
 def main():

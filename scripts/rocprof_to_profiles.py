@@ -1,0 +1,51 @@
+"""rocprofv3 output directories -> the summaries committed under profiles/.
+
+    python scripts/rocprof_to_profiles.py <stats_dir> <fetch_dir> <write_dir> <out_prefix>     e.g. profiles/r01
+
+  <stats_dir>  rocprofv3 --kernel-trace --stats            -> <out_prefix>_kernel_stats.csv (copied as is)
+  <fetch_dir>  rocprofv3 --pmc FETCH_SIZE  (own pass)      \\
+  <write_dir>  rocprofv3 --pmc WRITE_SIZE  (own pass)      /-> <out_prefix>_pmc_traffic.csv: per kernel, per launch
+Counter units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are in KiB; FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is taken as is."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+
+def per_kernel(dirname, counter):
+    f = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)[0]
+    tot = collections.defaultdict(float); n = collections.defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        tot[name] += float(r["Counter_Value"]); n[name] += 1
+    return tot, n
+
+
+def main(stats_dir, fetch_dir, write_dir, out):
+    src = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(src, out + "_kernel_stats.csv")
+    ft, fn = per_kernel(fetch_dir, "FETCH_SIZE")
+    wt, wn = per_kernel(write_dir, "WRITE_SIZE")
+    rows = []
+    for k in ft:
+        if not k.startswith(("void dmx_", "dmx_")):
+            continue
+        f_kb = ft[k] / fn[k]
+        w_kb = wt.get(k, 0.0) / max(wn.get(k, 0), 1)
+        rows.append((k, fn[k], f_kb, 2 * f_kb * 1024, w_kb, 2 * f_kb * 1024 + w_kb * 1024))
+    rows.sort(key=lambda r: -r[1] * r[5])
+    with open(out + "_pmc_traffic.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "FETCH_SIZE_KB_per_launch_raw", "FETCH_bytes_per_launch_corrected_x2", "WRITE_SIZE_KB_per_launch", "traffic_bytes_per_launch"])
+        for r in rows:
+            w.writerow([r[0], r[1], f"{r[2]:.1f}", f"{r[3]:.0f}", f"{r[4]:.1f}", f"{r[5]:.0f}"])
+    print(f"{len(rows)} kernels -> {out}_pmc_traffic.csv, {out}_kernel_stats.csv")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
