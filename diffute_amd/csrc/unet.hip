@@ -233,10 +233,10 @@ extern "C" int dmx_unet_set_context(dmx_unet* u, const void* ctx, int ctx_is_bf1
 namespace {
 
 struct Fwd {
-  dmx_unet* u; Exec& ex; int B; const float* tproj; const void* cache; int ctx_len;
+  dmx_unet* u; Exec& ex; int B; const float* tproj; int tp_ld; const void* cache; int ctx_len;
 
   Tn resnet(const ResW& r, const Tn& x0, const Tn* x1) {
-    return resnet_run(ex, u->arena, r, x0, x1, u->cfg.norm_num_groups, 1e-5f, tproj, u->tproj_total);
+    return resnet_run(ex, u->arena, r, x0, x1, u->cfg.norm_num_groups, 1e-5f, tproj, tp_ld);
   }
 
   Tn xformer(const XfW& w, const Tn& x) {
@@ -283,16 +283,19 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
              const long long* timesteps, int t_count, const void* cache, int ctx_len, float* out, int B, int H, int W) {
   const dmx_unet_config& cfg = u->cfg;
   const int* boc = cfg.block_out_channels; const int L = cfg.layers_per_block; const int temb = u->temb_dim;
-  // ---- time embedding (fp32, bf16 weights)
-  float* sinus = (float*)ex.raw((size_t)B * boc[0] * 4);
+  // ---- time embedding (fp32, bf16 weights).  A scalar timestep (the denoise loop) is embedded once and every image reads
+  // row 0 of the projections (row stride 0); per-sample timesteps (training) get one row each.
+  const int Bt = (t_count == 1) ? 1 : B;
+  const int tp_ld = (t_count == 1) ? 0 : u->tproj_total;
+  float* sinus = (float*)ex.raw((size_t)B * boc[0] * 4);              // sized for B rows either way (workspace query)
   float* e1 = (float*)ex.raw((size_t)B * temb * 4);
   float* emb = (float*)ex.raw((size_t)B * temb * 4);
   float* tproj = (float*)ex.raw((size_t)B * u->tproj_total * 4);
   if (!ex.dry && !ex.rc) {
-    ex.rc = dmx_timestep_embedding_launch(timesteps, t_count, u->at<float>(u->freq), B, boc[0], sinus, ex.stream);
-    if (!ex.rc) ex.rc = dmx_linear_small_launch(sinus, boc[0], u->at<bf16>(u->te_w1), boc[0], u->at<float>(u->te_b1), e1, temb, B, temb, boc[0], 0, ex.stream);
-    if (!ex.rc) ex.rc = dmx_linear_small_launch(e1, temb, u->at<bf16>(u->te_w2), temb, u->at<float>(u->te_b2), emb, temb, B, temb, temb, 1, ex.stream);
-    if (!ex.rc) ex.rc = dmx_linear_small_launch(emb, temb, u->at<bf16>(u->tp_w), temb, u->at<float>(u->tp_b), tproj, u->tproj_total, B, u->tproj_total, temb, 1, ex.stream);
+    ex.rc = dmx_timestep_embedding_launch(timesteps, t_count, u->at<float>(u->freq), Bt, boc[0], sinus, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(sinus, boc[0], u->at<bf16>(u->te_w1), boc[0], u->at<float>(u->te_b1), e1, temb, Bt, temb, boc[0], 0, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(e1, temb, u->at<bf16>(u->te_w2), temb, u->at<float>(u->te_b2), emb, temb, Bt, temb, temb, 1, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(emb, temb, u->at<bf16>(u->tp_w), temb, u->at<float>(u->tp_b), tproj, u->tproj_total, Bt, u->tproj_total, temb, 1, ex.stream);
   }
   ex.drop(sinus); ex.drop(e1); ex.drop(emb);
   // ---- conv_in: cat + layout + im2col, then GEMM
@@ -304,7 +307,7 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
   }
   Tn h = ex.linear(col, u->at<bf16>(u->ci_w), boc[0], u->at<float>(u->ci_b), nullptr, false);
   ex.drop(col);
-  Fwd f{u, ex, B, tproj, cache, ctx_len};
+  Fwd f{u, ex, B, tproj, tp_ld, cache, ctx_len};
   std::vector<Tn> skips; skips.push_back(h);
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L; ++j) {
