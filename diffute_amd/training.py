@@ -40,8 +40,10 @@ def train_step(unet, vae, scheduler, optimizer, batch, *, noise=None, timesteps=
     ocr_embeddings [B,S,1024] (the frozen TrOCR encoder's output, train_diffute_v1.py:868-871).  The random draws can be
     injected (tests); otherwise they come from torch's device RNG like the reference.  Returns loss / grad_norm tensors."""
     pv = batch["pixel_values"]
-    latents = encode_latents(vae, pv, enc_noise, generator)
-    masked_latents = encode_latents(vae, batch["masked_images"], enc_noise_masked, generator)
+    # both frozen-VAE encodes (train_diffute_v1.py:875,886) as one batch of 2B images: same arithmetic per image, half the launches
+    nz = None if enc_noise is None else torch.cat([enc_noise, enc_noise_masked], 0)
+    both = encode_latents(vae, torch.cat([pv, batch["masked_images"]], 0), nz, generator)
+    latents, masked_latents = both[:pv.shape[0]].contiguous(), both[pv.shape[0]:].contiguous()
     factor = 2 ** (len(vae.config.block_out_channels) - 1)
     mask = mask_to_latent(batch["masks"], factor).to(latents.dtype)
     B = latents.shape[0]
