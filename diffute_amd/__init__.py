@@ -8,8 +8,9 @@ from .models import (AutoencoderKL, UNet2DConditionModel, DiagonalGaussianDistri
                      SD2_INPAINT_UNET_CONFIG, SD_VAE_CONFIG)
 from .schedulers import DDIMScheduler, DDPMScheduler, SD2_SCHEDULER_CONFIG
 from .pipeline import denoise, edit_latents, mask_to_latent
+from .optim import FusedAdamW
 
 __all__ = ["AutoencoderKL", "UNet2DConditionModel", "DDPMScheduler", "DDIMScheduler", "denoise", "edit_latents",
-           "mask_to_latent", "DiagonalGaussianDistribution", "SD2_INPAINT_UNET_CONFIG", "SD_VAE_CONFIG",
+           "mask_to_latent", "FusedAdamW", "DiagonalGaussianDistribution", "SD2_INPAINT_UNET_CONFIG", "SD_VAE_CONFIG",
            "SD2_SCHEDULER_CONFIG"]
 __version__ = "0.1.0"

@@ -166,11 +166,9 @@ extern "C" int dmx_unet_load_param(dmx_unet* u, const char* name, const float* s
   return u->pt.load(u->arena, name, src, (hipStream_t)stream);
 }
 
-extern "C" int dmx_unet_finalize(dmx_unet* u, const float* h_freq, dmx_stream_t stream) {
-  DMX_REQUIRE(u && u->arena, "unet_finalize: arena not bound");
-  DMX_REQUIRE(h_freq != nullptr, "unet_finalize: null frequency table");
-  hipStream_t s = (hipStream_t)stream;
-  DMX_HIP(hipMemcpyAsync(u->arena + u->freq, h_freq, (size_t)(u->cfg.block_out_channels[0] / 2) * 4, hipMemcpyHostToDevice, s));
+// Recompute everything derived from the raw weights in the arena (folded shortcut biases, LayerNorm-folded GEMM
+// weights and their c1 / c2 vectors) after the raw weights changed in place (fused optimizer); asynchronous.
+static int refresh_derived(dmx_unet* u, hipStream_t s) {
   auto fuse = [&](const ResW& r) -> int { return resnet_finalize(r, u->arena, s); };
   int rc = 0;
   for (int i = 0; i < 4 && !rc; ++i) { for (auto& r : u->down_res[i]) if (!rc) rc = fuse(r); for (auto& r : u->up_res[i]) if (!rc) rc = fuse(r); }
@@ -185,6 +183,20 @@ extern "C" int dmx_unet_finalize(dmx_unet* u, const float* h_freq, dmx_stream_t 
     if (!rc) rc = dmx_ln_fold_launch(u->at<bf16>(x->wf1_raw), u->at<bf16>(x->wf1), u->at<float>(x->l3g), u->at<float>(x->l3b), u->at<float>(x->bf1),
                                      u->at<float>(x->c1_f1), u->at<float>(x->c2_f1), 8 * C, C, s);
   }
+  return rc;
+}
+extern "C" int dmx_unet_refresh_derived(dmx_unet* u, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->arena && u->finalized, "unet_refresh_derived: weights not finalized");
+  u->drop_graphs();
+  return refresh_derived(u, (hipStream_t)stream);
+}
+
+extern "C" int dmx_unet_finalize(dmx_unet* u, const float* h_freq, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->arena, "unet_finalize: arena not bound");
+  DMX_REQUIRE(h_freq != nullptr, "unet_finalize: null frequency table");
+  hipStream_t s = (hipStream_t)stream;
+  DMX_HIP(hipMemcpyAsync(u->arena + u->freq, h_freq, (size_t)(u->cfg.block_out_channels[0] / 2) * 4, hipMemcpyHostToDevice, s));
+  int rc = refresh_derived(u, s);
   DMX_HIP(hipStreamSynchronize(s));
   const bf16* zp = nullptr;
   if (!rc) rc = dmx_zero_page(&zp);                  // allocate the padding page now, never inside a stream capture

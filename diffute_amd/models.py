@@ -165,6 +165,8 @@ class _HipModel(nn.Module):
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("diffute_amd: model parameters must be on the GPU (call .cuda()); there is no CPU path")
+        if getattr(self, "_fused", None) is not None and self._arena is not None:
+            return                                   # a fused optimizer updates the arena in place; the arena is authoritative
         sig = self._signature()
         if self._packed_sig == sig and self._arena is not None:
             return
@@ -188,6 +190,12 @@ class _HipModel(nn.Module):
             self._ws = None
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def state_dict(self, *args, **kwargs):
+        f = getattr(self, "_fused", None)
+        if f is not None:
+            f.sync_to_model()
+        return super().state_dict(*args, **kwargs)
 
     # ---- (de)serialisation in the diffusers directory layout (train_diffute_v1.py:664-690)
     def save_pretrained(self, save_directory):
@@ -330,9 +338,10 @@ class UNet2DConditionModel(_HipModel):
             tb = self._tb = dict(wt=torch.empty(lib.dmx_unet_train_wt_bytes(self._h), dtype=torch.uint8, device=self.device),
                                  grads=torch.empty(lib.dmx_unet_grad_bytes(self._h) // 4, dtype=torch.float32, device=self.device),
                                  wt_sig=None, ws=None, events=None, plan=None)
-        if tb["wt_sig"] != self._packed_sig:
+        sig = (self._packed_sig, getattr(self, "_arena_version", 0))
+        if tb["wt_sig"] != sig:
             _cabi.check(lib.dmx_unet_train_prepare(self._h, _cabi.ptr(tb["wt"]), tb["wt"].numel(), _cabi.current_stream()), "unet_train_prepare")
-            tb["wt_sig"] = self._packed_sig
+            tb["wt_sig"] = sig
         return tb
 
     def set_gradient_sync(self, dist=None, group=None):
@@ -406,6 +415,9 @@ class UNet2DConditionModel(_HipModel):
                 reduce_buckets(tb["grads"], self._sync_plan(tb), sync["dist"], group=sync["group"],
                                wait_bucket=lambda i: side.wait_event(tb["events"][i]))
             tb["fwd_stream"].wait_stream(side)
+        if getattr(self, "_fused", None) is not None:      # the fused optimizer reads the gradient arena directly
+            torch.cuda.current_stream(dpred.device).wait_stream(tb["fwd_stream"])
+            return [None] * len(self._keys)
         out = []
         with torch.cuda.stream(tb["fwd_stream"]):
             st = _cabi.current_stream()

@@ -1,0 +1,76 @@
+"""Fused AdamW + global-norm gradient clipping on the packed fp32 arenas of the HIP UNet.
+
+Reference: `torch.optim.AdamW(unet.parameters(), lr, betas, weight_decay, eps)` (train_diffute_v1.py:721-727),
+`accelerator.clip_grad_norm_(unet.parameters(), args.max_grad_norm)` + `optimizer.step()` (:927-930).  Same arithmetic
+(torch's single-tensor AdamW formulas, fp32), but one pass over the gradient arena the HIP backward already filled:
+no per-parameter gradient export, no 686-tensor optimizer loop, no re-pack of the weights (the kernel writes the bf16 /
+fp32 compute copies in place).  The torch Parameters are refreshed from the master arena on demand (`sync_to_model`,
+done automatically by `state_dict()` / `save_pretrained()`)."""
+import ctypes
+
+import torch
+
+from . import _cabi
+
+
+class FusedAdamW:
+    def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0):
+        self.unet = unet
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = float(lr), tuple(betas), float(eps), float(weight_decay), float(max_grad_norm or 0.0)
+        self.t = 0
+        lib = _cabi.lib()
+        unet._ensure_packed()
+        dev = unet.device
+        n = lib.dmx_unet_grad_bytes(unet._h) // 4
+        self.masters = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        st = _cabi.current_stream()
+        for k, p in zip(unet._keys, unet._param_list()):
+            src = p.detach().to(torch.float32).contiguous()
+            _cabi.check(lib.dmx_unet_master_import(unet._h, _cabi.ptr(self.masters), k.encode(), _cabi.ptr(src), st), f"master_import({k})")
+        self.nchunks = lib.dmx_unet_optim_chunks(unet._h)
+        self.table = torch.empty(lib.dmx_unet_optim_table_bytes(unet._h), dtype=torch.uint8, device=dev)
+        _cabi.check(lib.dmx_unet_optim_table(unet._h, _cabi.ptr(self.table), self.table.numel(), st), "optim_table")
+        self.scalars = torch.zeros(2, dtype=torch.float32, device=dev)          # (|g| before clipping, clip coefficient)
+        self.ws = torch.empty(self.nchunks, dtype=torch.float32, device=dev)
+        self.dirty = False
+        unet._fused = self                      # the backward stops exporting per-parameter gradients; the arena is authoritative
+
+    @property
+    def grad_norm(self):
+        return self.scalars[0]
+
+    def zero_grad(self, set_to_none=True):
+        """the backward overwrites the gradient arena; nothing to clear"""
+
+    def step(self):
+        lib = _cabi.lib()
+        u = self.unet
+        tb = u._tb
+        self.t += 1
+        st = _cabi.current_stream()
+        _cabi.check(lib.dmx_unet_adamw_step(u._h, _cabi.ptr(self.table), self.nchunks, _cabi.ptr(self.masters), _cabi.ptr(self.exp_avg),
+                                            _cabi.ptr(self.exp_avg_sq), _cabi.ptr(tb["grads"]), self.lr, self.betas[0], self.betas[1], self.eps,
+                                            self.weight_decay, self.t, self.max_grad_norm, _cabi.ptr(self.scalars),
+                                            _cabi.ptr(self.ws), self.ws.numel() * 4, st), "adamw_step")
+        _cabi.check(lib.dmx_unet_refresh_derived(u._h, st), "refresh_derived")
+        u._arena_version = getattr(u, "_arena_version", 0) + 1      # transposed weights are refreshed by the next training forward
+        for sl in u._slots.values():
+            sl["ctx_key"] = None                                     # cached context K/V were projected with the old weights
+        self.dirty = True
+
+    def sync_to_model(self):
+        """master arena -> the torch Parameters (fp32, torch layouts)"""
+        if not self.dirty:
+            return
+        lib = _cabi.lib()
+        u = self.unet
+        st = _cabi.current_stream()
+        with torch.no_grad():
+            for k, p in zip(u._keys, u._param_list()):
+                dst = p.data if (p.dtype == torch.float32 and p.is_contiguous()) else torch.empty(p.shape, dtype=torch.float32, device=p.device)
+                _cabi.check(lib.dmx_unet_grad_export(u._h, _cabi.ptr(self.masters), k.encode(), _cabi.ptr(dst), st), "master_export")
+                if dst is not p.data:
+                    p.data.copy_(dst)
+        self.dirty = False

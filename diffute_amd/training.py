@@ -56,7 +56,11 @@ def train_step(unet, vae, scheduler, optimizer, batch, *, noise=None, timesteps=
     pred = unet(torch.cat([noisy, mask, masked_latents], dim=1), timesteps, batch["ocr_embeddings"]).sample
     loss = mse_loss(pred.float(), target.float())
     loss.backward()
-    grad_norm = torch.nn.utils.clip_grad_norm_(unet.parameters(), max_grad_norm) if max_grad_norm else None
-    optimizer.step()
-    optimizer.zero_grad(set_to_none=True)
+    if hasattr(optimizer, "masters"):                 # diffute_amd.optim.FusedAdamW: clipping and the update are one HIP pass
+        optimizer.step()
+        grad_norm = optimizer.grad_norm
+    else:
+        grad_norm = torch.nn.utils.clip_grad_norm_(unet.parameters(), max_grad_norm) if max_grad_norm else None
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
     return dict(loss=loss.detach(), grad_norm=grad_norm)

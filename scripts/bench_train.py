@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet / VAE (plumbing check)")
+    ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW on exported gradients instead of the fused HIP optimizer")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -38,7 +39,10 @@ def main():
     if dist is not None:
         DD.broadcast_parameters(list(unet.parameters()), dist)                      # D3
         unet.set_gradient_sync(dist)                                               # D1
-    opt = torch.optim.AdamW(unet.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)   # train_diffute_v1.py:190-194
+    if a.torch_adamw:
+        opt = torch.optim.AdamW(unet.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)   # train_diffute_v1.py:190-194
+    else:
+        opt = D.FusedAdamW(unet, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0)
     g = torch.Generator(device=dev).manual_seed(5 + rank)
     B, px = a.batch, a.px
     ctx_dim = unet.config.cross_attention_dim
@@ -62,7 +66,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "DDP training images/sec (forward + backward + exchange + AdamW)", "value": round(thr, 3), "unit": "images/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 2),
-                          "per_gpu_batch": B, "px": px, "dtype": "bf16", "data": "synthetic", "loss_last": float(losses[-1]),
+                          "optimizer": "torch.optim.AdamW" if a.torch_adamw else "FusedAdamW (HIP)", "per_gpu_batch": B, "px": px, "dtype": "bf16", "data": "synthetic", "loss_last": float(losses[-1]),
                           "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}))
 
 

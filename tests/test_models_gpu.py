@@ -332,3 +332,38 @@ def test_cfg1_full_train_step_golden(cuda):
     assert_close(sd["conv_in.weight"].grad, torch.from_numpy(g["g_conv_in"]), 8e-2, "grad conv_in.weight")
     assert_close(sd["mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight"].grad[:64], torch.from_numpy(g["g_mid_to_q"]), 8e-2, "grad mid to_q")
     assert_close(sd["up_blocks.3.resnets.2.norm2.weight"].grad, torch.from_numpy(g["g_up3_norm2"]), 8e-2, "grad up3 norm2")
+
+
+def test_fused_adamw_matches_torch(cuda):
+    """N3: two steps of the fused HIP AdamW (+ global-norm clipping) against torch.optim.AdamW + clip_grad_norm_ fed with
+    the SAME gradients (exported from the HIP backward): the first update agrees to fp32 rounding (same loss, same norm), the second within the
+    noise of a few flipped bf16 roundings; the bf16 compute copies follow (next forward changes identically), state_dict() returns the updated masters."""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from diffute_amd.synthetic import synth_inputs
+    lat, mask, mlat, ctx = synth_inputs(1, 8, 8, 20, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1); t = torch.tensor([500], device=cuda); target = torch.zeros(1, 4, 8, 8, device=cuda)
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ref = D.UNet2DConditionModel(**TINY_UNET).cuda()
+    opt_ref = torch.optim.AdamW(ref.parameters(), **hp)
+    fus = D.UNet2DConditionModel(**TINY_UNET).cuda()
+    opt_fus = D.FusedAdamW(fus, max_grad_norm=0.05, **hp)
+    for step in range(2):
+        l_ref = mse_loss(ref(x, t, ctx).sample, target); l_ref.backward()
+        gn_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+        opt_ref.step(); opt_ref.zero_grad(set_to_none=True)
+        l_fus = mse_loss(fus(x, t, ctx).sample, target); l_fus.backward()
+        opt_fus.step()
+        # step 0: identical weights -> identical loss; later the fp32 masters agree to ~1e-7, which flips a few bf16 roundings
+        assert abs(float(l_ref.detach()) - float(l_fus.detach())) <= (1e-6 if step == 0 else 2e-4) * abs(float(l_ref.detach())), f"step {step}: losses diverged"
+        assert abs(float(gn_ref) - float(opt_fus.grad_norm)) <= (1e-5 if step == 0 else 2e-3) * float(gn_ref)
+        if step == 0:
+            # identical weights and (deterministic) gradients went in: the updated masters must agree to fp32 rounding.
+            # (Later steps cannot be compared element-wise: Adam moves every element by ~lr whatever its gradient's size,
+            # so elements with noise-level gradients follow the sign of bf16 rounding noise.)
+            sd_ref = {k: v.clone() for k, v in ref.state_dict().items()}; sd_fus = fus.state_dict()
+            worst = max(float((sd_ref[k] - sd_fus[k]).abs().max() / (sd_ref[k].abs().max() + 1e-12)) for k in sd_ref)
+            assert worst <= 2e-6, f"parameters after one step differ: max deviation relative to the tensor's max {worst:.2e}"
+    with torch.no_grad():                       # inference path (folded LayerNorm copies refreshed) agrees as well
+        a = ref.requires_grad_(False)(x, t, ctx).sample; b = fus.requires_grad_(False)(x, t, ctx).sample
+    assert_close(b, a.cpu(), 2e-2, "forward after fused optimizer steps")
