@@ -4,13 +4,13 @@ Public names mirror what train_diffute_v1.py / app.ipynb import from diffusers
 (`AutoencoderKL, DDPMScheduler, UNet2DConditionModel`, train_diffute_v1.py:51) so the scripts can
 switch with `from diffute_amd import ...`.
 """
-from .models import (AutoencoderKL, UNet2DConditionModel, DiagonalGaussianDistribution,
-                     SD2_INPAINT_UNET_CONFIG, SD_VAE_CONFIG)
+from .models import (AutoencoderKL, UNet2DConditionModel, DiagonalGaussianDistribution, TrOCREncoder,
+                     SD2_INPAINT_UNET_CONFIG, SD_VAE_CONFIG, TROCR_LARGE_VIT_CONFIG)
 from .schedulers import DDIMScheduler, DDPMScheduler, SD2_SCHEDULER_CONFIG
 from .pipeline import denoise, edit_latents, mask_to_latent
 from .optim import FusedAdamW
 
 __all__ = ["AutoencoderKL", "UNet2DConditionModel", "DDPMScheduler", "DDIMScheduler", "denoise", "edit_latents",
-           "mask_to_latent", "FusedAdamW", "DiagonalGaussianDistribution", "SD2_INPAINT_UNET_CONFIG", "SD_VAE_CONFIG",
+           "mask_to_latent", "FusedAdamW", "TrOCREncoder", "TROCR_LARGE_VIT_CONFIG", "DiagonalGaussianDistribution", "SD2_INPAINT_UNET_CONFIG", "SD_VAE_CONFIG",
            "SD2_SCHEDULER_CONFIG"]
 __version__ = "0.1.0"

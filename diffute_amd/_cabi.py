@@ -21,8 +21,13 @@ class GemmDesc(ctypes.Structure):
         ("w", c_void_p), ("ldw", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
         ("bias", c_void_p), ("rowbias", c_void_p), ("rows_per_group", c_int), ("ldrb", c_int),
         ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("geglu", c_int),
-        ("force_tn", c_int), ("force_splitk", c_int), ("group_m", c_int), ("timing", c_void_p), ("dbg", c_int),
+        ("force_tn", c_int), ("force_splitk", c_int), ("group_m", c_int), ("timing", c_void_p), ("dbg", c_int), ("act", c_int),
     ]
+
+
+class ViTConfig(ctypes.Structure):
+    _fields_ = [("image_size", c_int), ("patch_size", c_int), ("num_channels", c_int), ("hidden_size", c_int), ("num_layers", c_int),
+                ("num_heads", c_int), ("intermediate_size", c_int), ("qkv_bias", c_int), ("layer_norm_eps", c_float)]
 
 
 class UNetConfig(ctypes.Structure):
@@ -82,6 +87,16 @@ _PROTOS = {
     "dmx_sched_add_noise": (c_int, [_P, _P, _P, _P, _P, c_int, c_size_t, _P]),
     "dmx_sched_get_velocity": (c_int, [_P, _P, _P, _P, _P, c_int, c_size_t, _P]),
     "dmx_gaussian_sample": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "dmx_vit_create": (_P, [POINTER(ViTConfig)]),
+    "dmx_vit_destroy": (None, [_P]),
+    "dmx_vit_param_count": (c_int, [_P]),
+    "dmx_vit_param_info": (c_int, [_P, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
+    "dmx_vit_arena_bytes": (c_size_t, [_P]),
+    "dmx_vit_bind_arena": (c_int, [_P, _P, c_size_t]),
+    "dmx_vit_load_param": (c_int, [_P, c_char_p, _P, _P]),
+    "dmx_vit_finalize": (c_int, [_P, _P]),
+    "dmx_vit_workspace_bytes": (c_size_t, [_P, c_int]),
+    "dmx_vit_forward": (c_int, [_P, _P, _P, c_int, _P, c_size_t, _P]),
     "dmx_unet_create": (_P, [POINTER(UNetConfig)]),
     "dmx_unet_destroy": (None, [_P]),
     "dmx_unet_param_count": (c_int, [_P]),

@@ -18,7 +18,7 @@ static GemmArgs to_args(const dmx_gemm_desc* d) {
   a.w = (const bf16*)d->w; a.ldw = d->ldw; a.M = d->M; a.N = d->N; a.K = d->K;
   a.bias = d->bias; a.rowbias = d->rowbias; a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1; a.ldrb = d->ldrb;
   a.res = (const bf16*)d->res; a.ldres = d->ldres; a.out = d->out; a.ldo = d->ldo; a.out_f32 = d->out_f32; a.geglu = d->geglu;
-  a.force_tn = d->force_tn; a.force_splitk = d->force_splitk; a.group_m = d->group_m; a.timing = d->timing; a.dbg = d->dbg;
+  a.force_tn = d->force_tn; a.force_splitk = d->force_splitk; a.group_m = d->group_m; a.timing = d->timing; a.dbg = d->dbg; a.act = d->act;
   return a;
 }
 extern "C" size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d) { return d ? dmx_gemm_workspace_bytes(to_args(d)) : 0; }

@@ -119,6 +119,8 @@ class Exec {
   struct RowStats { float* buf = nullptr; int tiles = 0; };
   Tn linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu,
             RowStats* rowstats = nullptr, const LnIn* ln = nullptr);
+  // y = gelu(x W^T + b), exact erf GELU in the GEMM epilogue (ViT MLP)
+  Tn linear_gelu(const Tn& x, const bf16* w, int N, const float* bias);
   // generic gemm on raw pointers (swapped-role V^T projection etc.)
   void gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N, int K, const float* bias,
                 void* out, int ldo, int out_f32);

@@ -212,6 +212,19 @@ void Exec::gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N
   run_gemm(a);
 }
 
+Tn Exec::linear_gelu(const Tn& x, const bf16* w, int N, const float* bias) {
+  Tn y = make(x.B, x.H, x.W, N);
+  GemmArgs a{};
+  a.x0 = x.p; a.x1 = x.p; a.ldx0 = x.ld; a.ldx1 = x.ld; a.cx0 = x.C; a.Cin = x.C;
+  a.direct = 1; a.ksize = 1; a.stride = 1; a.IH = a.OH = x.H; a.IW = a.OW = x.W;
+  a.Ktaps = x.C; a.K = x.C;
+  a.w = w; a.ldw = x.C; a.M = x.rows(); a.N = N;
+  a.bias = bias; a.rows_per_group = 1;
+  a.out = y.p; a.ldo = N; a.act = 1;
+  run_gemm(a);
+  return y;
+}
+
 Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps) {
   Tn y = make(x.B, x.H, x.W, x.C);
   if (!dry && !rc) {

@@ -560,6 +560,10 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bs[e]; v[4 + e] = v1[e] + bs[4 + e]; }
           }
+          if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+          }
           if (p.res) {
             float rf[8]; unpack_bf8(rv[k], rf);
 #pragma unroll
@@ -703,7 +707,7 @@ static double plan_cost(const GemmArgs& a, int c, int sk) {
 void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_out) {
   int best_c = 0, best_sk = 1; double best = 1e300;
   if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
-    const bool no_split = a.rowstats_out || a.ln_stats || a.geglu;
+    const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == a.ups &&
           !(a.geglu && (tp.cfg == 1 || tp.cfg == 3)) && !(no_split && tp.sk > 1)) {
@@ -728,7 +732,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     if (!a.force_tn && c != 1 && c != 3 && a.N <= 64) continue;
     if (!a.force_tn && (c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
     const int nkt = a.K / T.bk;
-    const int max_sk = (a.geglu || (a.N % 4) != 0 || a.rowstats_out || a.ln_stats) ? 1 : 16;   // those epilogues live in the GEMM kernel
+    const int max_sk = (a.geglu || a.act || (a.N % 4) != 0 || a.rowstats_out || a.ln_stats) ? 1 : 16;   // those epilogues live in the GEMM kernel
     for (int sk = 1; sk <= max_sk; ++sk) {
       if (a.force_splitk && sk != a.force_splitk) continue;
       if (sk > 1 && nkt / sk < (T.bk == 64 ? 4 : 8)) break;
@@ -777,6 +781,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   if (a.Ktaps < a.K) DMX_REQUIRE(a.s0 != nullptr && a.cs0 % 32 == 0, "gemm: shortcut segment needs s0 and aligned cs0");
   if (a.ln_stats) DMX_REQUIRE(a.ln_c1 && a.ln_c2 && a.ln_tiles > 0 && a.ln_C > 0 && !a.out_f32 && a.N % 8 == 0 && a.ldo % 8 == 0, "gemm: folded LayerNorm needs c1/c2, bf16 output and N %% 8 == 0");
   if (a.rowstats_out) DMX_REQUIRE(!a.out_f32 && a.N % 8 == 0 && a.ldo % 8 == 0 && !a.geglu, "gemm: row statistics need the bf16 coalesced epilogue");
+  if (a.act) DMX_REQUIRE(a.act == 1 && !a.out_f32 && !a.geglu && a.N % 8 == 0 && a.ldo % 8 == 0 && (a.res == nullptr || a.ldres % 8 == 0), "gemm: the GELU epilogue needs the bf16 coalesced path (N %% 8 == 0)");
   if (a.geglu) DMX_REQUIRE((a.bias || a.ln_stats) && a.N % 128 == 0 && !a.out_f32 && !a.res && !a.rowbias && a.ldo % 8 == 0, "gemm: GEGLU needs bias, N%%128==0, bf16 out");
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;

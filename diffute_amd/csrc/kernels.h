@@ -32,6 +32,7 @@ struct GemmArgs {
   int rows_per_group, ldrb;
   const bf16* res; int ldres;   // residual or null
   void* out; int ldo; int out_f32; int geglu;
+  int act;                                     // 1: exact (erf) GELU after the bias, before the residual (ViT MLP); bf16 coalesced epilogue only
   int force_tn, force_splitk;                  // 0 = automatic
   int group_m;                                 // m-tiles per rasterisation super-tile (0 = default 8)
   // folded LayerNorm: a producer GEMM emits per-row partial (sum, sumsq) of its rounded output, the consumer GEMM

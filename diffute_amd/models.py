@@ -583,3 +583,81 @@ class AutoencoderKL(_HipModel):
         z = post.sample(generator=generator) if sample_posterior else post.mode()
         dec = self.decode(z).sample
         return {"sample": dec} if return_dict else (dec,)
+
+
+TROCR_LARGE_VIT_CONFIG = dict(image_size=384, patch_size=16, num_channels=3, hidden_size=1024, num_hidden_layers=24,
+                              num_attention_heads=16, intermediate_size=4096, qkv_bias=False, layer_norm_eps=1e-12, hidden_act="gelu")
+
+
+class BaseModelOutput(SimpleNamespace):
+    """`.last_hidden_state` (app.ipynb:776, train_diffute_v1.py:871)."""
+
+
+class TrOCREncoder(_HipModel):
+    """The glyph encoder: ViT encoder of TrOCR (reference: `trocr_model = VisionEncoderDecoderModel.from_pretrained(
+    'microsoft/trocr-large-printed').encoder`, train_diffute_v1.py:630-631, app.ipynb:546-548;
+    `trocr_model(pixel_values).last_hidden_state`, :868-871 / :773-776).  Forward-only (frozen in the reference, :638)."""
+    _kind = "vit"
+
+    def __init__(self, seed=777, device="cpu", **config):
+        super().__init__()
+        cfg = dict(TROCR_LARGE_VIT_CONFIG); cfg.update(config)
+        if cfg.get("hidden_act", "gelu") != "gelu":
+            raise ValueError("TrOCREncoder: only the exact GELU activation is implemented")
+        self.config = _Config(**cfg)
+        c = _cabi.ViTConfig()
+        c.image_size = cfg["image_size"]; c.patch_size = cfg["patch_size"]; c.num_channels = cfg["num_channels"]
+        c.hidden_size = cfg["hidden_size"]; c.num_layers = cfg["num_hidden_layers"]; c.num_heads = cfg["num_attention_heads"]
+        c.intermediate_size = cfg["intermediate_size"]; c.qkv_bias = int(bool(cfg["qkv_bias"])); c.layer_norm_eps = float(cfg["layer_norm_eps"])
+        h = _cabi.lib().dmx_vit_create(ctypes.byref(c))
+        if not h:
+            raise ValueError("TrOCREncoder: " + _cabi.lib().dmx_last_error().decode())
+        self._setup(h, seed, device)
+        self.requires_grad_(False)
+
+    def _finalize(self, st):
+        _cabi.check(_cabi.lib().dmx_vit_finalize(self._h, st), "vit_finalize")
+
+    @staticmethod
+    def _convert_legacy_keys(sd):
+        """VisionEncoderDecoderModel checkpoints prefix the encoder with `encoder.`; the ViTModel pooler is unused."""
+        if any(k.startswith("encoder.embeddings.") for k in sd):
+            sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+        return {k: v for k, v in sd.items() if not k.startswith("pooler.")}
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, revision=None, **kw):
+        """transformers directory layout: config.json (a ViT config, or a VisionEncoderDecoder config whose `encoder` entry
+        is one) + model.safetensors / pytorch_model.bin."""
+        d = pretrained_model_name_or_path if subfolder is None else os.path.join(pretrained_model_name_or_path, subfolder)
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = json.load(f)
+        cfg = cfg.get("encoder", cfg)
+        keep = {k: cfg[k] for k in TROCR_LARGE_VIT_CONFIG if k in cfg}
+        model = cls(**keep)
+        st = os.path.join(d, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict(cls._convert_legacy_keys(sd))
+        return model
+
+    def forward(self, pixel_values, return_dict=True, **unused):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("diffute_amd: the glyph encoder is forward-only (frozen in the reference, train_diffute_v1.py:638)")
+        _cabi.require_cuda(pixel_values)
+        self._ensure_packed()
+        lib = _cabi.lib()
+        x = pixel_values.to(torch.float32).contiguous()
+        B, C, H, W = x.shape
+        if (C, H, W) != (self.config.num_channels, self.config.image_size, self.config.image_size):
+            raise ValueError(f"pixel_values must be [B,{self.config.num_channels},{self.config.image_size},{self.config.image_size}], got {tuple(x.shape)}")
+        n = (self.config.image_size // self.config.patch_size) ** 2 + 1
+        out = torch.empty(B, n, self.config.hidden_size, dtype=torch.float32, device=x.device)
+        ws = self._workspace(lib.dmx_vit_workspace_bytes(self._h, B))
+        _cabi.check(lib.dmx_vit_forward(self._h, _cabi.ptr(x), _cabi.ptr(out), B, _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "vit_forward")
+        if self._dtype != torch.float32 and pixel_values.dtype != torch.float32:
+            out = out.to(pixel_values.dtype)
+        return BaseModelOutput(last_hidden_state=out) if return_dict else (out,)

@@ -97,7 +97,7 @@ def pack_geglu_bias(b):
 
 
 def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=None, rowbias=None,
-              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0, dbg=0):
+              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0, dbg=0, act=0):
     """Fused conv / linear.  x0 (and x1) NHWC bf16; w packed bf16 [N][K].  Returns NHWC (bf16 or fp32)."""
     B, H, W, C0 = x0.shape
     Cin = C0 + (x1.shape[-1] if x1 is not None else 0)
@@ -131,7 +131,7 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
     Nout = N // 2 if geglu else N
     out = torch.empty(B, OH, OW, Nout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x0.device)
     d.out = out.data_ptr(); d.ldo = Nout; d.out_f32 = int(out_f32); d.geglu = int(geglu)
-    d.force_tn = force_tn; d.force_splitk = force_splitk; d.group_m = group_m; d.dbg = dbg
+    d.force_tn = force_tn; d.force_splitk = force_splitk; d.group_m = group_m; d.dbg = dbg; d.act = act
     if timing is not None:
         d.timing = timing.data_ptr()
     wsb = lib().dmx_conv_gemm_workspace_bytes(ctypes.byref(d))
@@ -184,12 +184,12 @@ def colsum(dy, groups=1, into=None):
     return out
 
 
-def linear(x, w, bias=None, res=None, geglu=False, out_f32=False):
+def linear(x, w, bias=None, res=None, geglu=False, out_f32=False, act=0):
     """x [..., K] bf16 (2-D view [rows][K]) @ w[N][K]^T."""
     K = x.shape[-1]
     x4 = x.reshape(1, 1, -1, K)
     r4 = None if res is None else res.reshape(1, 1, -1, res.shape[-1])
-    y = conv_gemm(x4, w, w.shape[0], ksize=1, pad=0, bias=bias, res=r4, geglu=geglu, out_f32=out_f32)
+    y = conv_gemm(x4, w, w.shape[0], ksize=1, pad=0, bias=bias, res=r4, geglu=geglu, out_f32=out_f32, act=act)
     return y.reshape(*x.shape[:-1], y.shape[-1])
 
 

@@ -73,6 +73,7 @@ typedef struct dmx_gemm_desc {
   long long* timing;                /* optional device buffer [blocks][4]: per-block start / prologue / loop / end
                                        timestamps in 10 ns ticks (measurement aid), normally NULL */
   int dbg;                          /* measurement aid, must be 0: bit0 skips the MFMA phase, bit1 the DMA refills */
+  int act;                          /* 1: exact (erf) GELU after the bias (ViT MLP fc1), bf16 output only             */
 } dmx_gemm_desc;
 size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d);
 int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
@@ -286,6 +287,31 @@ int dmx_unet_refresh_derived(dmx_unet* u, dmx_stream_t stream);
 size_t dmx_mse_loss_workspace_bytes(void);
 int dmx_mse_loss(const float* pred, const float* target, size_t n, float* loss, float* dpred, float grad_scale,
                  void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Glyph encoder: the ViT encoder of TrOCR, `trocr_model(pixel_values).last_hidden_state`
+ * (app.ipynb:773-776, train_diffute_v1.py:868-871).  Same handle protocol as the UNet / VAE: create, enumerate the
+ * parameters (transformers ViTModel state-dict keys), bind an arena, load fp32 tensors, finalize, forward.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dmx_vit dmx_vit;
+typedef struct dmx_vit_config {
+  int image_size, patch_size, num_channels;     /* 384, 16, 3 */
+  int hidden_size, num_layers, num_heads;       /* 1024, 24, 16 (head dim must be 64) */
+  int intermediate_size;                        /* 4096 */
+  int qkv_bias;                                 /* 0 for TrOCR (BEiT-style), 1 for plain ViT checkpoints */
+  float layer_norm_eps;                         /* 1e-12 */
+} dmx_vit_config;
+dmx_vit* dmx_vit_create(const dmx_vit_config* cfg);
+void dmx_vit_destroy(dmx_vit* v);
+int dmx_vit_param_count(const dmx_vit* v);
+int dmx_vit_param_info(const dmx_vit* v, int index, const char** name, int shape[4]);
+size_t dmx_vit_arena_bytes(const dmx_vit* v);
+int dmx_vit_bind_arena(dmx_vit* v, void* arena, size_t bytes);
+int dmx_vit_load_param(dmx_vit* v, const char* name, const float* src_f32, dmx_stream_t stream);
+int dmx_vit_finalize(dmx_vit* v, dmx_stream_t stream);
+size_t dmx_vit_workspace_bytes(dmx_vit* v, int B);
+int dmx_vit_forward(dmx_vit* v, const float* pixel_values, float* last_hidden_state, int B,
+                    void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
 typedef struct dmx_vae_config {
   int in_channels, out_channels, latent_channels;

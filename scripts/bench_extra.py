@@ -1,5 +1,5 @@
-"""Secondary configurations of BASELINE.json (not the headline bench line): cfg3 VAE encode+decode at 512 px and
-cfg5 768-px denoise loop.  Prints one JSON object per configuration."""
+"""Secondary configurations of BASELINE.json (not the headline bench line): cfg3 VAE encode+decode at 512 px,
+cfg5 768-px denoise loop, and the glyph encoder (TrOCR-large ViT).  Prints one JSON object per configuration."""
 import argparse
 import json
 import sys
@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--vae-batch", type=int, default=32)
     ap.add_argument("--skip-vae", action="store_true")
     ap.add_argument("--skip-768", action="store_true")
+    ap.add_argument("--skip-vit", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda")
     if not args.skip_vae:
@@ -43,6 +44,18 @@ def main():
                           "decode_ms": round(t_dec * 1e3, 2), "images_per_s": round(B / (t_enc + t_dec), 2),
                           "encode_tflops": round(fe / t_enc / 1e12, 1), "decode_tflops": round(fd / t_dec / 1e12, 1)}))
         del vae, img, rec, z
+        torch.cuda.empty_cache()
+    if not args.skip_vit:
+        enc = D.TrOCREncoder(device=dev)
+        fl1 = 2 * 576 * 1024 * 768 + 24 * (2 * 577 * 1024 * 3072 + 4 * 577 * 577 * 1024 + 2 * 577 * 1024 * 1024 + 4 * 577 * 1024 * 4096)
+        for B in (1, 8):
+            px = torch.randn(B, 3, 384, 384, device=dev)
+            with torch.no_grad():
+                t, y = timed(lambda: enc(px).last_hidden_state, 5)
+            assert torch.isfinite(y).all() and y.shape == (B, 577, 1024)
+            print(json.dumps({"config": f"glyph encoder: TrOCR-large ViT (24 layers, 577 tokens), batch {B}, bf16", "ms": round(t * 1e3, 2),
+                              "images_per_s": round(B / t, 1), "tflops": round(fl1 * B / t / 1e12, 1)}))
+        del enc
         torch.cuda.empty_cache()
     if not args.skip_768:
         unet = D.UNet2DConditionModel(device=dev).requires_grad_(False)

@@ -199,3 +199,27 @@ def test_oracle_training_step_matches_golden():
     for k in TRAIN_KEYS:
         ref = g["g_fp32_" + k]
         assert np.linalg.norm(grads[k].numpy() - ref) <= 1e-3 * np.linalg.norm(ref), k
+
+
+def test_glyph_encoder_param_table_matches_oracle_spec():
+    """N1: the C++ parameter table of the TrOCR ViT encoder agrees key-by-key and shape-by-shape with the oracle's
+    enumeration, for the tiny config (with q/k/v biases) and the TrOCR-large config (303,617,024 parameters without pooler)."""
+    import ctypes
+    from diffute_amd import _cabi
+    from oracle import vit as OVT
+    lib = _cabi.lib()
+    for cfg in (OVT.TINY_VIT, OVT.TROCR_LARGE_VIT):
+        c = _cabi.ViTConfig(cfg["image_size"], cfg["patch_size"], cfg["num_channels"], cfg["hidden_size"], cfg["num_layers"], cfg["num_heads"],
+                            cfg["intermediate_size"], int(cfg["qkv_bias"]), cfg["layer_norm_eps"])
+        h = lib.dmx_vit_create(ctypes.byref(c))
+        assert h
+        spec = OVT.vit_param_spec(cfg)
+        name = ctypes.c_char_p(); shape = (ctypes.c_int * 4)()
+        got = {}
+        for i in range(lib.dmx_vit_param_count(h)):
+            assert lib.dmx_vit_param_info(h, i, ctypes.byref(name), ctypes.byref(shape)) == 0
+            got[name.value.decode()] = tuple(int(s) for s in shape if s > 0)
+        lib.dmx_vit_destroy(h)
+        assert got == dict(spec)
+    n = sum(int(np.prod(s)) for s in OVT.vit_param_spec(OVT.TROCR_LARGE_VIT).values())
+    assert n == 303_617_024

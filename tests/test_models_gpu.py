@@ -367,3 +367,45 @@ def test_fused_adamw_matches_torch(cuda):
     with torch.no_grad():                       # inference path (folded LayerNorm copies refreshed) agrees as well
         a = ref.requires_grad_(False)(x, t, ctx).sample; b = fus.requires_grad_(False)(x, t, ctx).sample
     assert_close(b, a.cpu(), 2e-2, "forward after fused optimizer steps")
+
+
+# ------------------------------------------------------------------------------------------------ glyph encoder (N1)
+TINY_VIT = dict(image_size=64, patch_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, qkv_bias=True)
+
+
+def test_tiny_glyph_encoder(cuda):
+    """N1 on a tiny config (2 layers, 17 tokens, q/k/v biases): vs the bf16-emulating oracle and the fp32 oracle."""
+    import diffute_amd as D
+    from oracle import vit as OVT
+    enc = D.TrOCREncoder(**TINY_VIT).cuda()
+    g = torch.Generator().manual_seed(3)
+    px = torch.randn(3, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        y = enc(px.cuda()).last_hidden_state
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    assert y.shape == (3, 17, 128)
+    e16 = assert_close(y, OVT.vit_forward(P, OVT.TINY_VIT, px, emulate_bf16=True), E2E_EMU, "tiny ViT vs bf16-emulating oracle")
+    e32 = assert_close(y, OVT.vit_forward(P, OVT.TINY_VIT, px), 5e-2, "tiny ViT vs fp32 oracle")
+    print(f"tiny glyph encoder rel-L2: vs bf16emu {e16:.2e}, vs fp32 {e32:.2e}")
+
+
+def test_full_glyph_encoder_properties(cuda):
+    """TrOCR-large shapes (24 layers, 577 tokens of 1024): output shape, finiteness, batch independence, determinism,
+    and one full-size oracle comparison at B=1."""
+    import diffute_amd as D
+    from oracle import vit as OVT
+    enc = D.TrOCREncoder(device=cuda)
+    assert sum(p.numel() for p in enc.parameters()) == 303_617_024
+    g = torch.Generator().manual_seed(4)
+    px = torch.randn(2, 3, 384, 384, generator=g).cuda()
+    with torch.no_grad():
+        y = enc(px).last_hidden_state
+        y0 = enc(px[:1].contiguous()).last_hidden_state
+        y2 = enc(px).last_hidden_state
+    assert y.shape == (2, 577, 1024) and torch.isfinite(y).all()
+    assert torch.equal(y, y2)
+    assert_close(y[:1], y0.cpu(), E2E_EMU, "batch independence")     # B=1 and B=2 take different tile / split-K plans: bf16 noise over 24 layers
+    P = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    ref = OVT.vit_forward(P, OVT.TROCR_LARGE_VIT, px[:1].cpu(), emulate_bf16=True)
+    e = assert_close(y0, ref, E2E_EMU, "TrOCR-large encoder vs bf16-emulating oracle")
+    print(f"full glyph encoder rel-L2 vs bf16emu oracle {e:.2e}")
