@@ -77,7 +77,7 @@ def _train_sync_worker(rank, world, port, q):
     w = [torch.ones(3) * (rank + 5)]
     D.broadcast_parameters(w, dist, src=0)
     mean_loss = D.gather_scalar(float(rank + 1), dist, world)
-    q.put((rank, flat.clone(), order, w[0].clone(), mean_loss))
+    q.put((rank, flat.numpy().copy(), order, w[0].numpy().copy(), mean_loss))     # numpy: no fd passing races with process exit
     D.barrier_sync(dist)
     dist.destroy_process_group()
 
@@ -98,7 +98,7 @@ def test_bucketed_gradient_all_reduce_gloo_world2():
     for b, e in [(0, 1000), (1500, 3000), (3500, 4096)]:
         want[b:e] = idx[b:e] * (1 + 2) / 2.0                             # mean of rank-scaled values
     for rank, flat, order, w, mean_loss in res:
-        assert torch.equal(flat, want), f"rank {rank}: reduced arena differs"
+        assert torch.equal(torch.from_numpy(flat), want), f"rank {rank}: reduced arena differs"
         assert order == [0, 1]
-        assert torch.equal(w, torch.ones(3) * 5)
+        assert torch.equal(torch.from_numpy(w), torch.ones(3) * 5)
         assert abs(mean_loss - 1.5) < 1e-6
