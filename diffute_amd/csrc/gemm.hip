@@ -674,7 +674,7 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[7] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[8] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
@@ -682,6 +682,8 @@ static const TileCfg kCfg[7] = {            // measured (scripts/gemm_timeline.p
     {128, 128, 64, 256, 1.00, 7.0},         // deep ring (4 x 32 KB, 1 block/CU)
     {256, 256, 32, 256, 2.40, 16.0},        // 128 FLOP/B (experimental, force_tn = 6 only)
     {256, 128, 64, 256, 1.90, 11.0},        // warp-specialised 256x128x64: 4 MFMA waves + 4 DMA waves (~0.85 us per K-tile)
+    {128, 64, 64, 512, 0.55, 5.0},          // 128x64x64 with EIGHT waves (32x32 each): small grids are bound by the per-CU LDS-DMA fill
+                                            // rate, which doubles with 8 issuing waves (~95 vs ~50 GB/s); force_tn = 8 / tuned table
 };
 
 static double plan_cost(const GemmArgs& a, int c, int sk) {
@@ -710,18 +712,18 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == a.ups &&
-          !(a.geglu && (tp.cfg == 1 || tp.cfg == 3)) && !(no_split && tp.sk > 1)) {
+          !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
         const int nkt = a.K / kCfg[tp.cfg].bk;
         int ktps = cdiv(nkt, tp.sk);
         *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
         return;
       }
   }
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < 8; ++c) {
     const TileCfg& T = kCfg[c];
-    if ((c == 3 || c == 4 || c == 5) && !a.force_tn) continue;   // deep rings / 256x256: no gain inside the UNet pass; kept for experiments
+    if ((c == 3 || c == 4 || c == 5 || c == 7) && !a.force_tn) continue;   // deep rings / 256x256: no gain inside the UNet pass; kept for experiments
     if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
-    if (a.geglu && (c == 1 || c == 3)) continue;
+    if (a.geglu && (c == 1 || c == 3 || c == 7)) continue;
     if (a.force_tn == 1 && c != 1) continue;
     if (a.force_tn == 2 && c != 0) continue;
     if (a.force_tn == 3 && c != 2) continue;
@@ -729,6 +731,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     if (a.force_tn == 5 && c != 4) continue;
     if (a.force_tn == 6 && c != 5) continue;
     if (a.force_tn == 7 && c != 6) continue;
+    if (a.force_tn == 8 && c != 7) continue;
     if (!a.force_tn && c != 1 && c != 3 && a.N <= 64) continue;
     if (!a.force_tn && (c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
     const int nkt = a.K / T.bk;
@@ -804,14 +807,15 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   char tag[96];
   snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, c == 0 ? 2 : (c == 1 ? 1 : c + 1), sk);
   {
-    ProfScope ps((c == 0 || c == 4) ? PROF_GEMM128 : ((c == 1 || c == 3) ? PROF_GEMM64 : (c == 6 ? PROF_GEMM256WS : PROF_GEMM256)), stream, flops, bytes, tag);
+    ProfScope ps((c == 0 || c == 4) ? PROF_GEMM128 : ((c == 1 || c == 3 || c == 7) ? PROF_GEMM64 : (c == 6 ? PROF_GEMM256WS : PROF_GEMM256)), stream, flops, bytes, tag);
     if (c == 0) launch_cfg<2, 2, 32, 4>(a, grid, stream);
     else if (c == 1) launch_cfg<2, 1, 32, 4>(a, grid, stream);
     else if (c == 2) launch_cfg<4, 2, 64, 3>(a, grid, stream);
     else if (c == 3) launch_cfg<2, 1, 64, 6>(a, grid, stream);
     else if (c == 4) launch_cfg<2, 2, 64, 4>(a, grid, stream);
     else if (c == 5) launch_cfg<4, 4, 32, 4>(a, grid, stream);
-    else launch_cfg<2, 2, 64, 3, 4, 4>(a, grid, stream);
+    else if (c == 6) launch_cfg<2, 2, 64, 3, 4, 4>(a, grid, stream);
+    else launch_cfg<4, 1, 64, 3, 1>(a, grid, stream);
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;
