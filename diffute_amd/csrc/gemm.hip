@@ -674,7 +674,7 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[8] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[10] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
@@ -684,6 +684,8 @@ static const TileCfg kCfg[8] = {            // measured (scripts/gemm_timeline.p
     {256, 128, 64, 256, 1.90, 11.0},        // warp-specialised 256x128x64: 4 MFMA waves + 4 DMA waves (~0.85 us per K-tile)
     {128, 64, 64, 512, 0.55, 5.0},          // 128x64x64 with EIGHT waves (32x32 each): small grids are bound by the per-CU LDS-DMA fill
                                             // rate, which doubles with 8 issuing waves (~95 vs ~50 GB/s); force_tn = 8 / tuned table
+    {128, 128, 32, 512, 1.00, 8.0},         // 128x128x32 with eight waves (32x64 each), 4-stage ring; force_tn = 9 / tuned table
+    {128, 128, 64, 256, 1.00, 8.0},         // 128x128x64 with eight waves, 3-stage ring (96 KB); force_tn = 10 / tuned table
 };
 
 static double plan_cost(const GemmArgs& a, int c, int sk) {
@@ -719,9 +721,9 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
         return;
       }
   }
-  for (int c = 0; c < 8; ++c) {
+  for (int c = 0; c < 10; ++c) {
     const TileCfg& T = kCfg[c];
-    if ((c == 3 || c == 4 || c == 5 || c == 7) && !a.force_tn) continue;   // deep rings / 256x256: no gain inside the UNet pass; kept for experiments
+    if ((c == 3 || c == 4 || c == 5 || c >= 7) && !a.force_tn) continue;   // deep rings / 256x256: no gain inside the UNet pass; kept for experiments
     if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
     if (a.geglu && (c == 1 || c == 3 || c == 7)) continue;
     if (a.force_tn == 1 && c != 1) continue;
@@ -732,6 +734,8 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     if (a.force_tn == 6 && c != 5) continue;
     if (a.force_tn == 7 && c != 6) continue;
     if (a.force_tn == 8 && c != 7) continue;
+    if (a.force_tn == 9 && c != 8) continue;
+    if (a.force_tn == 10 && c != 9) continue;
     if (!a.force_tn && c != 1 && c != 3 && a.N <= 64) continue;
     if (!a.force_tn && (c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
     const int nkt = a.K / T.bk;
@@ -807,7 +811,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   char tag[96];
   snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, c == 0 ? 2 : (c == 1 ? 1 : c + 1), sk);
   {
-    ProfScope ps((c == 0 || c == 4) ? PROF_GEMM128 : ((c == 1 || c == 3 || c == 7) ? PROF_GEMM64 : (c == 6 ? PROF_GEMM256WS : PROF_GEMM256)), stream, flops, bytes, tag);
+    ProfScope ps((c == 0 || c == 4 || c == 8 || c == 9) ? PROF_GEMM128 : ((c == 1 || c == 3 || c == 7) ? PROF_GEMM64 : (c == 6 ? PROF_GEMM256WS : PROF_GEMM256)), stream, flops, bytes, tag);
     if (c == 0) launch_cfg<2, 2, 32, 4>(a, grid, stream);
     else if (c == 1) launch_cfg<2, 1, 32, 4>(a, grid, stream);
     else if (c == 2) launch_cfg<4, 2, 64, 3>(a, grid, stream);
@@ -815,7 +819,9 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     else if (c == 4) launch_cfg<2, 2, 64, 4>(a, grid, stream);
     else if (c == 5) launch_cfg<4, 4, 32, 4>(a, grid, stream);
     else if (c == 6) launch_cfg<2, 2, 64, 3, 4, 4>(a, grid, stream);
-    else launch_cfg<4, 1, 64, 3, 1>(a, grid, stream);
+    else if (c == 7) launch_cfg<4, 1, 64, 3, 1>(a, grid, stream);
+    else if (c == 8) launch_cfg<4, 2, 32, 4, 1>(a, grid, stream);
+    else launch_cfg<4, 2, 64, 3, 1>(a, grid, stream);
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;

@@ -66,11 +66,11 @@ def main(path):
             run = lambda tn, sk, i=0: ops.conv_gemm(x, ws[i % len(ws)], N, ksize=1, pad=0, force_tn=tn, force_splitk=sk)
         t_auto = time_it(lambda i: run(0, 0, i))
         res = []
-        for tn in (8, 7, 3, 2, 1):
+        for tn in (10, 9, 8, 7, 3, 2, 1):
             for sk in (1, 2, 3, 4, 6, 8, 12, 16):
-                if K % (64 if tn in (3, 4, 5, 7, 8) else 32):
+                if K % (64 if tn in (3, 4, 5, 7, 8, 10) else 32):
                     continue
-                if sk > 1 and (K // (64 if tn in (3, 4, 5, 7, 8) else 32)) // sk < (4 if tn in (3, 4, 5, 7, 8) else 8):
+                if sk > 1 and (K // (64 if tn in (3, 4, 5, 7, 8, 10) else 32)) // sk < (4 if tn in (3, 4, 5, 7, 8, 10) else 8):
                     continue
                 try:
                     res.append((time_it(lambda i: run(tn, sk, i)), tn, sk))

@@ -62,7 +62,7 @@ def test_conv(cuda, case):
     assert_close(nchw(out), ref, TOL, name)
 
 
-@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (4, 1), (5, 1), (6, 1), (6, 2), (7, 1), (7, 2), (8, 1), (8, 2)])
+@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (4, 1), (5, 1), (6, 1), (6, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2)])
 def test_conv_every_tile_config(cuda, tn, sk):
     """All three tile configurations (128x64, 128x128, 256x128) and split-K give the same conv + epilogue."""
     from diffute_amd import ops
