@@ -22,11 +22,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# rocprofv3 names of the GEMM template instances (dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP>)
-KERNEL_NAMES = {"gemm_128x128": "void dmx_gemm_kernel<2, 2, 32, 4, 2, 0>(GemmArgs)", "gemm_128x64": "void dmx_gemm_kernel<2, 1, 32, 4, 2, 0>(GemmArgs)",
-                "gemm_256x128": "void dmx_gemm_kernel<4, 2, 64, 3, 2, 0>(GemmArgs)", "gemm_256x128_ws": "void dmx_gemm_kernel<2, 2, 64, 3, 4, 4>(GemmArgs)"}
-PROF_CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128", "wgrad", "gemm_256x128_ws"]
-MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+# profile classes of the library (diffute_amd/csrc/kernels.h ProfClass); classes 10.. = one per GEMM tile config, named
+# after the rocprofv3 kernel name of that template instance dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP>
+GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0>"), ("gemm_128x64x32", "<2, 1, 32, 4, 2, 0>"), ("gemm_256x128x64", "<4, 2, 64, 3, 2, 0>"),
+             ("gemm_128x64x64_deep", "<2, 1, 64, 6, 2, 0>"), ("gemm_128x128x64_deep", "<2, 2, 64, 4, 2, 0>"), ("gemm_256x256x32", "<4, 4, 32, 4, 2, 0>"),
+             ("gemm_256x128x64_ws", "<2, 2, 64, 3, 4, 4>"), ("gemm_128x64x64_8w", "<4, 1, 64, 3, 1, 0>"), ("gemm_128x128x32_8w", "<4, 2, 32, 4, 1, 0>"),
+             ("gemm_128x128x64_8w", "<4, 2, 64, 3, 1, 0>")]
+KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % t for n, t in GEMM_CFGS}
+PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
+                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS]
+MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
 def pmc_traffic(kernel_name):

@@ -811,7 +811,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   char tag[96];
   snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, c == 0 ? 2 : (c == 1 ? 1 : c + 1), sk);
   {
-    ProfScope ps((c == 0 || c == 4 || c == 8 || c == 9) ? PROF_GEMM128 : ((c == 1 || c == 3 || c == 7) ? PROF_GEMM64 : (c == 6 ? PROF_GEMM256WS : PROF_GEMM256)), stream, flops, bytes, tag);
+    ProfScope ps((ProfClass)(PROF_GEMM_CFG0 + c), stream, flops, bytes, tag);
     if (c == 0) launch_cfg<2, 2, 32, 4>(a, grid, stream);
     else if (c == 1) launch_cfg<2, 1, 32, 4>(a, grid, stream);
     else if (c == 2) launch_cfg<4, 2, 64, 3>(a, grid, stream);

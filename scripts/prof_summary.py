@@ -3,7 +3,7 @@ import collections
 import csv
 import sys
 
-NAMES = ["gemm128", "gemm64", "splitk", "attn", "gn", "ln", "other", "gemm256"]
+NAMES = ["gemm128", "gemm64", "splitk", "attn", "gn", "ln", "other", "gemm256", "wgrad", "gemm256ws"] + [f"gemm_cfg{i}" for i in range(10)]
 
 
 def main(path, top=40):

@@ -1,10 +1,13 @@
 """rocprofv3 output directories -> the summaries committed under profiles/.
 
-    python scripts/rocprof_to_profiles.py <stats_dir> <fetch_dir> <write_dir> <out_prefix>     e.g. profiles/r01
+    python scripts/rocprof_to_profiles.py <stats_dir> <fetch_dir> <write_dir> <out_prefix> [<mfma_dir>]     e.g. profiles/r01
 
   <stats_dir>  rocprofv3 --kernel-trace --stats            -> <out_prefix>_kernel_stats.csv (copied as is)
   <fetch_dir>  rocprofv3 --pmc FETCH_SIZE  (own pass)      \\
   <write_dir>  rocprofv3 --pmc WRITE_SIZE  (own pass)      /-> <out_prefix>_pmc_traffic.csv: per kernel, per launch
+  <mfma_dir>   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass) -> <out_prefix>_pmc_mfma.csv: per kernel,
+               MFMA-busy cycles summed over the chip's 1024 SIMDs / (1024 x GPU-active cycles) = matrix-pipe utilisation
+               (GRBM_GUI_ACTIVE is reported as the sum of 16 instances: divided by 16)
 Counter units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are in KiB; FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is taken as is."""
 import collections
@@ -47,5 +50,28 @@ def main(stats_dir, fetch_dir, write_dir, out):
     print(f"{len(rows)} kernels -> {out}_pmc_traffic.csv, {out}_kernel_stats.csv")
 
 
+# rocprofv3 sums GRBM_GUI_ACTIVE over 16 counter instances on this part (cross-checked: value / 16 = kernel duration x ~2 GHz)
+GRBM_INSTANCES = 16.0
+
+
+def mfma(mfma_dir, out):
+    bt, bn = per_kernel(mfma_dir, "SQ_VALU_MFMA_BUSY_CYCLES")
+    at, an = per_kernel(mfma_dir, "GRBM_GUI_ACTIVE")
+    rows = []
+    for k in bt:
+        if not k.startswith(("void dmx_", "dmx_")) or at.get(k, 0) <= 0:
+            continue
+        rows.append((k, bn[k], bt[k] / bn[k], at[k] / an[k], bt[k] / (1024.0 * at[k] / GRBM_INSTANCES)))
+    rows.sort(key=lambda r: -r[1] * r[3])
+    with open(out + "_pmc_mfma.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "SQ_VALU_MFMA_BUSY_CYCLES_per_launch", "GRBM_GUI_ACTIVE_per_launch_sum_of_16_instances", "mfma_busy_fraction_of_1024_SIMDs"])
+        for r in rows:
+            w.writerow([r[0], r[1], f"{r[2]:.0f}", f"{r[3]:.0f}", f"{r[4]:.4f}"])
+    print(f"{len(rows)} kernels -> {out}_pmc_mfma.csv")
+
+
 if __name__ == "__main__":
     main(*sys.argv[1:5])
+    if len(sys.argv) > 5:
+        mfma(sys.argv[5], sys.argv[4])

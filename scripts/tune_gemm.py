@@ -39,7 +39,7 @@ def weights(N, K, total=384 << 20):
 def main(path):
     shapes = {}
     for r in csv.DictReader(open(path)):
-        if int(r["class"]) not in (0, 1, 7):
+        if int(r["class"]) not in (0, 1, 7, 9) and not 10 <= int(r["class"]) < 20:
             continue
         m = dict(re.findall(r"(\w+)=(\d+)", r["tag"]))
         key = tuple(int(m[k]) for k in ("M", "N", "K", "ks", "st", "ups"))
