@@ -121,6 +121,13 @@ _PROTOS = {
     "dmx_unet_train_backward": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "dmx_unet_grad_export": (c_int, [_P, _P, c_char_p, _P, _P]),
     "dmx_unet_grad_range": (c_int, [_P, c_char_p, POINTER(c_size_t), POINTER(c_size_t)]),
+    "dmx_vae_train_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int]),
+    "dmx_vae_train_wt_bytes": (c_size_t, [_P]),
+    "dmx_vae_train_prepare": (c_int, [_P, _P, c_size_t, _P]),
+    "dmx_vae_grad_bytes": (c_size_t, [_P]),
+    "dmx_vae_train_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_vae_train_backward": (c_int, [_P, _P, _P, _P]),
+    "dmx_vae_grad_export": (c_int, [_P, _P, c_char_p, _P, _P]),
     "dmx_unet_optim_chunks": (c_int, [_P]),
     "dmx_unet_optim_table_bytes": (c_size_t, [_P]),
     "dmx_unet_optim_elements": (c_size_t, [_P]),

@@ -173,6 +173,13 @@ int dmx_add_bf16_launch(const bf16* a, int lda, const bf16* b, int ldb, bf16* o,
 size_t dmx_mse_workspace_bytes();
 int dmx_mse_loss_launch(const float* pred, const float* target, size_t n, float* loss, float* dpred, float grad_scale,
                         void* workspace, size_t workspace_bytes, hipStream_t stream);
+// 1x1 convs between <= 8 channels (VAE quant / post_quant), softmax backward over rows (VAE mid attention)
+int dmx_pointwise_small_fwd_launch(const bf16* x, int ldx, const bf16* w, int ldw, const float* bias, void* y, int ldy, int M, int Cin, int Cout,
+                                   int out_f32, hipStream_t stream);
+size_t dmx_pointwise_small_bwd_ws_bytes(int M, int Cin, int Cout);
+int dmx_pointwise_small_bwd_launch(const bf16* x, int ldx, const float* dy, int lddy, const bf16* w, int ldw, bf16* dx, int lddx,
+                                   float* dw, int lddw, float* db, int M, int Cin, int Cout, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int dmx_softmax_bwd_rows_launch(const bf16* P, int ldp, const float* dP, int lddp, bf16* dS, int ldds, int rows, int n, float scale, hipStream_t stream);
 // y = W act(x) + b with act = SiLU when silu_in (dmx_linear_small): dw (+)= dy^T act(x), db (+)= colsum(dy), dx = act'(x) * (dy W)
 int dmx_linear_small_bwd_launch(const float* x, int ldx, const float* dy, int lddy, const bf16* w, int ldw,
                                 float* dw, int lddw, float* db, int db_stride, float* dx, int lddx,

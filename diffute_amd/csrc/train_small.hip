@@ -87,7 +87,99 @@ __global__ __launch_bounds__(256) void dmx_linear_small_bwd_x_kernel(const float
   if (silu_in) s *= dsilu1(x[(size_t)b * ldx + k]);
   dx[(size_t)b * lddx + k] = s;
 }
+// ---- 1x1 convolutions between tiny channel counts (VAE quant_conv 8->8, post_quant_conv 4->4): one thread per row
+#define PW_MAXC 8
+__global__ __launch_bounds__(256) void dmx_pointwise_small_fwd_kernel(const bf16* x, int ldx, const bf16* w, int ldw, const float* bias,
+                                                                      void* y, int ldy, int M, int Cin, int Cout, int out_f32) {
+  __shared__ float ws[PW_MAXC * PW_MAXC + PW_MAXC];
+  if ((int)threadIdx.x < Cout * Cin) ws[threadIdx.x] = (float)w[(threadIdx.x / Cin) * ldw + threadIdx.x % Cin];
+  if ((int)threadIdx.x < Cout) ws[PW_MAXC * PW_MAXC + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float xv[PW_MAXC];
+  for (int i = 0; i < Cin; ++i) xv[i] = (float)x[(size_t)m * ldx + i];
+  for (int o = 0; o < Cout; ++o) {
+    float a = ws[PW_MAXC * PW_MAXC + o];
+    for (int i = 0; i < Cin; ++i) a += ws[o * Cin + i] * xv[i];
+    if (out_f32) ((float*)y)[(size_t)m * ldy + o] = a;
+    else ((unsigned short*)y)[(size_t)m * ldy + o] = f2bf_bits(a);
+  }
+}
+// dX[m][i] = sum_o dy[m][o] W[o][i] ; per-block partials of dW[o][i] = sum_m dy[m][o] x[m][i] and db[o] = sum_m dy[m][o]
+__global__ __launch_bounds__(256) void dmx_pointwise_small_bwd_kernel(const bf16* x, int ldx, const float* dy, int lddy, const bf16* w, int ldw,
+                                                                      bf16* dx, int lddx, float* part, int M, int Cin, int Cout) {
+  __shared__ float ws[PW_MAXC * PW_MAXC];
+  __shared__ float red[256];
+  if ((int)threadIdx.x < Cout * Cin) ws[threadIdx.x] = (float)w[(threadIdx.x / Cin) * ldw + threadIdx.x % Cin];
+  __syncthreads();
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  float xv[PW_MAXC], dv[PW_MAXC];
+  for (int i = 0; i < PW_MAXC; ++i) { xv[i] = 0.f; dv[i] = 0.f; }
+  if (m < M) {
+    for (int i = 0; i < Cin; ++i) xv[i] = (float)x[(size_t)m * ldx + i];
+    for (int o = 0; o < Cout; ++o) dv[o] = dy[(size_t)m * lddy + o];
+    if (dx)
+      for (int i = 0; i < Cin; ++i) {
+        float a = 0.f;
+        for (int o = 0; o < Cout; ++o) a += dv[o] * ws[o * Cin + i];
+        ((unsigned short*)dx)[(size_t)m * lddx + i] = f2bf_bits(a);
+      }
+  }
+  const int nq = Cout * Cin + Cout;
+  for (int q = 0; q < nq; ++q) {                 // fixed-order tree per quantity
+    red[threadIdx.x] = q < Cout * Cin ? dv[q / Cin] * xv[q % Cin] : dv[q - Cout * Cin];
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * nq + q] = red[0];
+    __syncthreads();
+  }
+}
+__global__ void dmx_pointwise_small_final_kernel(const float* part, int nblk, int Cin, int Cout, float* dw, int lddw, float* db) {
+  const int q = threadIdx.x, nq = Cout * Cin + Cout;
+  if (q >= nq) return;
+  float s = 0.f;
+  for (int j = 0; j < nblk; ++j) s += part[(size_t)j * nq + q];
+  if (q < Cout * Cin) dw[(q / Cin) * lddw + q % Cin] = s; else db[q - Cout * Cin] = s;
+}
+
+// softmax backward over rows: dS = scale * P o (dP - rowsum(dP o P)); one block per row
+__global__ __launch_bounds__(256) void dmx_softmax_bwd_rows_kernel(const bf16* P, int ldp, const float* dP, int lddp, bf16* dS, int ldds, int n, float scale) {
+  __shared__ float red[256];
+  const size_t r = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < n; c += 256) s += (float)P[r * ldp + c] * dP[r * lddp + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  const float dot = red[0];
+  for (int c = threadIdx.x; c < n; c += 256)
+    ((unsigned short*)dS)[r * ldds + c] = f2bf_bits(scale * (float)P[r * ldp + c] * (dP[r * lddp + c] - dot));
+}
 }  // namespace
+
+int dmx_pointwise_small_fwd_launch(const bf16* x, int ldx, const bf16* w, int ldw, const float* bias, void* y, int ldy, int M, int Cin, int Cout,
+                                   int out_f32, hipStream_t stream) {
+  DMX_REQUIRE(Cin <= PW_MAXC && Cout <= PW_MAXC && Cin > 0 && Cout > 0, "pointwise_small: Cin=%d Cout=%d must be <= 8", Cin, Cout);
+  hipLaunchKernelGGL(dmx_pointwise_small_fwd_kernel, dim3(cdiv(M, 256)), dim3(256), 0, stream, x, ldx, w, ldw, bias, y, ldy, M, Cin, Cout, out_f32);
+  return dmx_check_launch("dmx_pointwise_small_fwd_kernel");
+}
+size_t dmx_pointwise_small_bwd_ws_bytes(int M, int Cin, int Cout) { return (size_t)cdiv(M, 256) * (Cout * Cin + Cout) * sizeof(float); }
+int dmx_pointwise_small_bwd_launch(const bf16* x, int ldx, const float* dy, int lddy, const bf16* w, int ldw, bf16* dx, int lddx,
+                                   float* dw, int lddw, float* db, int M, int Cin, int Cout, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  DMX_REQUIRE(Cin <= PW_MAXC && Cout <= PW_MAXC && Cin > 0 && Cout > 0, "pointwise_small_bwd: Cin=%d Cout=%d must be <= 8", Cin, Cout);
+  DMX_REQUIRE(workspace && workspace_bytes >= dmx_pointwise_small_bwd_ws_bytes(M, Cin, Cout), "pointwise_small_bwd: workspace too small");
+  const int nblk = cdiv(M, 256);
+  hipLaunchKernelGGL(dmx_pointwise_small_bwd_kernel, dim3(nblk), dim3(256), 0, stream, x, ldx, dy, lddy, w, ldw, dx, lddx, (float*)workspace, M, Cin, Cout);
+  int rc = dmx_check_launch("dmx_pointwise_small_bwd_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dmx_pointwise_small_final_kernel, dim3(1), dim3(128), 0, stream, (const float*)workspace, nblk, Cin, Cout, dw, lddw, db);
+  return dmx_check_launch("dmx_pointwise_small_final_kernel");
+}
+int dmx_softmax_bwd_rows_launch(const bf16* P, int ldp, const float* dP, int lddp, bf16* dS, int ldds, int rows, int n, float scale, hipStream_t stream) {
+  hipLaunchKernelGGL(dmx_softmax_bwd_rows_kernel, dim3(rows), dim3(256), 0, stream, P, ldp, dP, lddp, dS, ldds, n, scale);
+  return dmx_check_launch("dmx_softmax_bwd_rows_kernel");
+}
 
 int dmx_transpose_bf16_launch(const bf16* in, int ldin, bf16* out, int ldout, int R, int C, hipStream_t stream) {
   hipLaunchKernelGGL(dmx_transpose_bf16_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, stream,

@@ -480,6 +480,17 @@ class _UNetTrainFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class _VAETrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.model = model
+        return model._train_forward(x)
+
+    @staticmethod
+    def backward(ctx, drecon):
+        return (None, None) + tuple(ctx.model._train_backward(drecon))
+
+
 def mse_loss(pred, target):
     """F.mse_loss(pred.float(), target.float(), reduction="mean") (train_diffute_v1.py:918) as a HIP kernel with its
     gradient: two-stage fixed-order fp32 reduction."""
@@ -577,8 +588,63 @@ class AutoencoderKL(_HipModel):
                                        _cabi.current_stream()), "vae_decode")
         return DecoderOutput(sample=img) if return_dict else (img,)
 
+    # ---- training (train_vae.py:716-736): recon = decode(encode(x).mode()) with a HIP backward
+    def _train_buffers(self):
+        lib = _cabi.lib()
+        tb = getattr(self, "_tb", None)
+        if tb is None or tb["wt"].device != self.device:
+            tb = self._tb = dict(wt=torch.empty(lib.dmx_vae_train_wt_bytes(self._h), dtype=torch.uint8, device=self.device),
+                                 grads=torch.empty(lib.dmx_vae_grad_bytes(self._h) // 4, dtype=torch.float32, device=self.device),
+                                 wt_sig=None, ws=None)
+        if tb["wt_sig"] != self._packed_sig:
+            _cabi.check(lib.dmx_vae_train_prepare(self._h, _cabi.ptr(tb["wt"]), tb["wt"].numel(), _cabi.current_stream()), "vae_train_prepare")
+            tb["wt_sig"] = self._packed_sig
+        return tb
+
+    def _param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in self._keys]
+
+    def _train_forward(self, x):
+        lib = _cabi.lib()
+        self._ensure_packed()
+        tb = self._train_buffers()
+        B, _, H, W = x.shape
+        need = lib.dmx_vae_train_workspace_bytes(self._h, B, H, W)
+        if tb["ws"] is None or tb["ws"].numel() < need:
+            tb["ws"] = None
+            tb["ws"] = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+        recon = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=x.device)
+        _cabi.check(lib.dmx_vae_train_forward(self._h, _cabi.ptr(tb["wt"]), _cabi.ptr(x), _cabi.ptr(recon), B, H, W,
+                                              _cabi.ptr(tb["ws"]), tb["ws"].numel(), _cabi.current_stream()), "vae_train_forward")
+        tb["fwd_stream"] = torch.cuda.current_stream(x.device)
+        return recon
+
+    def _train_backward(self, drecon):
+        lib = _cabi.lib()
+        tb = self._tb
+        drecon = drecon.to(torch.float32).contiguous()
+        out = []
+        with torch.cuda.stream(tb["fwd_stream"]):
+            st = _cabi.current_stream()
+            _cabi.check(lib.dmx_vae_train_backward(self._h, _cabi.ptr(tb["grads"]), _cabi.ptr(drecon), st), "vae_train_backward")
+            for k, p in zip(self._keys, self._param_list()):
+                g = torch.empty(p.shape, dtype=torch.float32, device=drecon.device)
+                _cabi.check(lib.dmx_vae_grad_export(self._h, _cabi.ptr(tb["grads"]), k.encode(), _cabi.ptr(g), st), "vae_grad_export")
+                out.append(g if p.dtype == torch.float32 else g.to(p.dtype))
+        torch.cuda.current_stream(drecon.device).wait_stream(tb["fwd_stream"])
+        return out
+
     def forward(self, sample, sample_posterior=False, return_dict=True, generator=None):
         """`vae(x)["sample"]` (train_vae.py:721-722): decode(encode(x).latent_dist.mode())."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if sample_posterior:
+                raise NotImplementedError("diffute_amd: the differentiable VAE path is vae(x) with the posterior MODE (train_vae.py:721)")
+            _cabi.require_cuda(sample)
+            if sample.shape[2] % 64 or sample.shape[3] % 64:
+                raise ValueError("AutoencoderKL training: image sides must be multiples of 64")
+            dec = _VAETrainFn.apply(self, sample.detach().to(torch.float32).contiguous(), *self._param_list())
+            return {"sample": dec} if return_dict else (dec,)
         post = self.encode(sample).latent_dist
         z = post.sample(generator=generator) if sample_posterior else post.mode()
         dec = self.decode(z).sample

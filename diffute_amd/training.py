@@ -64,3 +64,15 @@ def train_step(unet, vae, scheduler, optimizer, batch, *, noise=None, timesteps=
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
     return dict(loss=loss.detach(), grad_norm=grad_norm)
+
+
+def train_vae_step(vae, optimizer, images, target=None, max_grad_norm=None):
+    """One optimizer step of train_vae.py:716-736: pred = vae(x)["sample"] (decode of the posterior mode),
+    loss = mse_loss(pred.float(), target.float()), backward, optimizer step.  `target` defaults to the input images."""
+    pred = vae(images)["sample"]
+    loss = mse_loss(pred.float(), (images if target is None else target).float())
+    loss.backward()
+    grad_norm = torch.nn.utils.clip_grad_norm_(vae.parameters(), max_grad_norm) if max_grad_norm else None
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return dict(loss=loss.detach(), grad_norm=grad_norm)

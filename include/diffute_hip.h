@@ -270,6 +270,17 @@ int dmx_unet_train_tail_range(const dmx_unet* u, size_t* begin, size_t* end);
 int dmx_unet_train_backward(dmx_unet* u, void* grads, const float* dpred, void* const* events, int n_events, dmx_stream_t stream);
 int dmx_unet_grad_export(const dmx_unet* u, const void* grads, const char* name, float* dst, dmx_stream_t stream);
 int dmx_unet_grad_range(const dmx_unet* u, const char* name, size_t* begin, size_t* end);
+/* Training of the autoencoder (train_vae.py:716-736): recon = decode(encode(x).latent_dist.mode()),
+ * backward for dLoss/drecon.  Same protocol and gradient-arena convention as the UNet. */
+size_t dmx_vae_train_workspace_bytes(dmx_vae* v, int B, int H, int W);
+size_t dmx_vae_train_wt_bytes(const dmx_vae* v);
+int dmx_vae_train_prepare(dmx_vae* v, void* wt_arena, size_t wt_bytes, dmx_stream_t stream);
+size_t dmx_vae_grad_bytes(const dmx_vae* v);
+int dmx_vae_train_forward(dmx_vae* v, const void* wt_arena, const float* x, float* recon, int B, int H, int W,
+                          void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+int dmx_vae_train_backward(dmx_vae* v, void* grads, const float* drecon, dmx_stream_t stream);
+int dmx_vae_grad_export(const dmx_vae* v, const void* grads, const char* name, float* dst, dmx_stream_t stream);
+
 /* Fused AdamW + global-norm clipping over packed fp32 arenas (torch.optim.AdamW + clip_grad_norm_,
  * train_diffute_v1.py:721-727,927-930).  masters / exp_avg / exp_avg_sq / grads: dmx_unet_grad_bytes each.  The step also
  * rewrites the weights arena (bf16 weights, fp32 vectors) in place; afterwards call dmx_unet_refresh_derived (folded

@@ -75,3 +75,17 @@ def unet_train_grads(P, cfg, inp, timesteps, ctx, target, emulate_bf16=False):
         loss = torch.mean((pred.float() - target.float()) ** 2)
         loss.backward()
     return float(loss.detach()), pred.detach(), {k: p.grad for k, p in Pg.items()}
+
+
+def vae_train_grads(P, cfg, x, target, emulate_bf16=False):
+    """Loss and parameter gradients of one autoencoder training step (train_vae.py:716-736: `pred = vae(x)["sample"]` =
+    decode(encode(x).latent_dist.mode()); `loss = F.mse_loss(pred.float(), target.float())`; backward), by torch autograd
+    over the restatement.  Returns (loss, recon, {name: grad})."""
+    from .vae import gaussian_mode, vae_decode, vae_encode_moments
+    Pg = {k: v.detach().clone().to(torch.float32).requires_grad_(True) for k, v in P.items()}
+    with torch.enable_grad():
+        z = gaussian_mode(vae_encode_moments.__wrapped__(Pg, cfg, x, emulate_bf16=emulate_bf16))
+        recon = vae_decode.__wrapped__(Pg, cfg, z, emulate_bf16=emulate_bf16)
+        loss = torch.mean((recon.float() - target.float()) ** 2)
+        loss.backward()
+    return float(loss.detach()), recon.detach(), {k: p.grad for k, p in Pg.items()}

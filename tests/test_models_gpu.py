@@ -409,3 +409,36 @@ def test_full_glyph_encoder_properties(cuda):
     ref = OVT.vit_forward(P, OVT.TROCR_LARGE_VIT, px[:1].cpu(), emulate_bf16=True)
     e = assert_close(y0, ref, E2E_EMU, "TrOCR-large encoder vs bf16-emulating oracle")
     print(f"full glyph encoder rel-L2 vs bf16emu oracle {e:.2e}")
+
+
+# ------------------------------------------------------------------------------------------------ VAE training (N4)
+def test_tiny_vae_train_step(cuda):
+    """N4: one autoencoder training step (train_vae.py:721-724) on the tiny VAE: HIP forward that keeps activations + HIP
+    backward vs torch autograd over the oracle.  Loss within 2 %, whole-gradient rel-L2 <= 5e-2, worst parameter <= 1.5e-1."""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from oracle import pipeline as OP, vae as OV
+    vae = D.AutoencoderKL(**TINY_VAE).cuda()
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).cuda()
+    tgt = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).cuda()
+    recon = vae(x)["sample"]
+    loss = mse_loss(recon, tgt)
+    loss.backward()
+    P = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+    for em in (True, False):
+        rl, rrec, rg = OP.vae_train_grads(P, OV.TINY_VAE, x.cpu(), tgt.cpu(), emulate_bf16=em)
+        assert_close(recon.detach(), rrec, 5e-2, "vae train forward")
+        assert abs(float(loss.detach()) - rl) <= 2e-2 * abs(rl)
+        errs = []; num = den = 0.0
+        for k, p in vae.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            gh = p.grad.float().cpu(); gr = rg[k]
+            num += float((gh - gr).pow(2).sum()); den += float(gr.pow(2).sum())
+            if not k.endswith("to_k.bias"):      # d/d(b_k) is exactly 0 in exact arithmetic (softmax is shift-invariant per row): pure noise
+                errs.append((rel_l2(gh, gr), k))
+        errs.sort(reverse=True)
+        tot = (num / den) ** 0.5
+        print(f"tiny VAE train step vs {'bf16-emulating' if em else 'fp32'} oracle: loss {float(loss.detach()):.6f} ({rl:.6f}); whole-gradient rel-L2 {tot:.2e}; "
+              "worst: " + ", ".join(f"{k} {e:.2e}" for e, k in errs[:4]))
+        assert tot <= 5e-2 and errs[0][0] <= 1.5e-1, f"gradient mismatch: whole {tot:.3e}, worst {errs[0]}"
