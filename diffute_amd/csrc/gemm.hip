@@ -13,15 +13,14 @@
 // K-segment appends the 1x1 shortcut of a ResnetBlock2D so conv2 + shortcut + residual
 // is one launch.
 //
-// Tiling: block = 256 threads = 4 waves (2 along m x 2 along n); block tile 128(m) x
-// {128,64}(n) x 32(k); per wave 2 x TN MFMA tiles of v_mfma_f32_32x32x16_bf16.  The
-// weight tile is the MFMA A operand (rows = n) and the activation tile the B operand
-// (cols = m) so each lane ends up with 4 consecutive output channels of one pixel
-// (8-byte bf16 / 16-byte fp32 stores).  LDS tiles are [rows][32] bf16 (64-byte rows) with
-// the 16-byte k-chunk XOR-swizzled by ((row>>2)&3) on the SOURCE side (glds writes
-// lane-linear), which makes the ds_read_b128 fragment reads bank-conflict free.  A 4-deep
-// LDS ring (64 KB at BN=128 -> 2 blocks per CU) keeps three K-tiles of DMA in flight behind
-// a counted `s_waitcnt vmcnt(N)` + raw s_barrier; the queue is never drained inside the loop.
+// Tiling (template dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP>): 2*WM MFMA waves (WM along m x 2 along n), each a
+// (32*TM) x (32*TN) sub-tile of v_mfma_f32_32x32x16_bf16; NP extra waves only issue DMA (warp specialisation).  The
+// weight tile is the MFMA A operand (rows = n) and the activation tile the B operand (cols = m) so each lane ends up
+// with 4 consecutive output channels of one pixel.  LDS tiles are [rows][BKT] bf16 (64- or 128-byte rows) with the
+// 16-byte k-chunk XOR-swizzled on the SOURCE side (glds writes lane-linear), which makes the ds_read_b128 fragment
+// reads bank-conflict free.  An NSTAGE-deep LDS ring keeps NSTAGE-1 K-tiles of DMA in flight behind a counted
+// `s_waitcnt vmcnt(N)` + raw s_barrier; the queue is never drained inside the loop.  The instances and what each is for
+// are listed at kCfg below; DESIGN.md section 4 has the measurements behind them.
 #include "common.h"
 #include "kernels.h"
 #include <stdio.h>
@@ -35,13 +34,15 @@ struct RowSrc {          // per-thread state for one staged activation row
   int valid;             // m < M
 };
 
-// Tile configurations (WM waves along m x 2 along n, each wave a 64 x 32*TN sub-tile; BKT = K-tile depth):
-//   <2,2,32>  128x128x32, 256 thr, 4-stage ring  64 KB -> 2 blocks/CU   (mid-size GEMMs)
-//   <2,1,32>  128x 64x32, 256 thr, 4-stage ring  48 KB -> 3 blocks/CU   (N <= 64, small grids)
-//   <4,2,64>  256x128x64, 512 thr, 3-stage ring 144 KB -> 1 block/CU    (large GEMMs: 128-byte DMA rows, 85 FLOP/B)
-//   <2,2,64,3,TM=4,NP=4>  warp-specialised 256x128x64: waves 0-3 are consumers (each a 128x64 MFMA sub-tile), waves 4-7
-//             only issue the LDS-DMA refills - a DMA instruction stalls its wave ~100 cycles, so keeping them off the
-//             MFMA waves lets the matrix pipe and the DMA queue run concurrently.
+// Tile configurations (plan id -> instance), see kCfg:
+//   0 <2,2,32,4>      128x128x32, 4 waves, 64 KB ring -> 2 blocks/CU   (mid-size GEMMs, split-K convolutions)
+//   1 <2,1,32,4>      128x 64x32, 4 waves, 48 KB                        (N <= 64)
+//   2 <4,2,64,3>      256x128x64, 8 waves, 144 KB -> 1 block/CU         (large GEMMs: 128-byte DMA rows, 85 FLOP/B)
+//   6 <2,2,64,3,4,4>  warp-specialised 256x128x64: waves 0-3 MFMA (128x64 sub-tiles, software-pipelined fragment reads),
+//                     waves 4-7 issue the LDS-DMA refills                (large K)
+//   7..9 <4,1,64,3,1> / <4,2,32,4,1> / <4,2,64,3,1>  128x64 / 128x128 tiles with EIGHT waves (32x32 / 32x64 sub-tiles): small
+//                     grids are bound by the per-CU LDS-DMA fill rate, which doubles with 8 issuing waves
+//   3, 4, 5           deep-ring and 256x256 experiments, force_tn only
 // measurement aid: 100 MHz wall ticks, or (dbg bit 2) shader-clock cycles - their ratio is the effective clock
 __device__ __forceinline__ long long dmx_now(int dbg) {
   return (dbg & 4) ? (long long)__builtin_amdgcn_s_memtime() : (long long)__builtin_amdgcn_s_memrealtime();
