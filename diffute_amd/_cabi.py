@@ -133,7 +133,7 @@ _PROTOS = {
     "dmx_unet_optim_elements": (c_size_t, [_P]),
     "dmx_unet_optim_table": (c_int, [_P, _P, c_size_t, _P]),
     "dmx_unet_master_import": (c_int, [_P, _P, c_char_p, _P, _P]),
-    "dmx_unet_adamw_step": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P, c_size_t, _P]),
+    "dmx_unet_adamw_step": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P, c_size_t, _P, c_float, _P]),
     "dmx_unet_refresh_derived": (c_int, [_P, _P]),
     "dmx_mse_loss_workspace_bytes": (c_size_t, []),
     "dmx_mse_loss": (c_int, [_P, _P, c_size_t, _P, _P, c_float, _P, c_size_t, _P]),

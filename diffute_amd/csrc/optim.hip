@@ -74,7 +74,8 @@ __global__ __launch_bounds__(1024) void dmx_clip_coef_kernel(const float* part, 
   }
 }
 __global__ __launch_bounds__(256) void dmx_adamw_kernel(const OptChunk* tab, float* p, float* m, float* v, const float* g, char* arena,
-                                                        const float* scal, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                                        const float* scal, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                        float* ema, float ema_omd) {
   const OptChunk c = tab[blockIdx.x];
   const float clip = scal[1];
   const float step_size = lr / bc1;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void dmx_adamw_kernel(const OptChunk* tab, flo
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     pv -= step_size * (mv / denom);
     p[j] = pv; m[j] = mv; v[j] = vv;
+    if (ema) { const float e = ema[j]; ema[j] = e - ema_omd * (e - pv); }          // EMAModel.step: s.sub_((1 - decay) * (s - p))
     if (c.is_bf16) ((unsigned short*)(arena + c.arena_off))[i] = f2bf_bits(pv);
     else ((float*)(arena + c.arena_off))[i] = pv;
   }
@@ -154,10 +156,13 @@ extern "C" int dmx_unet_master_import(const dmx_unet* u, void* masters, const ch
   return dmx_check_launch("dmx_master_pack_kernel");
 }
 
-// scalars: device float[2] = (gradient norm before clipping, clip coefficient); workspace: nchunks floats
+// scalars: device float[2] = (gradient norm before clipping, clip coefficient); workspace: nchunks floats.
+// ema (optional, fp32 arena with the masters' layout): shadow parameters updated in the same pass with
+// ema -= (1 - ema_decay) * (ema - p_new)   (diffusers EMAModel.step, the reference's `ema_unet.step(unet.parameters())`,
+// train_diffute_v1.py:934-935); the caller owns the decay schedule.
 extern "C" int dmx_unet_adamw_step(dmx_unet* u, const void* table_dev, int nchunks, void* masters, void* exp_avg, void* exp_avg_sq, const void* grads,
                                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_grad_norm,
-                                   float* scalars, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+                                   float* scalars, void* workspace, size_t workspace_bytes, void* ema, float ema_decay, dmx_stream_t stream) {
   DMX_REQUIRE(u && u->arena && table_dev && masters && exp_avg && exp_avg_sq && grads && scalars, "unet_adamw_step: null argument");
   DMX_REQUIRE(nchunks > 0 && step >= 1, "unet_adamw_step: bad chunk count / step");
   DMX_REQUIRE(workspace && workspace_bytes >= (size_t)nchunks * sizeof(float), "unet_adamw_step: workspace too small");
@@ -171,7 +176,8 @@ extern "C" int dmx_unet_adamw_step(dmx_unet* u, const void* table_dev, int nchun
   if (rc) return rc;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(dmx_adamw_kernel, dim3(nchunks), dim3(256), 0, s, tab, (float*)masters, (float*)exp_avg, (float*)exp_avg_sq, (const float*)grads,
-                     u->arena, (const float*)scalars, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+                     u->arena, (const float*)scalars, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
+                     (float*)ema, 1.0f - ema_decay);
   rc = dmx_check_launch("dmx_adamw_kernel");
   if (rc) return rc;
   u->drop_graphs();                      // captured inference graphs hold no weights, but folded copies are stale until refreshed

@@ -5,7 +5,11 @@ Reference: `torch.optim.AdamW(unet.parameters(), lr, betas, weight_decay, eps)` 
 (torch's single-tensor AdamW formulas, fp32), but one pass over the gradient arena the HIP backward already filled:
 no per-parameter gradient export, no 686-tensor optimizer loop, no re-pack of the weights (the kernel writes the bf16 /
 fp32 compute copies in place).  The torch Parameters are refreshed from the master arena on demand (`sync_to_model`,
-done automatically by `state_dict()` / `save_pretrained()`)."""
+done automatically by `state_dict()` / `save_pretrained()`).
+
+`ema_decay` adds the reference's `--use_ema` shadow copy (`EMAModel(ema_unet.parameters(), ...)` + `ema_unet.step(...)` after
+every optimizer step, train_diffute_v1.py:642-646,934-935) as a fourth fp32 arena updated inside the same kernel pass;
+the decay schedule is diffusers' `EMAModel.get_decay`."""
 import ctypes
 
 import torch
@@ -14,8 +18,11 @@ from . import _cabi
 
 
 class FusedAdamW:
-    def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0):
+    def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0,
+                 ema_decay=None, ema_min_decay=0.0, ema_update_after_step=0, ema_use_warmup=False, ema_inv_gamma=1.0, ema_power=2.0 / 3.0):
         self.unet = unet
+        self.ema_decay, self.ema_min_decay, self.ema_update_after_step = ema_decay, float(ema_min_decay), int(ema_update_after_step)
+        self.ema_use_warmup, self.ema_inv_gamma, self.ema_power = bool(ema_use_warmup), float(ema_inv_gamma), float(ema_power)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = float(lr), tuple(betas), float(eps), float(weight_decay), float(max_grad_norm or 0.0)
         self.t = 0
         lib = _cabi.lib()
@@ -29,6 +36,7 @@ class FusedAdamW:
         for k, p in zip(unet._keys, unet._param_list()):
             src = p.detach().to(torch.float32).contiguous()
             _cabi.check(lib.dmx_unet_master_import(unet._h, _cabi.ptr(self.masters), k.encode(), _cabi.ptr(src), st), f"master_import({k})")
+        self.ema = self.masters.clone() if ema_decay is not None else None      # shadow parameters start as a copy of the model
         self.nchunks = lib.dmx_unet_optim_chunks(unet._h)
         self.table = torch.empty(lib.dmx_unet_optim_table_bytes(unet._h), dtype=torch.uint8, device=dev)
         _cabi.check(lib.dmx_unet_optim_table(unet._h, _cabi.ptr(self.table), self.table.numel(), st), "optim_table")
@@ -40,6 +48,14 @@ class FusedAdamW:
     @property
     def grad_norm(self):
         return self.scalars[0]
+
+    def ema_decay_at(self, optimization_step):
+        """diffusers EMAModel.get_decay (the value used by the `optimization_step`-th call of EMAModel.step)"""
+        step = max(0, optimization_step - self.ema_update_after_step - 1)
+        if step <= 0:
+            return 0.0
+        cur = 1.0 - (1.0 + step / self.ema_inv_gamma) ** -self.ema_power if self.ema_use_warmup else (1.0 + step) / (10.0 + step)
+        return max(min(cur, float(self.ema_decay)), self.ema_min_decay)
 
     def zero_grad(self, set_to_none=True):
         """the backward overwrites the gradient arena; nothing to clear"""
@@ -53,12 +69,28 @@ class FusedAdamW:
         _cabi.check(lib.dmx_unet_adamw_step(u._h, _cabi.ptr(self.table), self.nchunks, _cabi.ptr(self.masters), _cabi.ptr(self.exp_avg),
                                             _cabi.ptr(self.exp_avg_sq), _cabi.ptr(tb["grads"]), self.lr, self.betas[0], self.betas[1], self.eps,
                                             self.weight_decay, self.t, self.max_grad_norm, _cabi.ptr(self.scalars),
-                                            _cabi.ptr(self.ws), self.ws.numel() * 4, st), "adamw_step")
+                                            _cabi.ptr(self.ws), self.ws.numel() * 4,
+                                            _cabi.ptr(self.ema) if self.ema is not None else None,
+                                            self.ema_decay_at(self.t) if self.ema is not None else 0.0, st), "adamw_step")
         _cabi.check(lib.dmx_unet_refresh_derived(u._h, st), "refresh_derived")
         u._arena_version = getattr(u, "_arena_version", 0) + 1      # transposed weights are refreshed by the next training forward
         for sl in u._slots.values():
             sl["ctx_key"] = None                                     # cached context K/V were projected with the old weights
         self.dirty = True
+
+    def ema_state_dict(self):
+        """the EMA shadow parameters as fp32 tensors in torch layouts (what `ema_unet.save_pretrained` would store)"""
+        if self.ema is None:
+            raise RuntimeError("FusedAdamW was built without ema_decay")
+        lib = _cabi.lib()
+        u = self.unet
+        st = _cabi.current_stream()
+        out = {}
+        for k, p in zip(u._keys, u._param_list()):
+            dst = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+            _cabi.check(lib.dmx_unet_grad_export(u._h, _cabi.ptr(self.ema), k.encode(), _cabi.ptr(dst), st), "ema_export")
+            out[k] = dst
+        return out
 
     def sync_to_model(self):
         """master arena -> the torch Parameters (fp32, torch layouts)"""

@@ -285,7 +285,9 @@ int dmx_vae_grad_export(const dmx_vae* v, const void* grads, const char* name, f
  * train_diffute_v1.py:721-727,927-930).  masters / exp_avg / exp_avg_sq / grads: dmx_unet_grad_bytes each.  The step also
  * rewrites the weights arena (bf16 weights, fp32 vectors) in place; afterwards call dmx_unet_refresh_derived (folded
  * LayerNorm / bias copies of the inference graph) and dmx_unet_train_prepare (transposed weights).
- * scalars: device float[2] = (gradient norm before clipping, clip coefficient). */
+ * scalars: device float[2] = (gradient norm before clipping, clip coefficient).
+ * ema (optional, may be NULL): fp32 shadow arena of the same layout, updated in the same pass with
+ * ema -= (1 - ema_decay) * (ema - p_new)  (diffusers EMAModel.step; `ema_unet.step(unet.parameters())`, :934-935). */
 int dmx_unet_optim_chunks(const dmx_unet* u);
 size_t dmx_unet_optim_table_bytes(const dmx_unet* u);
 size_t dmx_unet_optim_elements(const dmx_unet* u);
@@ -293,7 +295,7 @@ int dmx_unet_optim_table(const dmx_unet* u, void* table_dev, size_t bytes, dmx_s
 int dmx_unet_master_import(const dmx_unet* u, void* masters, const char* name, const float* src, dmx_stream_t stream);
 int dmx_unet_adamw_step(dmx_unet* u, const void* table_dev, int nchunks, void* masters, void* exp_avg, void* exp_avg_sq, const void* grads,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_grad_norm,
-                        float* scalars, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+                        float* scalars, void* workspace, size_t workspace_bytes, void* ema, float ema_decay, dmx_stream_t stream);
 int dmx_unet_refresh_derived(dmx_unet* u, dmx_stream_t stream);
 size_t dmx_mse_loss_workspace_bytes(void);
 int dmx_mse_loss(const float* pred, const float* target, size_t n, float* loss, float* dpred, float grad_scale,

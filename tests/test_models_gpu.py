@@ -369,6 +369,37 @@ def test_fused_adamw_matches_torch(cuda):
     assert_close(b, a.cpu(), 2e-2, "forward after fused optimizer steps")
 
 
+def test_fused_adamw_ema_shadow(cuda):
+    """`--use_ema` (train_diffute_v1.py:642-646,934-935): the shadow arena updated inside the fused optimizer pass follows
+    diffusers' EMAModel.step recurrence  s -= (1 - decay_k) * (s - p_k)  with decay_k = min(decay, (1 + k') / (10 + k')),
+    k' = max(0, k - update_after_step - 1), applied to the parameters the optimizer just produced."""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from diffute_amd.synthetic import synth_inputs
+    lat, mask, mlat, ctx = synth_inputs(1, 8, 8, 20, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1); t = torch.tensor([300], device=cuda); target = torch.zeros(1, 4, 8, 8, device=cuda)
+    unet = D.UNet2DConditionModel(**TINY_UNET).cuda()
+    opt = D.FusedAdamW(unet, lr=1e-3, max_grad_norm=1.0, ema_decay=0.9999)
+    shadow = {k: v.detach().clone().float() for k, v in unet.state_dict().items()}
+    for k in range(1, 5):
+        mse_loss(unet(x, t, ctx).sample, target).backward()
+        opt.step()
+        step = max(0, k - 0 - 1)
+        decay = 0.0 if step <= 0 else min(0.9999, (1 + step) / (10 + step))
+        assert abs(opt.ema_decay_at(k) - decay) < 1e-12
+        params = unet.state_dict()
+        for name in shadow:
+            shadow[name] = shadow[name] - (1 - decay) * (shadow[name] - params[name].float())
+    ema = opt.ema_state_dict()
+    assert set(ema) == set(shadow)
+    worst = max(float((ema[n] - shadow[n]).abs().max() / (shadow[n].abs().max() + 1e-12)) for n in shadow)
+    assert worst <= 1e-6, f"EMA shadow parameters deviate from the EMAModel recurrence: {worst:.2e}"
+    moved = max(float((ema[n] - params[n].float()).abs().max()) for n in shadow)
+    assert moved > 0, "the shadow copy must lag the parameters"
+    with pytest.raises(RuntimeError):
+        D.FusedAdamW(D.UNet2DConditionModel(**TINY_UNET).cuda()).ema_state_dict()
+
+
 # ------------------------------------------------------------------------------------------------ glyph encoder (N1)
 TINY_VIT = dict(image_size=64, patch_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, qkv_bias=True)
 
