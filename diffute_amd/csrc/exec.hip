@@ -142,8 +142,10 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
     a.C = C; a.groups = groups; a.B = x0.B; a.HW = x0.H * x0.W;
     a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu ? 1 : 0;
     a.y = y.p; a.ldy = y.ld; a.partial = (float*)part;
-    char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d", x0.rows(), C);
-    ProfScope ps(PROF_GNORM, stream, 0.0, 6.0 * (double)x0.rows() * C, tag);     // read x twice (stats, apply) + write y, bf16
+    const bool one = dmx_gn_single_launch(a);
+    char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d%s", x0.rows(), C, one ? " slab" : "");
+    // bf16: read x + write y when the slab stays in registers, otherwise x is read twice (stats, apply)
+    ProfScope ps(PROF_GNORM, stream, 0.0, (one ? 4.0 : 6.0) * (double)x0.rows() * C, tag);
     rc = dmx_groupnorm_launch(a, stream);
   }
   ws.release(part);

@@ -88,6 +88,7 @@ struct GroupNormArgs {
 };
 size_t dmx_gn_workspace_bytes(int B, int HW, int groups);
 int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream);
+bool dmx_gn_single_launch(GroupNormArgs a);   // the register-resident one-launch path applies to this shape
 int dmx_layernorm_launch(const bf16* x, int ldx, bf16* y, int ldy, const float* gamma, const float* beta,
                          int rows, int C, float eps, hipStream_t stream);
 

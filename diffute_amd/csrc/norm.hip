@@ -2,7 +2,8 @@
 //
 // Both are HBM-bound: every load/store is 16 B per lane (8 bf16), statistics in fp32.
 //
-// GroupNorm is two launches and deterministic (no float atomics):
+// GroupNorm is ONE launch when a (sample, group) slab fits the registers of a 1024-thread block (every shape of the
+// 512-px pipeline; dmx_gn_slab_kernel below), otherwise two launches; both are deterministic (no float atomics):
 //   stats : grid (nchunk, B); each block reduces rows_per_chunk pixels x C channels to
 //           per-group (sum, sumsq) partials  -> partial[b][chunk][g][2]
 //   apply : grid (row blocks, B); a parallel prologue folds the <=256 partials of its sample in a
@@ -12,6 +13,7 @@
 // torch.cat([h, skip], 1) is never materialised.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ const bf16* gn_src(const GroupNormArgs& p, size_t row, int c) {
   return (c < p.c0) ? (p.x0 + row * p.ldx0 + c) : (p.x1 + row * p.ldx1 + (c - p.c0));
@@ -149,6 +151,179 @@ __global__ __launch_bounds__(1024) void dmx_gn_apply_kernel(const GroupNormArgs 
   }
 }
 
+// ---- single-launch GroupNorm ("slab" kernel): one block owns one (sample, group) slab - HW pixels x cpg channels,
+// 5..240 KB of bf16 - and keeps it in REGISTERS between the statistics and the normalisation: one read, one write,
+// one launch, no partials buffer and no grid-wide dependency.  Thread = (pixel lane r, unit `within` of the pixel's
+// cpg-channel segment); a unit is VEC dwords (2*VEC channels), so the per-thread channel affine sits in registers and
+// the pixel stride R is a constant.  The variance is taken about the mean (second pass over the registers).
+// Blocks are dealt to XCDs round-robin, so XCD x gets the groups [x*G/8, (x+1)*G/8): a contiguous channel band whose
+// cache lines it shares with a neighbour only at the band edges.
+template <int VEC> struct GnVec;
+template <> struct GnVec<1> { typedef unsigned int T; };
+template <> struct GnVec<2> { typedef u32x2 T; };
+template <> struct GnVec<4> { typedef u32x4 T; };
+template <int VEC> __device__ __forceinline__ unsigned int gn_dw(const typename GnVec<VEC>::T& v, int i) { return v[i]; }
+template <> __device__ __forceinline__ unsigned int gn_dw<1>(const unsigned int& v, int) { return v; }
+template <int VEC> __device__ __forceinline__ void gn_set(typename GnVec<VEC>::T& v, int i, unsigned int x) { v[i] = x; }
+template <> __device__ __forceinline__ void gn_set<1>(unsigned int& v, int, unsigned int x) { v = x; }
+
+__device__ __forceinline__ float gn_block_sum(float v, float* red, int t, int nw) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  __syncthreads();                                   // `red` may still be read from the previous reduction
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  float a = 0.f;
+  for (int k = 0; k < nw; ++k) a += red[k];          // every thread folds the wave sums in the same fixed order
+  return a;
+}
+
+template <int VEC, int NU, bool SILU>
+__global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p, int SU, int R, int dbg) {
+  typedef typename GnVec<VEC>::T V;
+  typedef __attribute__((address_space(1))) V GV;   // the opaque running pointers lose their address space: say global again
+  __shared__ float red[16];
+  __shared__ float AF[2][128];
+  const int t = threadIdx.x, nw = (blockDim.x + 63) >> 6;
+  const int G = p.groups;
+  int b, g;
+  if ((G & 7) == 0) { const int gpx = G >> 3, j = blockIdx.x >> 3; b = j / gpx; g = (blockIdx.x & 7) * gpx + j % gpx; }
+  else { b = blockIdx.x / G; g = blockIdx.x - b * G; }
+  const int cpg = p.C / G;
+  const int within = t % SU, r = t / SU;
+  const bool active = r < R;
+  const int c = g * cpg + within * 2 * VEC;          // first channel of this thread's unit
+  const bf16* src; int ld;
+  if (c < p.c0) { src = p.x0 + c; ld = p.ldx0; } else { src = p.x1 + (c - p.c0); ld = p.ldx1; }
+  src += (size_t)b * p.HW * ld;
+  V v[NU];
+  float s = 0.f;
+  // Branch-free on purpose: a conditional load makes the compiler carry the whole register-resident slab through a
+  // phi per unit (and spill it).  Out-of-range units re-read the slab's first pixel and are masked in the arithmetic.
+  // One running pointer per direction, stepped by a constant stride and made opaque to the optimiser: otherwise it
+  // materialises all NU 64-bit addresses up front.
+  const char* const safe = (const char*)src;
+  const char* lp = (const char*)(src + (size_t)r * ld);
+  const size_t lstep = (size_t)R * ld * 2;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const bool ok = active && (r + k * R < p.HW);
+    asm volatile("" : "+v"(lp));
+    v[k] = *(const GV*)((ok && !(dbg & 2)) ? lp : safe);
+    lp += lstep;
+    __builtin_amdgcn_sched_barrier(0);               // issue each load before forming the next address
+  }
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const bool ok = active && (r + k * R < p.HW);
+    float u = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const unsigned int w = gn_dw<VEC>(v[k], i);
+      u += __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
+    }
+    s += ok ? u : 0.f;
+  }
+  const float inv_n = 1.0f / ((float)p.HW * (float)cpg);
+  const float mean = gn_block_sum(s, red, t, nw) * inv_n;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const bool ok = active && (r + k * R < p.HW);
+    float u = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const unsigned int w = gn_dw<VEC>(v[k], i);
+      const float d0 = __uint_as_float(w << 16) - mean, d1 = __uint_as_float(w & 0xffff0000u) - mean;
+      u += d0 * d0 + d1 * d1;
+    }
+    q += ok ? u : 0.f;
+  }
+  const float var = gn_block_sum(q, red, t, nw) * inv_n;
+  const float rstd = rsqrtf(var + p.eps);
+  if (t < cpg) {
+    const float a = rstd * p.gamma[g * cpg + t];
+    AF[0][t] = a; AF[1][t] = p.beta[g * cpg + t] - mean * a;
+  }
+  if (t == 0 && p.stats_out) { p.stats_out[((size_t)b * G + g) * 2] = mean; p.stats_out[((size_t)b * G + g) * 2 + 1] = rstd; }
+  __syncthreads();
+  float A[2 * VEC], Bv[2 * VEC];
+#pragma unroll
+  for (int e = 0; e < 2 * VEC; ++e) { A[e] = AF[0][within * 2 * VEC + e]; Bv[e] = AF[1][within * 2 * VEC + e]; }
+  float A2[2 * VEC], B2[2 * VEC];
+#pragma unroll
+  for (int e = 0; e < 2 * VEC; ++e) { A2[e] = -1.44269504088896f * A[e]; B2[e] = -1.44269504088896f * Bv[e]; }
+  const size_t sstep = (size_t)R * p.ldy * 2;
+  {
+    char* sp = (char*)(p.y + ((size_t)b * p.HW + r) * p.ldy + c);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      if (k * R >= p.HW) break;                        // uniform: the instance may hold more units than this shape has
+      const bool ok = active && (r + k * R < p.HW);
+      asm volatile("" : "+v"(sp));
+      V o;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const unsigned int w = gn_dw<VEC>(v[k], i);
+        const float x0 = __uint_as_float(w << 16), x1 = __uint_as_float(w & 0xffff0000u);
+        float y0 = __builtin_fmaf(x0, A[2 * i], Bv[2 * i]);
+        float y1 = __builtin_fmaf(x1, A[2 * i + 1], Bv[2 * i + 1]);
+        if (SILU) {
+          // y * sigmoid(y) = y * rcp(1 + 2^(-y*log2(e))); the exponent comes from its own fma with pre-scaled affine
+          // terms and v_rcp_f32 (1 ulp) replaces an IEEE division: the kernel is VALU-bound and the result is
+          // rounded to bf16 anyway
+          y0 *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(x0, A2[2 * i], B2[2 * i])));
+          y1 *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(x1, A2[2 * i + 1], B2[2 * i + 1])));
+        }
+        gn_set<VEC>(o, i, pack_bf2(y0, y1));
+      }
+      if (ok && !(dbg & 1)) *(GV*)sp = o;
+      sp += sstep;
+      __builtin_amdgcn_sched_barrier(0);             // finish a unit before starting the next: bounded live ranges
+    }
+  }
+}
+
+// picks the slab instance for (C, groups, HW), or returns false (shape outside the register budget -> two-pass path)
+static bool gn_slab_launch(const GroupNormArgs& a, hipStream_t stream, bool dry = false) {
+  const int cpg = a.C / a.groups;
+  if (cpg & 1 || cpg > 128 || a.B * a.groups > 65535) return false;
+  const int vec = (cpg % 8 == 0) ? 4 : (cpg % 4 == 0) ? 2 : 1;
+  if (a.c0 % (2 * vec) || a.ldx0 % (2 * vec) || a.ldx1 % (2 * vec) || a.ldy % (2 * vec)) return false;
+  // measured (B=4, MI355X): thin segments (< 40 B per pixel: dword accesses, ~13 cache lines per wave instruction) over
+  // many pixels are slower than the two coalesced streaming passes; everything else gains 3-8 us per GroupNorm
+  if (cpg * 2 < 40 && a.HW > 1024) return false;
+  const int SU = cpg / (2 * vec);
+  int R = 1024 / SU; if (R > a.HW) R = a.HW;
+  const int nu = cdiv(a.HW, R);
+  const int threads = cdiv(R * SU, 64) * 64;
+  const dim3 grid(a.B * a.groups), block(threads);
+  static const int dbg = getenv("DMX_GN_SLAB_DBG") ? atoi(getenv("DMX_GN_SLAB_DBG")) : 0;   // measurement aid: 1 = no stores, 2 = no loads
+#define GN_SLAB(V_, N_)                                                                                      \
+  if (vec == V_ && nu <= N_) {                                                                              \
+    if (dry) return true;                                                                                   \
+    if (a.silu) hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, true>), grid, block, 0, stream, a, SU, R, dbg);    \
+    else hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, false>), grid, block, 0, stream, a, SU, R, dbg);          \
+    return true;                                                                                            \
+  }
+  // (instances whose slab would spill - 64 x 1, 44 x 2, 16 x 4 dwords per thread - are not built: those shapes take the two-launch path)
+  GN_SLAB(1, 8) GN_SLAB(1, 24)
+  GN_SLAB(2, 4) GN_SLAB(2, 16)
+  GN_SLAB(4, 2) GN_SLAB(4, 4) GN_SLAB(4, 8)
+#undef GN_SLAB
+  return false;
+}
+
+static bool gn_two_pass_forced() {
+  static const bool off = getenv("DMX_GN_TWO_PASS") != nullptr;          // measurement aid: force the two-launch path
+  return off;
+}
+// true when dmx_groupnorm_launch will take the single-launch path for this shape (1 read + 1 write of the tensor)
+bool dmx_gn_single_launch(GroupNormArgs a) {
+  if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; }
+  return !gn_two_pass_forced() && a.C % a.groups == 0 && gn_slab_launch(a, nullptr, true);
+}
+
 #define GN_MAX_CHUNKS 256
 size_t dmx_gn_workspace_bytes(int B, int HW, int groups) {
   // partials [B][<=256 chunks][groups][2] + per-channel affine [B][C<=2560][2]
@@ -162,6 +337,8 @@ int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream) {
   DMX_REQUIRE(a.c0 % 8 == 0 && a.ldx0 % 8 == 0 && a.ldy % 8 == 0, "groupnorm: strides/splits must be multiples of 8");
   DMX_REQUIRE(a.partial != nullptr, "groupnorm: partial workspace is null");
   if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; }
+  if (!gn_two_pass_forced() && gn_slab_launch(a, stream)) return dmx_check_launch("dmx_gn_slab_kernel");
+  // ---- two-launch path (slabs that do not fit the register budget, e.g. 1024-px images)
   // thread = (row lane r < R, channel octet); wide blocks so each thread walks only a few rows
   const int oc = a.C / 8;
   int R = 1024 / oc; if (R > 16) R = 16; if (R < 1) R = 1;

@@ -136,7 +136,11 @@ def test_geglu(cuda):
 
 GN_CASES = [("gn_320_silu", 2, 16, 16, 320, 0, True, 1e-5), ("gn_960_concat", 2, 8, 8, 640, 320, True, 1e-5),
             ("gn_1920_concat", 1, 16, 16, 1280, 640, True, 1e-5), ("gn_2560", 1, 8, 8, 1280, 1280, True, 1e-5),
-            ("gn_128_nosilu_eps6", 1, 64, 64, 128, 0, False, 1e-6), ("gn_64_oddHW", 1, 12, 12, 64, 0, True, 1e-6)]
+            ("gn_128_nosilu_eps6", 1, 64, 64, 128, 0, False, 1e-6), ("gn_64_oddHW", 1, 12, 12, 64, 0, True, 1e-6),
+            # the register-resident single-launch instances at their largest slabs, and (640 @ 64x64) the two-launch path
+            ("gn_320_64x64", 1, 64, 64, 320, 0, True, 1e-5), ("gn_640_32x32", 2, 32, 32, 640, 0, True, 1e-5),
+            ("gn_1280_32x32", 1, 32, 32, 1280, 0, False, 1e-5), ("gn_1280_24x24", 1, 24, 24, 1280, 0, True, 1e-5),
+            ("gn_960_concat_32x32", 1, 32, 32, 640, 320, True, 1e-5), ("gn_640_64x64_twopass", 1, 64, 64, 640, 0, True, 1e-5)]
 
 
 @pytest.mark.parametrize("case", GN_CASES, ids=[c[0] for c in GN_CASES])
