@@ -106,7 +106,9 @@ def main():
     assert torch.isfinite(out).all(), "non-finite latents"
     ms_per_step = 1e3 * elapsed / args.steps
 
-    loop_flops = T * unet_flops(unet.config, B, hw, hw, 577, True) + context_kv_flops(unet.config, B, 577)
+    # executed work: the upsampler convs run phase-decomposed (4/9 of the reference formulation's multiply-adds) unless
+    # DMX_UPS_DIRECT pins the direct gather
+    loop_flops = T * unet_flops(unet.config, B, hw, hw, 577, True, phase_upsample="DMX_UPS_DIRECT" not in os.environ) + context_kv_flops(unet.config, B, 577)
     result = {
         "metric": "512x512 50-step denoise images/sec", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

@@ -27,6 +27,32 @@ extern "C" int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t wor
   return dmx_gemm_launch(to_args(d), workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// nearest x2 upsample + conv3x3 as four 2x2 phase convolutions (GemmArgs.ups2)
+static GemmArgs ups2x_args(const void* x, int ldx, int B, int IH, int IW, int Cin, const void* wp, int N, const float* bias,
+                           void* out, int ldo, int force_tn, int force_splitk) {
+  GemmArgs a{};
+  a.x0 = a.x1 = (const bf16*)x; a.ldx0 = a.ldx1 = ldx; a.cx0 = Cin; a.Cin = Cin;
+  a.ksize = 2; a.stride = 1; a.ups2 = 1; a.IH = a.OH = IH; a.IW = a.OW = IW;
+  a.M4 = B * IH * IW; a.M = 4 * a.M4; a.N = N; a.K = a.Ktaps = 4 * Cin;
+  a.w = (const bf16*)wp; a.ldw = 4 * Cin; a.w_phase_stride = (long long)N * 4 * Cin;
+  a.bias = bias; a.rows_per_group = 1; a.out = out; a.ldo = ldo;
+  a.force_tn = force_tn; a.force_splitk = force_splitk;
+  return a;
+}
+extern "C" size_t dmx_conv_ups2x_workspace_bytes(int B, int IH, int IW, int Cin, int N, int force_tn, int force_splitk) {
+  return dmx_gemm_workspace_bytes(ups2x_args(nullptr, Cin, B, IH, IW, Cin, nullptr, N, nullptr, nullptr, N, force_tn, force_splitk));
+}
+extern "C" int dmx_conv_ups2x(const void* x, int ldx, int B, int IH, int IW, int Cin, const void* phase_weights, int N, const float* bias,
+                              void* out, int ldo, int force_tn, int force_splitk, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(x && phase_weights && out, "conv_ups2x: null argument");
+  DMX_REQUIRE(Cin % 32 == 0 && N % 8 == 0 && ldo % 8 == 0, "conv_ups2x: Cin %% 32, N %% 8 and ldo %% 8 must be 0");
+  return dmx_gemm_launch(ups2x_args(x, ldx, B, IH, IW, Cin, phase_weights, N, bias, out, ldo, force_tn, force_splitk), workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int dmx_pack_ups_phase_weights(const void* w3, int ldw3, void* phase_weights, int N, int Cin, dmx_stream_t stream) {
+  DMX_REQUIRE(w3 && phase_weights, "pack_ups_phase_weights: null argument");
+  return dmx_ups_phase_weights_launch((const bf16*)w3, ldw3, (bf16*)phase_weights, N, Cin, (hipStream_t)stream);
+}
+
 static WgradArgs to_wgrad(const dmx_gemm_desc* d, const void* dy, int lddy, float* dw, int accumulate) {
   WgradArgs a{};
   a.dy = (const bf16*)dy; a.lddy = lddy;

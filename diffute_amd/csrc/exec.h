@@ -80,6 +80,7 @@ struct Tn {                 // NHWC bf16 activation [B*H*W][C] with row stride l
 
 struct ConvOpts {
   int ksize = 3, stride = 1, pad = 1, ups = 0;
+  int ups2 = 0;             // with ups: `w` holds the [4][Cout][4*Cin] phase weights (GemmArgs.ups2), not the 3x3 taps
   const float* bias = nullptr;
   const float* rowbias = nullptr; int ldrb = 0;
   const Tn* res = nullptr;

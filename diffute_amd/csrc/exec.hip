@@ -174,6 +174,11 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   }
   a.w = w; a.ldw = a.K;
   a.M = x0.B * OH * OW; a.N = Cout;
+  if (o.ups && o.ups2) {                               // four 2x2 phase convolutions on the source grid
+    a.ups = 0; a.ups2 = 1; a.ksize = 2; a.pad = 0;
+    a.OH = x0.H; a.OW = x0.W; a.M4 = x0.rows();
+    a.Ktaps = a.K = 4 * a.Cin; a.ldw = a.K; a.w_phase_stride = (long long)Cout * a.K;
+  }
   a.bias = o.bias; a.rowbias = o.rowbias; a.rows_per_group = OH * OW; a.ldrb = o.ldrb;
   if (o.res) { a.res = o.res->p; a.ldres = o.res->ld; }
   a.out = o.out_f32 ? f32_out : (void*)y.p; a.ldo = Cout; a.out_f32 = o.out_f32;

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
   if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-  const int tiles_m = (p.M + BM - 1) / BM;
+  // ups2 (phase-decomposed nearest-x2 upsample + 3x3 conv): the m-tiles are 4 phase blocks of tiles over the SOURCE grid
+  const int Mlim = p.ups2 ? p.M4 : p.M;               // rows of the gathered operand (per phase)
+  const int tiles_mp = (Mlim + BM - 1) / BM;
+  const int tiles_m = p.ups2 ? 4 * tiles_mp : tiles_mp;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int gm = p.group_m > 0 ? p.group_m : 8;
   const int width = gm * tiles_n;
@@ -89,10 +92,19 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
   const int first_m = gid * gm;
   const int gsz = min(tiles_m - first_m, gm);
   const int rem_id = bid - gid * width;
-  const int tile_m = first_m + rem_id % gsz;
+  const int tile_mv = first_m + rem_id % gsz;
   const int tile_n = rem_id / gsz;
+  const int phase = p.ups2 ? tile_mv / tiles_mp : 0;   // (output row parity, output column parity)
+  const int pa = phase >> 1, pb = phase & 1;
+  const int tile_m = tile_mv - phase * tiles_mp;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
+  // output row of gathered row m: identity, or pixel (2i+pa, 2j+pb) of the upsampled grid for source pixel (i, j)
+  auto out_row = [&](int m) -> size_t {
+    if (!p.ups2) return (size_t)m;
+    const int q = m / p.IW;                            // n*IH + i
+    return (size_t)2 * m + (size_t)2 * p.IW * q + (size_t)(pa * 2 * p.IW + pb);
+  };
 
   const int nkt_total = p.K / BKT;
   int kt_begin = 0, kt_end = nkt_total;
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
     const int r = lt / CPR + RSTEP * i;
     const int m = m0 + r;
     kcx[i] = (slot ^ swz(r)) * 8;
-    xr[i].valid = m < p.M;
+    xr[i].valid = m < Mlim;
     if (p.direct) {
       xr[i].bbase = m; xr[i].iy0 = 0; xr[i].ix0 = 0;
     } else {
@@ -120,8 +132,8 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
       const int oy = rem / p.OW;
       const int ox = rem - oy * p.OW;
       xr[i].bbase = b * p.IH * p.IW;
-      xr[i].iy0 = oy * p.stride - p.pad;
-      xr[i].ix0 = ox * p.stride - p.pad;
+      xr[i].iy0 = p.ups2 ? oy - (1 - pa) : oy * p.stride - p.pad;     // ups2: the 2x2 window starts at (i - 1 + pa, j - 1 + pb)
+      xr[i].ix0 = p.ups2 ? ox - (1 - pb) : ox * p.stride - p.pad;
     }
   }
   const int eh = p.ups ? 2 * p.IH : p.IH;   // extent of the (virtually upsampled) input grid
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
     const int r = lt / CPR + RSTEP * i;
     const int n = n0 + r;
     const int kc = (slot ^ swz(r)) * 8;
-    if (n < p.N) { wp[i] = (const char*)(p.w + (size_t)n * p.ldw + (size_t)kt_begin * BKT + kc); winc[i] = ROWB; }
+    if (n < p.N) { wp[i] = (const char*)(p.w + (size_t)phase * p.w_phase_stride + (size_t)n * p.ldw + (size_t)kt_begin * BKT + kc); winc[i] = ROWB; }
     else { wp[i] = (const char*)p.zeros; winc[i] = 0; }
   }
   int p_kt = kt_begin, p_left = 0;
@@ -146,6 +158,7 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
     if (k0 < p.Ktaps) {
       int tap = 0; ci = k0;
       if (p.ksize == 3) { tap = k0 / p.Cin; ci = k0 - tap * p.Cin; dy = tap / 3; dx = tap - dy * 3; }
+      else if (p.ksize == 2) { tap = k0 / p.Cin; ci = k0 - tap * p.Cin; dy = tap >> 1; dx = tap & 1; }
       if (ci < p.cx0) { src = p.x0 + ci; ld = p.ldx0; cend = p.cx0; } else { src = p.x1 + (ci - p.cx0); ld = p.ldx1; cend = p.Cin; }
     } else {
       sc = true; ci = k0 - p.Ktaps; const int ctot = p.K - p.Ktaps;
@@ -406,11 +419,12 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
         const int m = m0 + wm * (32 * TM) + b * 32 + lr;
-        if (m >= p.M) continue;
+        if (m >= Mlim) continue;
+        const size_t orow = out_row(m);                  // partials are kept in output-row order: the reduce pass needs no map
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + wn * 32 * TN + a * 32 + 8 * g + 4 * lh;
-          float* o = part + (size_t)m * p.N + n;
+          float* o = part + orow * p.N + n;
           if (n + 3 < p.N && (p.N & 3) == 0) {
             f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
             *(f32x4*)o = v;
@@ -547,7 +561,7 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
           asm volatile("" ::: "memory");               // keep each item's LDS reads in its own iteration (VGPR pressure)
           const int r = t / OC + (NT / OC) * k;
           const int m = m0 + rbase + r;
-          const bool live = nvalid && m < p.M;
+          const bool live = nvalid && m < Mlim;
           const f32x4 v0 = *(const f32x4*)(tile + r * LDT + o * 8), v1 = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
           float v[8];
           if (p.ln_stats) {
@@ -571,7 +585,7 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
             for (int e = 0; e < 8; ++e) v[e] += rf[e];
           }
           const u32x4 pk = pack_bf8(v);
-          if (live) *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + n) = pk;
+          if (live) *(u32x4*)((bf16*)p.out + out_row(m) * p.ldo + n) = pk;
           if (p.rowstats_out) {
             // per-row (sum, sumsq) of the rounded outputs over this n-tile: the OC lanes of a row are adjacent lanes
             float f[8]; unpack_bf8(pk, f);
@@ -599,7 +613,8 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
         const int m = m0 + wm * (32 * TM) + b * 32 + lr;
-        if (m >= p.M) continue;
+        if (m >= Mlim) continue;
+        const size_t orow = out_row(m);
         const float* rb = p.rowbias ? (p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb) : nullptr;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -612,8 +627,8 @@ __global__ __launch_bounds__(64 * (2 * WM + NP), 2) void dmx_gemm_kernel(const G
             if (p.bias) x += p.bias[n + e];
             if (rb) x += rb[n + e];
             if (p.res) x += bf_bits2f(*(const unsigned short*)(p.res + (size_t)m * p.ldres + n + e));
-            if (p.out_f32) ((float*)p.out)[(size_t)m * p.ldo + n + e] = x;
-            else ((unsigned short*)p.out)[(size_t)m * p.ldo + n + e] = f2bf_bits(x);
+            if (p.out_f32) ((float*)p.out)[orow * p.ldo + n + e] = x;
+            else ((unsigned short*)p.out)[orow * p.ldo + n + e] = f2bf_bits(x);
           }
         }
       }
@@ -714,7 +729,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
   if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
     const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
-      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == a.ups &&
+      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) &&
           !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
         const int nkt = a.K / kCfg[tp.cfg].bk;
         int ktps = cdiv(nkt, tp.sk);
@@ -791,6 +806,11 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   if (a.rowstats_out) DMX_REQUIRE(!a.out_f32 && a.N % 8 == 0 && a.ldo % 8 == 0 && !a.geglu, "gemm: row statistics need the bf16 coalesced epilogue");
   if (a.act) DMX_REQUIRE(a.act == 1 && !a.out_f32 && !a.geglu && a.N % 8 == 0 && a.ldo % 8 == 0 && (a.res == nullptr || a.ldres % 8 == 0), "gemm: the GELU epilogue needs the bf16 coalesced path (N %% 8 == 0)");
   if (a.geglu) DMX_REQUIRE((a.bias || a.ln_stats) && a.N % 128 == 0 && !a.out_f32 && !a.res && !a.rowbias && a.ldo % 8 == 0, "gemm: GEGLU needs bias, N%%128==0, bf16 out");
+  if (a.ups2) {
+    DMX_REQUIRE(a.ksize == 2 && !a.direct && !a.ups && a.stride == 1 && a.OH == a.IH && a.OW == a.IW && a.M4 > 0 && a.M == 4 * a.M4 &&
+                a.Ktaps == a.K && a.K == 4 * a.Cin && a.w_phase_stride > 0, "gemm: inconsistent phase-decomposed upsample conv arguments");
+    DMX_REQUIRE(!a.res && !a.rowbias && !a.geglu && !a.act && !a.ln_stats && !a.rowstats_out, "gemm: the phase-decomposed upsample conv takes a bias only");
+  }
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;
   int c, sk, ktps;
@@ -805,12 +825,12 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     a.partial = (float*)workspace;
   }
   const TileCfg& T = kCfg[c];
-  dim3 grid(cdiv(a.M, T.bm) * cdiv(a.N, T.bn), sk, 1);
+  dim3 grid((a.ups2 ? 4 * cdiv(a.M4, T.bm) : cdiv(a.M, T.bm)) * cdiv(a.N, T.bn), sk, 1);
   // algorithmic work of this launch: 2*M*N*K flops; bytes = activations read once + weights + output
   const double flops = 2.0 * a.M * (double)a.N * a.K;
-  const double bytes = 2.0 * ((double)a.M * (a.K / (a.direct ? 1 : (a.ksize * a.ksize))) + (double)a.N * a.K + (double)a.M * (a.geglu ? a.N / 2 : a.N));
+  const double bytes = 2.0 * ((double)(a.ups2 ? a.M4 : a.M) * (a.K / (a.direct ? 1 : (a.ksize * a.ksize))) + (double)a.N * a.K * (a.ups2 ? 4 : 1) + (double)a.M * (a.geglu ? a.N / 2 : a.N));
   char tag[96];
-  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups, c == 0 ? 2 : (c == 1 ? 1 : c + 1), sk);
+  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=%d sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups2 ? 2 : a.ups, c == 0 ? 2 : (c == 1 ? 1 : c + 1), sk);
   {
     ProfScope ps((ProfClass)(PROF_GEMM_CFG0 + c), stream, flops, bytes, tag);
     if (c == 0) launch_cfg<2, 2, 32, 4>(a, grid, stream);
@@ -866,4 +886,38 @@ int dmx_ln_fold_launch(const bf16* w_raw, bf16* w_out, const float* gamma, const
   DMX_REQUIRE(K % 8 == 0, "ln_fold: K=%d must be a multiple of 8", K);
   hipLaunchKernelGGL(dmx_ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, stream, w_raw, w_out, gamma, beta, bias, c1, c2, N, K);
   return dmx_check_launch("dmx_ln_fold_kernel");
+}
+
+// ------------------------------------------------------------------------- phase weights of the upsample conv
+// conv3x3(nearest_x2(x)) at output pixel (2i+pa, 2j+pb) only sees the 2x2 source window starting at (i-1+pa, j-1+pb):
+// the taps that land on the same source pixel are summed once here (fp32 sum of the bf16 taps, one rounding),
+//   rows: pa=0: {ky=0} | {ky=1,2}     pa=1: {ky=0,1} | {ky=2}      (columns likewise with pb, kx)
+// wp[phase = 2*pa+pb][n][(2*ty+tx)*Cin + ci].  2.25x fewer multiply-adds than the gather over the virtual upsampled grid.
+__global__ __launch_bounds__(256) void dmx_ups_phase_weights_kernel(const bf16* w3, int ldw3, bf16* wp, int N, int Cin) {
+  const size_t total = (size_t)4 * N * 4 * (Cin / 8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int oc = (int)(i % (Cin / 8)); size_t r = i / (Cin / 8);
+    const int tap = (int)(r % 4); r /= 4;
+    const int n = (int)(r % N); const int phase = (int)(r / N);
+    const int pa = phase >> 1, pb = phase & 1, ty = tap >> 1, tx = tap & 1;
+    const int ky0 = pa == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = pa == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+    const int kx0 = pb == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = pb == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) {
+        float f[8]; unpack_bf8(*(const u32x4*)(w3 + (size_t)n * ldw3 + (size_t)(ky * 3 + kx) * Cin + oc * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += f[e];
+      }
+    *(u32x4*)(wp + ((size_t)phase * N + n) * 4 * Cin + (size_t)tap * Cin + oc * 8) = pack_bf8(acc);
+  }
+}
+int dmx_ups_phase_weights_launch(const bf16* w3, int ldw3, bf16* wp, int N, int Cin, hipStream_t stream) {
+  DMX_REQUIRE(Cin % 8 == 0 && ldw3 % 8 == 0 && ldw3 >= 9 * Cin, "ups_phase_weights: Cin=%d / ldw=%d unsupported", Cin, ldw3);
+  const size_t total = (size_t)4 * N * 4 * (Cin / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dmx_ups_phase_weights_kernel, dim3(blocks), dim3(256), 0, stream, w3, ldw3, wp, N, Cin);
+  return dmx_check_launch("dmx_ups_phase_weights_kernel");
 }

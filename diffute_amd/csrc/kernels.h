@@ -23,6 +23,11 @@ struct GemmArgs {
   int direct;              // 1: row m of X is row m of x0/x1 (linear / 1x1 s1); 0: conv gather
   int IH, IW, OH, OW;      // source grid (before the optional x2 nearest upsample), output grid
   int stride, pad, ups, ksize;
+  // ups2 = 1: nearest-x2 upsample + 3x3 conv computed as four 2x2 convolutions on the SOURCE grid, one per output pixel
+  // parity (pa, pb), with pre-summed weights (dmx_ups_phase_weights_launch): 4*Cin instead of 9*Cin multiply-adds per
+  // output.  ksize = 2, OH/OW = IH/IW, M4 = B*IH*IW gathered rows per phase, M = 4*M4 output rows, K = Ktaps = 4*Cin,
+  // w = [4 phases][N][ldw], w_phase_stride = elements between phases; bias only.
+  int ups2, M4; long long w_phase_stride;
   int Cin;                 // channels per tap
   int Ktaps;               // ksize*ksize*Cin ; K - Ktaps = shortcut channels
   const bf16* s0; const bf16* s1; int lds0, lds1, cs0;   // fused 1x1 shortcut segment
@@ -53,6 +58,8 @@ void dmx_gemm_plan(const GemmArgs& a, int* tn, int* splitk, int* ktps);
 int dmx_zero_page(const bf16** out);
 int dmx_gemm_tiles_n(const GemmArgs& a);       // n-tiles of the plan that dmx_gemm_launch will pick (rowstats_out sizing)
 // W' = bf16(W*gamma) and the c1 / c2 vectors of the folded LayerNorm, from the raw bf16 weights (rows may be GEGLU-packed)
+// [4][N][4*Cin] phase weights of GemmArgs.ups2 from taps-major 3x3 weights [N][ldw3]
+int dmx_ups_phase_weights_launch(const bf16* w3, int ldw3, bf16* wp, int N, int Cin, hipStream_t stream);
 int dmx_ln_fold_launch(const bf16* w_raw, bf16* w_out, const float* gamma, const float* beta, const float* bias,
                        float* c1, float* c2, int N, int K, hipStream_t stream);
 

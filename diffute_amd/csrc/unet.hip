@@ -13,6 +13,7 @@
 //   - GEGLU: Linear(C,8C) + a*gelu(b) in one launch; every Linear bias / residual in the GEMM epilogue
 //   - all 22 time_emb_proj Linear layers: one GEMV launch
 //   - cross-attention K / V^T of the glyph context computed once per image (set_context)
+#include <stdlib.h>
 #include <math.h>
 #include "unet_model.h"
 
@@ -116,6 +117,7 @@ extern "C" dmx_unet* dmx_unet_create(const dmx_unet_config* cfg) {
       u->up_us[i].c = c; u->up_us[i].w = pt.reserve((size_t)c * 9 * c * 2);
       pt.conv_at(p + "weight", c, c, 3, u->up_us[i].w, 9 * c, 0);
       u->up_us[i].b = pt.f32(p + "bias", c);
+      u->up_us[i].wp = pt.reserve((size_t)4 * c * 4 * c * 2);      // derived: phase weights of the upsample conv (refresh_derived)
     }
   }
   u->cno_g = pt.f32("conv_norm_out.weight", boc[0]); u->cno_b = pt.f32("conv_norm_out.bias", boc[0]);
@@ -173,6 +175,8 @@ static int refresh_derived(dmx_unet* u, hipStream_t s) {
   int rc = 0;
   for (int i = 0; i < 4 && !rc; ++i) { for (auto& r : u->down_res[i]) if (!rc) rc = fuse(r); for (auto& r : u->up_res[i]) if (!rc) rc = fuse(r); }
   if (!rc) rc = fuse(u->mid_res[0]); if (!rc) rc = fuse(u->mid_res[1]);
+  for (int i = 0; i < 3 && !rc; ++i)
+    rc = dmx_ups_phase_weights_launch(u->at<bf16>(u->up_us[i].w), 9 * u->up_us[i].c, u->at<bf16>(u->up_us[i].wp), u->up_us[i].c, u->up_us[i].c, s);
   // fold norm1/2/3 of every BasicTransformerBlock into the GEMM that consumes it (W' = W*gamma, c1, c2)
   for (const XfW* x : u->xf_all) {
     const int C = x->C;
@@ -345,8 +349,10 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
       h = y;
     }
     if (i < 3) {
-      ConvOpts o; o.ups = 1; o.bias = u->at<float>(u->up_us[i].b);
-      Tn y = ex.conv(h, nullptr, u->at<bf16>(u->up_us[i].w), boc[3 - i], o);
+      // nearest x2 + conv3x3 as four 2x2 phase convolutions on the source grid (pre-summed taps): 4/9 of the multiply-adds
+      static const bool direct = getenv("DMX_UPS_DIRECT") != nullptr;      // measurement aid: gather over the virtual upsampled grid
+      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = u->at<float>(u->up_us[i].b);
+      Tn y = ex.conv(h, nullptr, u->at<bf16>(direct ? u->up_us[i].w : u->up_us[i].wp), boc[3 - i], o);
       ex.drop(h); h = y;
     }
   }

@@ -15,7 +15,7 @@ struct XfW {
   // folded LayerNorm: raw (as loaded) copies of the three LN-consuming weights + the derived c1 / c2 vectors
   size_t wqkv_raw, wq2_raw, wf1_raw, c1_qkv, c2_qkv, c1_q2, c2_q2, c1_f1, c2_f1;
 };
-struct ConvW { size_t w, b; int c; };
+struct ConvW { size_t w, b; int c; size_t wp = 0; /* upsamplers: derived [4][c][4c] phase weights */ };
 
 struct dmx_unet {
   dmx_unet_config cfg;

@@ -5,6 +5,7 @@
 // HBM-bound remainder.  The asymmetric (0,1,0,1) pad of the encoder's stride-2 convs and the
 // decoder's nearest x2 upsamples are folded into the conv gather.  The single-head d=512
 // mid-block attention runs as QK^T GEMM -> fp32 row softmax -> PV GEMM per sample.
+#include <stdlib.h>
 #include <math.h>
 #include "vae_model.h"
 
@@ -130,8 +131,10 @@ int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, in
       ex.drop(h); h = y;
     }
     if (i < 3) {
-      ConvOpts o; o.ups = 1; o.bias = v->at<float>(v->d_us[i].b);
-      Tn y = ex.conv(h, nullptr, v->at<bf16>(v->d_us[i].w), c.block_out_channels[3 - i], o);
+      // nearest x2 + conv3x3 as four 2x2 phase convolutions on the source grid (GemmArgs.ups2)
+      static const bool direct = getenv("DMX_UPS_DIRECT") != nullptr;      // measurement aid
+      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = v->at<float>(v->d_us[i].b);
+      Tn y = ex.conv(h, nullptr, v->at<bf16>(direct ? v->d_us[i].w : v->d_us[i].wp), c.block_out_channels[3 - i], o);
       ex.drop(h); h = y;
     }
   }
@@ -186,7 +189,10 @@ extern "C" dmx_vae* dmx_vae_create(const dmx_vae_config* cfg) {
       resnet_build(pt, v->d_res[i][j], d + "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", cprev, c);
       cprev = c;
     }
-    if (i < 3) big_conv(pt, v->d_us[i], d + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.", c, c);
+    if (i < 3) {
+      big_conv(pt, v->d_us[i], d + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.", c, c);
+      v->d_us[i].wp = pt.reserve((size_t)4 * c * 4 * c * 2);        // derived: phase weights of the upsample conv (dmx_vae_finalize)
+    }
   }
   v->d_ng = pt.f32(d + "conv_norm_out.weight", cprev); v->d_nb = pt.f32(d + "conv_norm_out.bias", cprev);
   big_conv(pt, v->d_out, d + "conv_out.", cfg->out_channels, cprev);
@@ -223,6 +229,8 @@ extern "C" int dmx_vae_finalize(dmx_vae* v, dmx_stream_t stream) {
     for (auto& r : v->d_res[i]) if (!rc) rc = resnet_finalize(r, v->arena, s);
   }
   for (int k = 0; k < 2 && !rc; ++k) { rc = resnet_finalize(v->e_mid[k], v->arena, s); if (!rc) rc = resnet_finalize(v->d_mid[k], v->arena, s); }
+  for (int i = 0; i < 3 && !rc; ++i)
+    rc = dmx_ups_phase_weights_launch(v->at<bf16>(v->d_us[i].w), v->d_us[i].kpad, v->at<bf16>(v->d_us[i].wp), v->d_us[i].cout, v->d_us[i].cin, s);
   DMX_HIP(hipStreamSynchronize(s));
   v->finalized = (rc == 0);
   return rc;

@@ -6,7 +6,7 @@
 #include "../../include/diffute_hip.h"
 
 struct AttnW { int C = 0; size_t gg, gb, wq, bq, wk, bk, wv, bv, wo, bo; };
-struct CW { size_t w = 0, b = 0; int cin = 0, cout = 0, kpad = 0; };
+struct CW { size_t w = 0, b = 0; int cin = 0, cout = 0, kpad = 0; size_t wp = 0; /* decoder upsamplers: derived [4][cout][4*cin] phase weights */ };
 
 struct dmx_vae {
   dmx_vae_config cfg;

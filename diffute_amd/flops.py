@@ -2,7 +2,8 @@
 activations excluded, <0.1 %) - the figure roofline numbers are computed from."""
 
 
-def unet_flops(cfg, B, h, w, ctx_len=577, cached_ctx_kv=True):
+def unet_flops(cfg, B, h, w, ctx_len=577, cached_ctx_kv=True, phase_upsample=False):
+    """phase_upsample: count the upsampler convs as executed by dmx_conv_ups2x (4 instead of 9 taps per output)."""
     boc = tuple(cfg.block_out_channels); L = cfg.layers_per_block; ctxd = cfg.cross_attention_dim
     down_attn = [t.startswith("CrossAttn") for t in cfg.down_block_types]
     up_attn = [t.startswith("CrossAttn") for t in cfg.up_block_types]
@@ -38,7 +39,7 @@ def unet_flops(cfg, B, h, w, ctx_len=577, cached_ctx_kv=True):
             f += res(hw, cprev + skips.pop(), c) + (xf(hw, c) if up_attn[i] else 0)
             cprev = c
         if i < len(boc) - 1:
-            hw *= 4; f += conv(hw, c, c)
+            hw *= 4; f += conv(hw, c, c) * 4 // 9 if phase_upsample else conv(hw, c, c)
     return f + conv(hw, boc[0], cfg.out_channels)
 
 

@@ -96,6 +96,24 @@ def pack_geglu_bias(b):
     return out
 
 
+def pack_ups_phase_weights(w3, N, Cin):
+    """taps-major packed 3x3 weights [N][9*Cin] (pack_conv_weight) -> [4][N][4*Cin] phase weights of conv_ups2x"""
+    wp = torch.empty(4, N, 4 * Cin, dtype=torch.bfloat16, device=w3.device)
+    check(lib().dmx_pack_ups_phase_weights(ptr(w3), w3.stride(0), ptr(wp), N, Cin, current_stream()), "pack_ups_phase_weights")
+    return wp
+
+
+def conv_ups2x(x, wp, N, bias=None, force_tn=0, force_splitk=0):
+    """conv3x3(nearest_x2(x)) through four 2x2 phase convolutions on the source grid.  x NHWC bf16 -> NHWC bf16 [B,2H,2W,N]."""
+    B, H, W, Cin = x.shape
+    out = torch.empty(B, 2 * H, 2 * W, N, dtype=torch.bfloat16, device=x.device)
+    wsb = lib().dmx_conv_ups2x_workspace_bytes(B, H, W, Cin, N, force_tn, force_splitk)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
+    check(lib().dmx_conv_ups2x(ptr(x), _ld(x), B, H, W, Cin, ptr(wp), N, ptr(bias) if bias is not None else None, ptr(out), N,
+                               force_tn, force_splitk, ptr(ws), wsb, current_stream()), "conv_ups2x")
+    return out
+
+
 def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=None, rowbias=None,
               res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0, dbg=0, act=0):
     """Fused conv / linear.  x0 (and x1) NHWC bf16; w packed bf16 [N][K].  Returns NHWC (bf16 or fp32)."""

@@ -78,6 +78,17 @@ typedef struct dmx_gemm_desc {
 size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d);
 int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* K10 (Upsample2D: F.interpolate(scale 2, nearest) + conv3x3, the diffusers call inside pipeline_diffute.py's unet(...),
+ * SURVEY.md 8a) as four 2x2 convolutions on the SOURCE grid, one per output pixel parity, with the 3x3 taps that land on
+ * the same source pixel summed beforehand: 4/9 of the multiply-adds of the direct form, same result up to one bf16
+ * rounding of the summed taps.  phase_weights = [4][N][4*Cin] bf16 from dmx_pack_ups_phase_weights (w3 = taps-major
+ * packed 3x3 weights [N][ldw3] as dmx_pack_conv_weight writes them).  x: NHWC bf16 [B*IH*IW][ldx]; out: NHWC bf16
+ * [B*2IH*2IW][ldo]; bias fp32 [N] or NULL. */
+int dmx_pack_ups_phase_weights(const void* w3, int ldw3, void* phase_weights, int N, int Cin, dmx_stream_t stream);
+size_t dmx_conv_ups2x_workspace_bytes(int B, int IH, int IW, int Cin, int N, int force_tn, int force_splitk);
+int dmx_conv_ups2x(const void* x, int ldx, int B, int IH, int IW, int Cin, const void* phase_weights, int N, const float* bias,
+                   void* out, int ldo, int force_tn, int force_splitk, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+
 /* Training: weight gradient of the conv / linear that `d` describes (the forward call's gather
  * fields x0/x1/cx0/direct/IH.../ksize/Cin and M, N; K taken as Ktaps - the fused shortcut is a separate direct call):
  *   dw[n][k] (+)= sum_m dy[m][n] * X[m][k]   fp32, k in the packed (tap, channel) order of the forward weights.

@@ -36,10 +36,12 @@ def weights(N, K, total=384 << 20):
     return [(torch.randn(N, K, device='cuda') / math.sqrt(K)).to(torch.bfloat16) for _ in range(n)]
 
 
-def main(path):
+def main(path, only=""):
     shapes = {}
     for r in csv.DictReader(open(path)):
         if int(r["class"]) not in (0, 1, 7, 9) and not 10 <= int(r["class"]) < 20:
+            continue
+        if only and only not in r["tag"]:
             continue
         m = dict(re.findall(r"(\w+)=(\d+)", r["tag"]))
         key = tuple(int(m[k]) for k in ("M", "N", "K", "ks", "st", "ups"))
@@ -51,11 +53,16 @@ def main(path):
     print(f'per-launch floor of this harness: {floor:.1f} us')
     for (M, N, K, ks, st, ups), cnt in sorted(shapes.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
         B = 4 if M % 4 == 0 else 1
-        if ks == 3:
+        if ks == 3 and ups != 2:
             ohw = M // B; OH = int(round(math.sqrt(ohw))); Cin = K // 9
             if Cin * 9 != K:      # fused shortcut: treat as plain K for timing
                 ks = 1
-        if ks == 3:
+        if ups == 2:                                   # phase-decomposed upsample conv: M = 4*B*H*W output rows, K = 4*Cin
+            Cin = K // 4; H = int(round(math.sqrt(M // 4 // B)))
+            x = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16)
+            ws = [w.view(4, N, K) for w in weights(4 * N, K)]
+            run = lambda tn, sk, i=0: ops.conv_ups2x(x, ws[i % len(ws)], N, force_tn=tn, force_splitk=sk)
+        elif ks == 3:
             H = OH // 2 if ups else (OH * 2 if st == 2 else OH)
             x = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16)
             ws = weights(N, K)
@@ -86,4 +93,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")

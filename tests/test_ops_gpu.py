@@ -83,6 +83,37 @@ def test_conv_every_tile_config(cuda, tn, sk):
         assert_close(outg.reshape(M, 4 * C), bf(a_ * F.gelu(gate)), TOL, f"geglu tn={tn}")
 
 
+UPS2X_CASES = [("8x8_128_128", 1, 8, 8, 128, 128, 0, 0), ("12x12_64_72_tailM", 1, 12, 12, 64, 72, 0, 0), ("16x16_256_320_b2", 2, 16, 16, 256, 320, 0, 0),
+               ("8x8_1280_splitk", 1, 8, 8, 1280, 1280, 0, 0), ("16x16_128_128_tn1_sk2", 1, 16, 16, 128, 128, 1, 2),
+               ("32x32_64_128_tn3", 1, 32, 32, 64, 128, 3, 0), ("16x16_128_256_ws", 2, 16, 16, 128, 256, 7, 0), ("16x16_64_64_8w", 1, 16, 16, 64, 64, 8, 0)]
+
+
+@pytest.mark.parametrize("case", UPS2X_CASES, ids=[c[0] for c in UPS2X_CASES])
+def test_conv_ups2x_phase_decomposition(cuda, case):
+    """K10 as four 2x2 phase convolutions with pre-summed taps (dmx_conv_ups2x).  (a) With weights whose tap sums are exact
+    in bf16 (multiples of 2^-6, |w| <= 4/64) the decomposition is an algebraic identity: it must meet the per-kernel
+    tolerance against F.conv2d(F.interpolate(x, 2, 'nearest')) like the direct gather does.  (b) With ordinary weights the
+    summed taps are rounded to bf16 once more (relative 2^-9 per weight), so the comparison against the bf16-tap reference
+    is held to 3e-3; against the direct HIP path likewise."""
+    from diffute_amd import ops
+    name, B, H, W, Cin, Cout, tn, sk = case
+    x = bf(seeded((B, Cin, H, W), 1))
+    b = seeded((Cout,), 3, 0.1)
+    g = torch.Generator().manual_seed(7)
+    w_exact = torch.randint(-4, 5, (Cout, Cin, 3, 3), generator=g).float() / 64.0
+    w_rand = bf(seeded((Cout, Cin, 3, 3), 2, 1.0 / math.sqrt(Cin * 9)))
+    for w, tol, what in ((w_exact, TOL, "exact tap sums"), (w_rand, 3e-3, "rounded tap sums")):
+        ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+        w3 = ops.pack_conv_weight(w.to(cuda))
+        wp = ops.pack_ups_phase_weights(w3, Cout, Cin)
+        assert wp.shape == (4, Cout, 4 * Cin)
+        out = ops.conv_ups2x(nhwc(x, cuda), wp, Cout, bias=b.to(cuda), force_tn=tn, force_splitk=sk)
+        assert out.shape == (B, 2 * H, 2 * W, Cout)
+        assert_close(nchw(out), bf(ref), tol, f"{name}: {what} vs torch")
+        direct = ops.conv_gemm(nhwc(x, cuda), w3, Cout, ksize=3, pad=1, ups=True, bias=b.to(cuda))
+        assert_close(nchw(out), nchw(direct), tol, f"{name}: {what} vs the direct upsample gather")
+
+
 def test_conv_concat_temb_shortcut(cuda):
     """ResnetBlock2D conv pair of an up block: conv1 over (h|skip)+temb; conv2 + fused 1x1 shortcut over (h|skip)."""
     from diffute_amd import ops
