@@ -14,3 +14,4 @@ __all__ = ["AutoencoderKL", "UNet2DConditionModel", "DDPMScheduler", "DDIMSchedu
            "mask_to_latent", "FusedAdamW", "TrOCREncoder", "TROCR_LARGE_VIT_CONFIG", "DiagonalGaussianDistribution", "SD2_INPAINT_UNET_CONFIG", "SD_VAE_CONFIG",
            "SD2_SCHEDULER_CONFIG"]
 __version__ = "0.1.0"
+from . import prepost  # noqa: E402,F401  (on-device pre/post-processing)

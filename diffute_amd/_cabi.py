@@ -135,6 +135,9 @@ _PROTOS = {
     "dmx_unet_master_import": (c_int, [_P, _P, c_char_p, _P, _P]),
     "dmx_unet_adamw_step": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P, c_size_t, _P, c_float, _P]),
     "dmx_unet_refresh_derived": (c_int, [_P, _P]),
+    "dmx_mask_rasterize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dmx_preprocess_crop": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "dmx_postprocess_paste": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dmx_pack_ups_phase_weights": (c_int, [_P, c_int, _P, c_int, c_int, _P]),
     "dmx_conv_ups2x_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "dmx_conv_ups2x": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),

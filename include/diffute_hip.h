@@ -292,6 +292,26 @@ int dmx_vae_train_forward(dmx_vae* v, const void* wt_arena, const float* x, floa
 int dmx_vae_train_backward(dmx_vae* v, void* grads, const float* drecon, dmx_stream_t stream);
 int dmx_vae_grad_export(const dmx_vae* v, const void* grads, const char* name, float* dst, dmx_stream_t stream);
 
+/* On-device pre/post-processing either side of the denoise loop.  Reference (host, PIL / numpy / cv2 /
+ * albumentations): generate_mask app.ipynb:370-378; prepare_mask_and_masked_image :380-383; the crop + alb.Resize(512,512)
+ * + alb.Normalize(0.5, 0.5) + ToTensorV2 pipelines :332-344,:722-745; F.interpolate(mask, latent size) :776-779;
+ * (image_vae / 2 + 0.5) * 255, cv2.resize to the crop, paste inside the text box, round to uint8 :825-846.
+ * Resize semantics: OpenCV INTER_LINEAR as published (uint8 fixed point / fp32; exact 2x downscale = 2x2 area mean).
+ *   mask_rasterize:   mask[y][x] = 1 inside the inclusive rectangle (x0,y0)-(x1,y1), else 0 (PIL draw.rectangle, fill=1).
+ *   preprocess_crop:  image_hwc uint8 [H][W][3], mask uint8 [H][W]; crop [y_s:y_s+crop_scale, x_s:x_s+crop_scale] (clipped at
+ *                     the border like a numpy slice) -> S x S: out_image / out_masked_image fp32 [3][S][S] normalised to
+ *                     [-1,1] (masked = image * (mask < 0.5) before the resize), out_mask uint8 [S][S],
+ *                     out_mask_latent fp32 [S/8][S/8] (nearest; may be NULL).
+ *   postprocess_paste: image_vae fp32 [3][S][S] in [-1,1] -> resized to the crop extent, written over original_hwc inside
+ *                     the box [y1:y2, x1:x2] only; out_hwc uint8 [H][W][3] (everything else copied).  Values outside
+ *                     [0,255] are clamped (numpy's cast is undefined there). */
+int dmx_mask_rasterize(unsigned char* mask, int H, int W, int x0, int y0, int x1, int y1, dmx_stream_t stream);
+int dmx_preprocess_crop(const unsigned char* image_hwc, const unsigned char* mask, int H, int W, int x_s, int y_s, int crop_scale,
+                        int S, float* out_image, float* out_masked_image, unsigned char* out_mask, float* out_mask_latent,
+                        dmx_stream_t stream);
+int dmx_postprocess_paste(const float* image_vae, int S, const unsigned char* original_hwc, unsigned char* out_hwc, int H, int W,
+                          int x_s, int y_s, int crop_scale, int x1, int y1, int x2, int y2, dmx_stream_t stream);
+
 /* Fused AdamW + global-norm clipping over packed fp32 arenas (torch.optim.AdamW + clip_grad_norm_,
  * train_diffute_v1.py:721-727,927-930).  masters / exp_avg / exp_avg_sq / grads: dmx_unet_grad_bytes each.  The step also
  * rewrites the weights arena (bf16 weights, fp32 vectors) in place; afterwards call dmx_unet_refresh_derived (folded

@@ -223,3 +223,30 @@ def test_glyph_encoder_param_table_matches_oracle_spec():
         assert got == dict(spec)
     n = sum(int(np.prod(s)) for s in OVT.vit_param_spec(OVT.TROCR_LARGE_VIT).values())
     assert n == 303_617_024
+
+
+def test_crop_ladder_and_origin_match_the_notebook_logic():
+    """N2 host logic (app.ipynb:674-720): product mirror vs the oracle's restatement over a sweep of boxes, and the
+    ladder's documented break points"""
+    import numpy as np
+    from diffute_amd import prepost as P
+    from oracle import prepost as OP
+    assert P.crop_scale_for([0, 0, 50, 20], 1000, 1000) == 128            # 6*20 < 128
+    assert P.crop_scale_for([0, 0, 50, 22], 1000, 1000) == 256            # 132 >= 128
+    assert P.crop_scale_for([0, 0, 700, 22], 1000, 1200) == 1000          # text longer than the ladder value -> short side
+    assert P.crop_scale_for([0, 0, 50, 200], 900, 1200) == 900            # 6*200 = 1200 > short side
+    rng = np.random.RandomState(3)
+    for _ in range(300):
+        h, w = int(rng.randint(64, 1500)), int(rng.randint(64, 1500))
+        x1 = int(rng.randint(0, w - 8)); y1 = int(rng.randint(0, h - 8))
+        x2 = int(rng.randint(x1 + 4, w)); y2 = int(rng.randint(y1 + 2, h))
+        loc = [x1, y1, x2, y2]
+        cs = P.crop_scale_for(loc, h, w)
+        assert cs == OP.crop_scale_for(loc, h, w) and 0 < cs <= min(h, w)
+        try:
+            want = OP.crop_origin(loc, cs, w, np.random.RandomState(9))
+        except ValueError:                                                  # np.random.randint(low >= high): the reference raises too
+            with pytest.raises(ValueError):
+                P.crop_origin(loc, cs, w, np.random.RandomState(9))
+            continue
+        assert P.crop_origin(loc, cs, w, np.random.RandomState(9)) == want
