@@ -77,15 +77,36 @@ __global__ __launch_bounds__(256) void dmx_linear_small_bwd_w_kernel(const float
     db[(size_t)n * db_stride] = accumulate ? db[(size_t)n * db_stride] + s : s;
   }
 }
-// dx[b][k] = act'(x[b][k]) * sum_n dy[b][n] W[n][k]
-__global__ __launch_bounds__(256) void dmx_linear_small_bwd_x_kernel(const float* dy, int lddy, const bf16* w, int ldw, const float* x, int ldx,
-                                                                     float* dx, int lddx, int B, int N, int K, int silu_in) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (k >= K) return;
-  float s = 0.f;
-  for (int n = 0; n < N; ++n) s += dy[(size_t)b * lddy + n] * (float)w[(size_t)n * ldw + k];
-  if (silu_in) s *= dsilu1(x[(size_t)b * ldx + k]);
-  dx[(size_t)b * lddx + k] = s;
+// dx[b][k] = act'(x[b][k]) * sum_n dy[b][n] W[n][k].  N is the long axis here (time_emb_proj of all 22 resnets stacked:
+// N ~ 20k rows of K = 1280), so a block owns 32 columns k and up to 8 samples and splits N over 32 lanes of threads: W
+// is read once (64-byte row segments), the dy values are block-uniform, the 32 partial sums are folded in lane order.
+__global__ __launch_bounds__(1024) void dmx_linear_small_bwd_x_kernel(const float* dy, int lddy, const bf16* w, int ldw, const float* x, int ldx,
+                                                                      float* dx, int lddx, int B, int N, int K, int silu_in) {
+  __shared__ float red[32][8][33];
+  const int kk = threadIdx.x & 31, nl = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + kk, b0 = blockIdx.y * 8;
+  const int nb = min(8, B - b0);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (k < K)
+    for (int n = nl; n < N; n += 32) {
+      const float wv = (float)w[(size_t)n * ldw + k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < nb) acc[j] += dy[(size_t)(b0 + j) * lddy + n] * wv;
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[nl][j][kk] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int j = threadIdx.x >> 5;
+    if (j < nb && k < K) {
+      float s = 0.f;
+      for (int l = 0; l < 32; ++l) s += red[l][j][kk];
+      if (silu_in) s *= dsilu1(x[(size_t)(b0 + j) * ldx + k]);
+      dx[(size_t)(b0 + j) * lddx + k] = s;
+    }
+  }
 }
 // ---- 1x1 convolutions between tiny channel counts (VAE quant_conv 8->8, post_quant_conv 4->4): one thread per row
 #define PW_MAXC 8
@@ -214,7 +235,7 @@ int dmx_linear_small_bwd_launch(const float* x, int ldx, const float* dy, int ld
     if (rc) return rc;
   }
   if (dx) {
-    hipLaunchKernelGGL(dmx_linear_small_bwd_x_kernel, dim3(cdiv(K, 256), B), dim3(256), 0, stream, dy, lddy, w, ldw, x, ldx, dx, lddx, B, N, K, silu_in);
+    hipLaunchKernelGGL(dmx_linear_small_bwd_x_kernel, dim3(cdiv(K, 32), cdiv(B, 8)), dim3(1024), 0, stream, dy, lddy, w, ldw, x, ldx, dx, lddx, B, N, K, silu_in);
     return dmx_check_launch("dmx_linear_small_bwd_x_kernel");
   }
   return DMX_OK;
