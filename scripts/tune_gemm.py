@@ -11,6 +11,9 @@ sys.path.insert(0, ".")
 from diffute_amd import ops  # noqa: E402
 
 
+TUNE_B = int(__import__('os').environ.get('TUNE_B', '4'))     # batch the profiled pass ran at (8 for the training step)
+
+
 def time_it(fn, reps=12, replays=3):
     """us per call of fn(i).  The calls are captured into one graph (no host launch overhead: the python/ctypes path
     costs ~25 us per call, more than the small GEMMs) and fn rotates its weights (i) so they stream from HBM as in the
@@ -52,7 +55,7 @@ def main(path, only=""):
     floor = time_it(lambda i: ops.conv_gemm(zx, zw, 64, ksize=1, pad=0))
     print(f'per-launch floor of this harness: {floor:.1f} us')
     for (M, N, K, ks, st, ups), cnt in sorted(shapes.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
-        B = 4 if M % 4 == 0 else 1
+        B = TUNE_B if M % TUNE_B == 0 else 1
         if ks == 3 and ups != 2:
             ohw = M // B; OH = int(round(math.sqrt(ohw))); Cin = K // 9
             if Cin * 9 != K:      # fused shortcut: treat as plain K for timing
