@@ -212,13 +212,24 @@ __global__ __launch_bounds__(256) void dmx_colsum_part_kernel(const bf16* __rest
     }
   }
 }
-__global__ void dmx_colsum_final_kernel(const float* __restrict__ part, int cpg, int N, float* __restrict__ out, int ldo, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, grp = blockIdx.y;
-  if (c >= N) return;
+// 256 threads = 8 partial lanes x 32 columns: the cpg partials of a column are independent loads spread over 8 lanes (a
+// single thread walking up to 128 of them serially made this trivial kernel cost 12 us), folded in lane order
+__global__ __launch_bounds__(256) void dmx_colsum_final_kernel(const float* __restrict__ part, int cpg, int N, float* __restrict__ out, int ldo, int accumulate) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, grp = blockIdx.y;
   float s = 0.f;
-  for (int j = 0; j < cpg; ++j) s += part[((size_t)grp * cpg + j) * N + c];
-  float* o = out + (size_t)grp * ldo + c;
-  *o = accumulate ? *o + s : s;
+  if (c < N)
+    for (int j = l; j < cpg; j += 8) s += part[((size_t)grp * cpg + j) * N + c];
+  red[l][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[k][cl];
+    float* o = out + (size_t)grp * ldo + c;
+    *o = accumulate ? *o + v : v;
+  }
 }
 }  // namespace
 
@@ -296,6 +307,6 @@ int dmx_colsum_launch(const bf16* dy, int lddy, int groups, int rows_per_group, 
   hipLaunchKernelGGL(dmx_colsum_part_kernel, dim3(cdiv(N, 64), groups * cpg), dim3(256), 0, stream, dy, lddy, rows_per_group, cpg, N, (float*)workspace);
   int rc = dmx_check_launch("dmx_colsum_part_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(dmx_colsum_final_kernel, dim3(cdiv(N, 256), groups), dim3(256), 0, stream, (const float*)workspace, cpg, N, out, ldo, accumulate);
+  hipLaunchKernelGGL(dmx_colsum_final_kernel, dim3(cdiv(N, 32), groups), dim3(256), 0, stream, (const float*)workspace, cpg, N, out, ldo, accumulate);
   return dmx_check_launch("dmx_colsum_final_kernel");
 }
