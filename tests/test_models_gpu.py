@@ -89,6 +89,26 @@ def test_tiny_unet_forward(cuda, tiny_unet):
     assert torch.equal(tiny_unet.forward_parts([lat, mask, mlat], t), yp)
 
 
+def test_tiny_unet_nonsquare_odd_batch(cuda, tiny_unet):
+    """shapes the goldens do not cover: batch 3, an 8 x 24 latent grid (64 x 192 px) and a 40-token context - every
+    gather / GroupNorm slab / upsample-phase / attention tail path away from the square power-of-two case, against the
+    oracle run here"""
+    from oracle import unet as OU
+    from diffute_amd.synthetic import synth_inputs
+    lat, mask, mlat, ctx = synth_inputs(3, 8, 24, 40, 128, device=cuda, seed=11)
+    x = torch.cat([lat, mask, mlat], 1)
+    t = torch.tensor([981, 500, 3])
+    with torch.no_grad():
+        y = tiny_unet(x, t.to(cuda), ctx).sample
+    P = {k: v.detach().cpu().float() for k, v in tiny_unet.state_dict().items()}
+    ref = OU.unet_forward(P, OU.TINY_UNET, x.cpu().float(), t, ctx.cpu().float(), emulate_bf16=True)
+    assert y.shape == (3, 4, 8, 24)
+    assert_close(y, ref, E2E_EMU, "tiny unet, B=3, 8x24 latents, 40 context tokens")
+    with torch.no_grad():                                   # sample 1 alone == sample 1 of the batch (batch independence)
+        y1 = tiny_unet(x[1:2].contiguous(), t[1:2].to(cuda), ctx[1:2].contiguous()).sample
+    assert rel_l2(y1, y[1:2]) < 2e-2
+
+
 def test_tiny_vae(cuda, tiny_vae):
     from diffute_amd.synthetic import synth_images
     from diffute_amd.init import normal
