@@ -134,6 +134,23 @@ def test_tiny_vae(cuda, tiny_vae):
         assert rec.shape == img.shape and torch.isfinite(rec).all()
 
 
+def test_tiny_vae_nonsquare(cuda, tiny_vae):
+    """64 x 96 px, batch 3: the asymmetric stride-2 pad, the phase-decomposed decoder upsamplers and the d=C attention on a
+    non-square grid, against the oracle run here"""
+    from oracle import vae as OV
+    from diffute_amd.synthetic import synth_images
+    from diffute_amd.init import normal
+    img = synth_images(3, 64, 96, device=cuda)
+    P = {k: v.detach().cpu().float() for k, v in tiny_vae.state_dict().items()}
+    with torch.no_grad():
+        mom = tiny_vae.encode(img).latent_dist.parameters
+        z = normal(6, 24, 3 * 4 * 8 * 12, cuda).reshape(3, 4, 8, 12)
+        dec = tiny_vae.decode(z).sample
+    assert mom.shape == (3, 8, 8, 12) and dec.shape == (3, 3, 64, 96)
+    assert_close(mom, OV.vae_encode_moments(P, OV.TINY_VAE, img.cpu(), emulate_bf16=True), E2E_EMU, "tiny vae encode 64x96")
+    assert_close(dec, OV.vae_decode(P, OV.TINY_VAE, z.cpu(), emulate_bf16=True), E2E_EMU, "tiny vae decode 64x96")
+
+
 def test_tiny_denoise_loops(cuda, tiny_unet):
     """P1: the 4-step loop (app.ipynb:796-816) with DDIM and with DDPM + injected variance noise."""
     import diffute_amd as D
