@@ -138,6 +138,7 @@ _PROTOS = {
     "dmx_mask_rasterize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dmx_preprocess_crop": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "dmx_postprocess_paste": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dmx_gemm_plan_override": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "dmx_pack_ups_phase_weights": (c_int, [_P, c_int, _P, c_int, c_int, _P]),
     "dmx_conv_ups2x_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "dmx_conv_ups2x": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),

@@ -53,6 +53,12 @@ extern "C" int dmx_pack_ups_phase_weights(const void* w3, int ldw3, void* phase_
   return dmx_ups_phase_weights_launch((const bf16*)w3, ldw3, (bf16*)phase_weights, N, Cin, (hipStream_t)stream);
 }
 
+// tuning aid: time candidate GEMM plans inside a real pass (cfg = template instance id, < 0 clears every override)
+extern "C" int dmx_gemm_plan_override(int M, int N, int K, int stride, int ups, int cfg, int splitk) {
+  dmx_gemm_plan_override_set(M, N, K, stride, ups, cfg, splitk);
+  return DMX_OK;
+}
+
 static WgradArgs to_wgrad(const dmx_gemm_desc* d, const void* dy, int lddy, float* dw, int accumulate) {
   WgradArgs a{};
   a.dy = (const bf16*)dy; a.lddy = lddy;

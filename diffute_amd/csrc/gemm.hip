@@ -24,6 +24,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdio.h>
+#include <vector>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -724,10 +725,29 @@ static double plan_cost(const GemmArgs& a, int c, int sk) {
 
 #include "gemm_tuned.h"
 
+// Tuning aid (scripts/tune_in_situ.py): plan overrides set at run time take precedence over the compiled table, so a
+// candidate plan can be timed inside the real UNet pass - with the shape's real epilogue, neighbours and cache state.
+static std::vector<TunedPlan> g_plan_overrides;
+void dmx_gemm_plan_override_set(int M, int N, int K, int st, int ups, int cfg, int sk) {
+  if (cfg < 0) { g_plan_overrides.clear(); return; }
+  for (TunedPlan& tp : g_plan_overrides)
+    if (tp.M == M && tp.N == N && tp.K == K && tp.st == st && tp.ups == ups) { tp.cfg = cfg; tp.sk = sk; return; }
+  g_plan_overrides.push_back(TunedPlan{M, N, K, 0, st, ups, cfg, sk});
+}
+
 void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_out) {
   int best_c = 0, best_sk = 1; double best = 1e300;
   if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
     const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
+    for (const TunedPlan& tp : g_plan_overrides)
+      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 10 &&
+          !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
+        const int bk = kCfg[tp.cfg].bk, nkt = a.K / bk;
+        if (a.K % bk || a.Cin % bk || a.cx0 % bk || a.Ktaps % bk || (a.Ktaps < a.K && a.cs0 % bk) || tp.sk < 1 || nkt / tp.sk < 4) break;   // not applicable: normal plan
+        int ktps = cdiv(nkt, tp.sk);
+        *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
+        return;
+      }
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) &&
           !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
@@ -850,7 +870,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     const size_t total4 = (size_t)a.M * a.N / 4;
     int blocks = (int)((total4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    ProfScope ps(PROF_SPLITK, stream, 0.0, 4.0 * sk * (double)a.M * a.N);
+    ProfScope ps(PROF_SPLITK, stream, 0.0, 4.0 * sk * (double)a.M * a.N, tag);
     hipLaunchKernelGGL(dmx_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
     rc = dmx_check_launch("dmx_splitk_reduce_kernel");
   }

@@ -56,6 +56,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
 size_t dmx_gemm_workspace_bytes(const GemmArgs& a);
 void dmx_gemm_plan(const GemmArgs& a, int* tn, int* splitk, int* ktps);
 int dmx_zero_page(const bf16** out);
+void dmx_gemm_plan_override_set(int M, int N, int K, int st, int ups, int cfg, int sk);   // tuning aid; cfg < 0 clears all
 int dmx_gemm_tiles_n(const GemmArgs& a);       // n-tiles of the plan that dmx_gemm_launch will pick (rowstats_out sizing)
 // W' = bf16(W*gamma) and the c1 / c2 vectors of the folded LayerNorm, from the raw bf16 weights (rows may be GEGLU-packed)
 // [4][N][4*Cin] phase weights of GemmArgs.ups2 from taps-major 3x3 weights [N][ldw3]

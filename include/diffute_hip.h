@@ -89,6 +89,11 @@ size_t dmx_conv_ups2x_workspace_bytes(int B, int IH, int IW, int Cin, int N, int
 int dmx_conv_ups2x(const void* x, int ldx, int B, int IH, int IW, int Cin, const void* phase_weights, int N, const float* bias,
                    void* out, int ldo, int force_tn, int force_splitk, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* Tuning aid (scripts/tune_in_situ.py): override the tile plan of every GEMM with this (M, N, K, stride, ups) signature
+ * (ups: 0, 1, or 2 for the phase-decomposed upsample conv) by template instance `cfg` (0..9) and split-K factor; cfg < 0
+ * clears all overrides.  Not thread-safe; captured hipGraphs keep the plan they were captured with. */
+int dmx_gemm_plan_override(int M, int N, int K, int stride, int ups, int cfg, int splitk);
+
 /* Training: weight gradient of the conv / linear that `d` describes (the forward call's gather
  * fields x0/x1/cx0/direct/IH.../ksize/Cin and M, N; K taken as Ktaps - the fused shortcut is a separate direct call):
  *   dw[n][k] (+)= sum_m dy[m][n] * X[m][k]   fp32, k in the packed (tap, channel) order of the forward weights.
