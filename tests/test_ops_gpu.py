@@ -62,7 +62,7 @@ def test_conv(cuda, case):
     assert_close(nchw(out), ref, TOL, name)
 
 
-@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (4, 1), (5, 1), (6, 1), (6, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2)])
+@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (4, 1), (5, 1), (6, 1), (6, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2), (11, 1), (11, 2)])
 def test_conv_every_tile_config(cuda, tn, sk):
     """All three tile configurations (128x64, 128x128, 256x128) and split-K give the same conv + epilogue."""
     from diffute_amd import ops
@@ -85,7 +85,7 @@ def test_conv_every_tile_config(cuda, tn, sk):
 
 UPS2X_CASES = [("8x8_128_128", 1, 8, 8, 128, 128, 0, 0), ("12x12_64_72_tailM", 1, 12, 12, 64, 72, 0, 0), ("16x16_256_320_b2", 2, 16, 16, 256, 320, 0, 0),
                ("8x8_1280_splitk", 1, 8, 8, 1280, 1280, 0, 0), ("16x16_128_128_tn1_sk2", 1, 16, 16, 128, 128, 1, 2),
-               ("32x32_64_128_tn3", 1, 32, 32, 64, 128, 3, 0), ("16x16_128_256_ws", 2, 16, 16, 128, 256, 7, 0), ("16x16_64_64_8w", 1, 16, 16, 64, 64, 8, 0)]
+               ("32x32_64_128_tn3", 1, 32, 32, 64, 128, 3, 0), ("16x16_128_256_ws", 2, 16, 16, 128, 256, 7, 0), ("16x16_64_64_8w", 1, 16, 16, 64, 64, 8, 0), ("16x16_128_320_w160", 2, 16, 16, 128, 320, 11, 0)]
 
 
 @pytest.mark.parametrize("case", UPS2X_CASES, ids=[c[0] for c in UPS2X_CASES])
