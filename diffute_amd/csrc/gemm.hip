@@ -46,13 +46,16 @@ struct RowSrc {          // per-thread state for one staged activation row
 //   10 <4,5,64,2,1,0,1> 128x160x64: FOUR waves in one column (NWN = 1), 32x160 sub-tiles, 2-buffer ring (72 KB -> 2 blocks/CU).
 //                     160 divides every channel count of the UNet (320 k): no wasted tile columns where N = 320 / 640 / 960;
 //                     its own coalesced epilogue (20 octets per row do not divide the block); bias / row bias / residual only
+//   11 <4,5,64,2,1,0,2> 128x320x64: eight waves (4 x 2) of 32x160 sub-tiles, 2-buffer ring (112 KB, 1 block/CU); five whole packed
+//                     GEGLU groups per tile, same epilogue as 10 plus folded LayerNorm + GEGLU: the FF1 GEMM of the 16x16 level
+//                     (1024 x 10240 x 1280) becomes 256 tiles = one full round instead of 640 tiles on 512 slots
 //   3, 4, 5           deep-ring and 256x256 experiments, force_tn only
 // measurement aid: 100 MHz wall ticks, or (dbg bit 2) shader-clock cycles - their ratio is the effective clock
 __device__ __forceinline__ long long dmx_now(int dbg) {
   return (dbg & 4) ? (long long)__builtin_amdgcn_s_memtime() : (long long)__builtin_amdgcn_s_memrealtime();
 }
 template <int WM, int TN, int BKT, int NSTAGE, int TM = 2, int NP = 0, int NWN = 2>
-__global__ __launch_bounds__(64 * (NWN * WM + NP), 2) void dmx_gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2) void dmx_gemm_kernel(const GemmArgs p) {
   static_assert(NWN == 1 || NWN == 2, "one or two waves along n");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * NWN;
   constexpr int NC = NWN * WM;                         // consumer (MFMA) waves: WM along m x NWN along n
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), 2) void dmx_gemm_kernel(const
   // ---- folded LayerNorm (consumer side): the GEMM runs on the RAW rows x with W' = W*diag(gamma); the epilogue
   // applies y = rstd*(acc - mean*c1[n]) + c2[n].  Row mean / rstd come from the producer's per-n-tile partial sums.
   constexpr int EPI_BYTES = BM * (BN + 4) * 4;                                  // whole-tile fp32 staging (epilogue)
-  constexpr int EPI_PASS = NWN == 1 ? EPI_BYTES / 2 : (EPI_BYTES <= 152 * 1024) ? EPI_BYTES : EPI_BYTES / WM;  // or one slab of rows per pass
+  constexpr int EPI_PASS = TN == 5 ? EPI_BYTES / 2 : (EPI_BYTES <= 152 * 1024) ? EPI_BYTES : EPI_BYTES / WM;  // or one slab of rows per pass
   constexpr int LN_OFF = (NSTAGE * STAGE > EPI_PASS) ? NSTAGE * STAGE : EPI_PASS;
   float* lnst = (float*)(smem + LN_OFF);               // [BM][2] = (mean, rstd); only allocated when ln_stats != null
   if (p.ln_stats) {
@@ -440,15 +443,19 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), 2) void dmx_gemm_kernel(const
           }
         }
       }
-  } else if (NWN == 1 && !p.out_f32 && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (p.res == nullptr || (p.ldres & 7) == 0)) {
-    // ---- coalesced epilogue of the 160-column tile (BN / 8 = 20 octets per row does not divide the block, so the
-    // (row, octet) of an item varies per thread and the column vectors are fetched per item): two passes of BM/2 rows
-    // staged in LDS as fp32; bias + time-embedding row bias + residual, bf16 out.  (The plan keeps GEGLU / folded
-    // LayerNorm / row statistics / GELU on the power-of-two tiles.)
-    if constexpr (NWN == 1) {
-      constexpr int LDT = BN + 4, OC = BN / 8, EP = 2, RPP = BM / EP, ITEMS = RPP * OC / NT;
-      static_assert(RPP * OC % NT == 0 && WM % EP == 0, "160-column epilogue: items must divide the block");
+  } else if (TN == 5 && !p.out_f32 && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (p.res == nullptr || (p.ldres & 7) == 0)) {
+    // ---- coalesced epilogue of the 160 / 320-column tiles (BN / 8 = 20 or 40 octets per row do not divide the block, so
+    // the (row, octet) of an item varies per thread and the column vectors are fetched per item): two passes of BM/2 rows
+    // staged in LDS as fp32; bias or the folded-LayerNorm affine, time-embedding row bias, residual, GEGLU (320-column
+    // tile: 5 whole packed 64-column groups), bf16 out.  Row statistics / GELU stay on the power-of-two tiles (plan).
+    if constexpr (TN == 5) {
+      constexpr int LDT = BN + 4, EP = 2, RPP = BM / EP;
+      static_assert(WM % EP == 0, "160-column epilogue: whole waves per pass");
       float* tile = (float*)smem;
+      const bool geglu = NWN == 2 && p.geglu != 0;
+      const int OCI = geglu ? BN / 16 : BN / 8;          // output octets per tile row
+      const int items = RPP * OCI;
+      const float* bsrc = p.ln_stats ? p.ln_c2 : p.bias;
 #pragma unroll
       for (int ep = 0; ep < EP; ++ep) {
         __builtin_amdgcn_s_barrier();
@@ -461,25 +468,51 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), 2) void dmx_gemm_kernel(const
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-                *(f32x4*)(tile + r * LDT + a * 32 + 8 * g + 4 * lh) = v;
+                *(f32x4*)(tile + r * LDT + wn * 32 * TN + a * 32 + 8 * g + 4 * lh) = v;
               }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        for (int q = t; q < items; q += NT) {
+          const int r = q / OCI, o = q - r * OCI;
+          const int m = m0 + ep * RPP + r;
+          if (m >= Mlim) continue;
+          float mean = 0.f, rstd = 1.f;
+          if (p.ln_stats) { mean = lnst[2 * (ep * RPP + r)]; rstd = lnst[2 * (ep * RPP + r) + 1]; }
+          auto column = [&](int tc, int n, float* v) {   // tile column tc, global (packed) column n: acc -> affine
+            const f32x4 v0 = *(const f32x4*)(tile + r * LDT + tc), v1 = *(const f32x4*)(tile + r * LDT + tc + 4);
+            float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (bsrc) {
+              const f32x4 b0 = *(const f32x4*)(bsrc + n), b1 = *(const f32x4*)(bsrc + n + 4);
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-          const int q = t + NT * k;
-          const int r = q / OC, o = q - r * OC;
-          const int m = m0 + ep * RPP + r, n = n0 + o * 8;
-          if (m >= Mlim || n >= p.N) continue;
-          const f32x4 v0 = *(const f32x4*)(tile + r * LDT + o * 8), v1 = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
-          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          if (p.bias) {
-            const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+              for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
+            }
+            if (p.ln_stats) {
+              const f32x4 c0 = *(const f32x4*)(p.ln_c1 + n), c1 = *(const f32x4*)(p.ln_c1 + n + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+              for (int e = 0; e < 4; ++e) { v[e] = rstd * (v0[e] - mean * c0[e]) + bs[e]; v[4 + e] = rstd * (v1[e] - mean * c1[e]) + bs[4 + e]; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bs[e]; v[4 + e] = v1[e] + bs[4 + e]; }
+            }
+          };
+          float v[8];
+          if (geglu) {
+            const int Gg = o >> 2, jj = (o & 3) * 8;     // packed 64-column group: 32 'a' columns then 32 gate columns
+            const int na = n0 + 64 * Gg + jj;
+            if (na >= p.N) continue;
+            float gt[8];
+            column(64 * Gg + jj, na, v);
+            column(64 * Gg + 32 + jj, na + 32, gt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(gt[e]);
+            *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + (n0 >> 1) + 32 * Gg + jj) = pack_bf8(v);
+            continue;
           }
+          const int n = n0 + o * 8;
+          if (n >= p.N) continue;
+          column(o * 8, n, v);
           if (p.rowbias) {
             const float* rb = p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb + n;
             const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
@@ -495,13 +528,13 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), 2) void dmx_gemm_kernel(const
         }
       }
     }
-  } else if (NWN == 2 && !p.out_f32 && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (p.res == nullptr || (p.ldres & 7) == 0)) {
+  } else if (TN != 5 && !p.out_f32 && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (p.res == nullptr || (p.ldres & 7) == 0)) {
     // ---- coalesced epilogue: accumulators (+ time-embedding row bias) -> LDS as fp32 (the ring is free now) ->
     // each thread finishes 8 consecutive channels of one pixel: + bias + residual (or GEGLU a*gelu(b)), one
     // rounding to bf16, one 16-byte store; a wave writes whole 128/256-byte row segments.  Raw s_barrier +
     // lgkmcnt only: __syncthreads() would also wait for the global stores (vmcnt counts stores on gfx950), and
     // every global load is issued before the first store for the same reason.
-    if constexpr (NWN == 2) {
+    if constexpr (TN != 5) {
     constexpr int LDT = BN + 4;                        // padded row stride (floats): conflict-free b128 writes
     constexpr int OC = BN / 8;                         // output octets per tile row (NT % OC == 0: o fixed per thread)
     constexpr int EP = (EPI_BYTES <= 152 * 1024) ? 1 : WM;   // passes: the 256x256 tile stages 64 rows (one wm) at a time
@@ -666,7 +699,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), 2) void dmx_gemm_kernel(const
         }
       }
     }
-    }   // if constexpr (NWN == 2)
+    }   // if constexpr (TN != 5)
   } else {
     // ---- generic epilogue (fp32 output, channel counts that are not multiples of 8): per-lane 4-channel groups
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldo & 3) == 0);
@@ -753,7 +786,7 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[11] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[12] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
@@ -767,6 +800,8 @@ static const TileCfg kCfg[11] = {            // measured (scripts/gemm_timeline.
     {128, 128, 64, 256, 1.00, 8.0},         // 128x128x64 with eight waves, 3-stage ring (96 KB); force_tn = 10 / tuned table
     {128, 160, 64, 512, 1.10, 8.0},         // 128x160x64, four waves with 32x160 sub-tiles (one wave column): 160 divides every channel
                                             // count of this UNet (320 k), so no column of a tile is wasted; force_tn = 11 / tuned table
+    {128, 320, 64, 256, 2.00, 10.0},        // 128x320x64, eight waves (4 x 2), 32x160 sub-tiles, 2-buffer ring (112 KB, 1 block/CU): five whole
+                                            // GEGLU groups per tile - the feed-forward GEMMs (N = 8C) tile without a partial round; force_tn = 12
 };
 
 static double plan_cost(const GemmArgs& a, int c, int sk) {
@@ -804,17 +839,17 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
   if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
     const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
     for (const TunedPlan& tp : g_plan_overrides)
-      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 11 && !(tp.cfg >= 10 && (a.geglu || a.ln_stats || a.rowstats_out || a.act || a.out_f32 || (a.N & 7))) &&
+      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 12 && !(tp.cfg >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
           !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
         const int bk = kCfg[tp.cfg].bk, nkt = a.K / bk;
-        if (a.K % bk || a.Cin % bk || a.cx0 % bk || a.Ktaps % bk || (a.Ktaps < a.K && a.cs0 % bk) || tp.sk < 1 || nkt / tp.sk < 4) break;   // not applicable: normal plan
+        if (a.K % bk || a.Cin % bk || a.cx0 % bk || a.Ktaps % bk || (a.Ktaps < a.K && a.cs0 % bk) || tp.sk < 1 || (tp.sk > 1 && nkt / tp.sk < 4)) break;   // not applicable: normal plan
         int ktps = cdiv(nkt, tp.sk);
         *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
         return;
       }
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) &&
-          !(tp.cfg >= 10 && (a.geglu || a.ln_stats || a.rowstats_out || a.act || a.out_f32 || (a.N & 7))) &&
+          !(tp.cfg >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
           !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
         const int nkt = a.K / kCfg[tp.cfg].bk;
         int ktps = cdiv(nkt, tp.sk);
@@ -822,7 +857,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
         return;
       }
   }
-  for (int c = 0; c < 11; ++c) {
+  for (int c = 0; c < 12; ++c) {
     const TileCfg& T = kCfg[c];
     if ((c == 3 || c == 4 || c == 5 || c >= 7) && !a.force_tn) continue;   // deep rings / 256x256: no gain inside the UNet pass; kept for experiments
     if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
@@ -838,7 +873,8 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     if (a.force_tn == 9 && c != 8) continue;
     if (a.force_tn == 10 && c != 9) continue;
     if (a.force_tn == 11 && c != 10) continue;
-    if (c >= 10 && (a.geglu || a.ln_stats || a.rowstats_out || a.act || a.out_f32 || (a.N & 7))) continue;   // plain epilogue only
+    if (a.force_tn == 12 && c != 11) continue;
+    if (c >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (c == 10 && a.geglu))) continue;   // what their epilogue covers
     if (!a.force_tn && c != 1 && c != 3 && a.N <= 64) continue;
     if (!a.force_tn && (c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
     const int nkt = a.K / T.bk;
@@ -874,7 +910,7 @@ static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * NWN;
   size_t lds = (size_t)NST * (BM + BN) * BKT * 2;
   size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);             // fp32 staging tile of the coalesced epilogue
-  if (NWN == 1) lds_epi /= 2;                                          // the 160-column tile stages half its rows per pass
+  if (TN == 5) lds_epi /= 2;                                           // the 160 / 320-column tiles stage half their rows per pass
   else if (lds_epi > 152 * 1024) lds_epi /= WM;                            // (only the experimental 256x256 tile)                            // staged one 64-row slab at a time
   if (lds_epi > lds) lds = lds_epi;
   if (a.ln_stats) lds += (size_t)BM * 2 * sizeof(float);               // (mean, rstd) per row of the folded LayerNorm
@@ -931,7 +967,8 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     else if (c == 7) launch_cfg<4, 1, 64, 3, 1>(a, grid, stream);
     else if (c == 8) launch_cfg<4, 2, 32, 4, 1>(a, grid, stream);
     else if (c == 9) launch_cfg<4, 2, 64, 3, 1>(a, grid, stream);
-    else launch_cfg<4, 5, 64, 2, 1, 0, 1>(a, grid, stream);
+    else if (c == 10) launch_cfg<4, 5, 64, 2, 1, 0, 1>(a, grid, stream);
+    else launch_cfg<4, 5, 64, 2, 1, 0, 2>(a, grid, stream);
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;

@@ -109,6 +109,36 @@ def test_tiny_unet_nonsquare_odd_batch(cuda, tiny_unet):
     assert rel_l2(y1, y[1:2]) < 2e-2
 
 
+def test_tiny_unet_on_the_160_column_tiles(cuda):
+    """the 128x160 / 128x320 tile instances with their own epilogue (folded LayerNorm + GEGLU, bias + row bias + residual)
+    inside a whole UNet: every eligible GEMM signature of the tiny model is pinned to them through the run-time plan
+    override and the result is held to the same bound against the golden as the default plans"""
+    import diffute_amd as D
+    from diffute_amd import _cabi
+    from diffute_amd.synthetic import synth_inputs
+    g = np.load(os.path.join(GOLD, "tiny_unet.npz"))
+    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1)
+    lib = _cabi.lib()
+    unet = D.UNet2DConditionModel(**TINY_UNET).cuda().requires_grad_(False)
+    ref = None
+    try:
+        with torch.no_grad():
+            ref = unet(x, torch.tensor(981), ctx).sample.clone()
+        for (B_, hw, C) in ((2, 256, 64), (2, 64, 128), (2, 16, 256), (2, 4, 256)):
+            M = B_ * hw
+            lib.dmx_gemm_plan_override(M, 8 * C, C, 1, 0, 11, 1)            # FF1: folded LayerNorm + GEGLU on the 128x320 tile
+            for (N, K) in ((C, C), (C, 4 * C), (3 * C, C), (C, 9 * C), (C, 18 * C), (C, 9 * C + C)):
+                lib.dmx_gemm_plan_override(M, N, K, 1, 0, 10, 1)            # linears / convolutions of that level on the 128x160 tile
+        unet2 = D.UNet2DConditionModel(**TINY_UNET).cuda().requires_grad_(False)   # fresh handle: no captured graphs, new workspace query
+        with torch.no_grad():
+            y = unet2(x, torch.tensor(981), ctx).sample
+    finally:
+        lib.dmx_gemm_plan_override(0, 0, 0, 0, 0, -1, 0)
+    assert_close(y, torch.from_numpy(g["eps_bf16emu"]), E2E_EMU, "tiny unet on the 160-column tiles vs bf16-emulating oracle")
+    assert rel_l2(y, ref) < 2e-2 and not torch.equal(y, ref), "the override must have changed at least one GEMM's tile plan"
+
+
 def test_tiny_vae(cuda, tiny_vae):
     from diffute_amd.synthetic import synth_images
     from diffute_amd.init import normal

@@ -62,7 +62,7 @@ def test_conv(cuda, case):
     assert_close(nchw(out), ref, TOL, name)
 
 
-@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (4, 1), (5, 1), (6, 1), (6, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2), (11, 1), (11, 2)])
+@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (4, 1), (5, 1), (6, 1), (6, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2), (11, 1), (11, 2), (12, 1), (12, 2)])
 def test_conv_every_tile_config(cuda, tn, sk):
     """All three tile configurations (128x64, 128x128, 256x128) and split-K give the same conv + epilogue."""
     from diffute_amd import ops
@@ -163,6 +163,11 @@ def test_geglu(cuda):
     ref = bf(a * F.gelu(gate))
     out = ops.linear(x.to(cuda).to(torch.bfloat16), ops.pack_linear_weight(w.to(cuda), geglu=True), bias=ops.pack_geglu_bias(b.to(cuda)), geglu=True)
     assert_close(out, ref, TOL, "geglu")
+    # every tile instance with a GEGLU epilogue, incl. the 128x320 tile (5 whole packed groups, here with an N tail: 1024 = 3.2 tiles)
+    x4 = x.to(cuda).to(torch.bfloat16).reshape(1, 1, M, C)
+    for tn in (2, 3, 7, 9, 10, 12):
+        o = ops.conv_gemm(x4, ops.pack_linear_weight(w.to(cuda), geglu=True), 8 * C, ksize=1, pad=0, bias=ops.pack_geglu_bias(b.to(cuda)), geglu=True, force_tn=tn)
+        assert_close(o.reshape(M, 4 * C), ref, TOL, f"geglu, tile instance {tn}")
 
 
 GN_CASES = [("gn_320_silu", 2, 16, 16, 320, 0, True, 1e-5), ("gn_960_concat", 2, 8, 8, 640, 320, True, 1e-5),
