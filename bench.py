@@ -24,11 +24,12 @@ if ROOT not in sys.path:
 
 # profile classes of the library (diffute_amd/csrc/kernels.h ProfClass); classes 10.. = one per GEMM tile config, named
 # after the rocprofv3 kernel name of that template instance dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP>
-GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0>"), ("gemm_128x64x32", "<2, 1, 32, 4, 2, 0>"), ("gemm_256x128x64", "<4, 2, 64, 3, 2, 0>"),
-             ("gemm_128x64x64_deep", "<2, 1, 64, 6, 2, 0>"), ("gemm_128x128x64_deep", "<2, 2, 64, 4, 2, 0>"), ("gemm_256x256x32", "<4, 4, 32, 4, 2, 0>"),
-             ("gemm_256x128x64_ws", "<2, 2, 64, 3, 4, 4>"), ("gemm_128x64x64_8w", "<4, 1, 64, 3, 1, 0>"), ("gemm_128x128x32_8w", "<4, 2, 32, 4, 1, 0>"),
-             ("gemm_128x128x64_8w", "<4, 2, 64, 3, 1, 0>")]
+GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2>"), ("gemm_128x64x32", "<2, 1, 32, 4, 2, 0, 2>"), ("gemm_256x128x64", "<4, 2, 64, 3, 2, 0, 2>"),
+             ("gemm_128x64x64_deep", "<2, 1, 64, 6, 2, 0, 2>"), ("gemm_128x128x64_deep", "<2, 2, 64, 4, 2, 0, 2>"), ("gemm_256x256x32", "<4, 4, 32, 4, 2, 0, 2>"),
+             ("gemm_256x128x64_ws", "<2, 2, 64, 3, 4, 4, 2>"), ("gemm_128x64x64_8w", "<4, 1, 64, 3, 1, 0, 2>"), ("gemm_128x128x32_8w", "<4, 2, 32, 4, 1, 0, 2>"),
+             ("gemm_128x128x64_8w", "<4, 2, 64, 3, 1, 0, 2>"), ("gemm_128x160x64", "<4, 5, 64, 2, 1, 0, 1>"), ("gemm_128x320x64", "<4, 5, 64, 2, 1, 0, 2>")]
 KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % t for n, t in GEMM_CFGS}
+KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true>(AttnArgs)"
 PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
                 "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS]
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -139,7 +140,8 @@ def main():
                 classes[name] = {"launches": int(n), "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / n, 2),
                                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if fl > 0 and ms > 0 else None,
                                  "gbps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-        dom = max((k for k in classes if k.startswith("gemm")), key=lambda k: classes[k]["total_ms"])
+        # dominant kernel = the MFMA kernel (a GEMM template instance or the attention kernel) with the most time in the pass
+        dom = max((k for k in classes if k.startswith("gemm") or k == "attention_d64"), key=lambda k: classes[k]["total_ms"])
         n, ms, fl, by = buf[4 * PROF_CLASSES.index(dom):4 * PROF_CLASSES.index(dom) + 4]
         ach = fl / (ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -17,7 +17,7 @@ from diffute_amd.synthetic import synth_inputs           # noqa: E402
 
 CLASSES = ["gemm_128x128", "gemm_128x64", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128", "wgrad", "gemm_256x128_ws",
            "gemm_128x128x32", "gemm_128x64x32", "gemm_256x128x64", "gemm_128x64x64_deep", "gemm_128x128x64_deep", "gemm_256x256x32", "gemm_256x128x64_ws",
-           "gemm_128x64x64_8w", "gemm_128x128x32_8w", "gemm_128x128x64_8w"]
+           "gemm_128x64x64_8w", "gemm_128x128x32_8w", "gemm_128x128x64_8w", "gemm_128x160x64", "gemm_128x320x64"]
 
 
 def main():

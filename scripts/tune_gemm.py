@@ -42,7 +42,7 @@ def weights(N, K, total=384 << 20):
 def main(path, only=""):
     shapes = {}
     for r in csv.DictReader(open(path)):
-        if int(r["class"]) not in (0, 1, 7, 9) and not 10 <= int(r["class"]) < 20:
+        if int(r["class"]) not in (0, 1, 7, 9) and not 10 <= int(r["class"]) < 22:
             continue
         if only and only not in r["tag"]:
             continue

@@ -24,7 +24,7 @@ from diffute_amd.synthetic import synth_inputs           # noqa: E402
 
 CFG_BK = {0: 32, 1: 32, 2: 64, 3: 64, 4: 64, 5: 32, 6: 64, 7: 64, 8: 32, 9: 64, 10: 64, 11: 64}   # template instance -> K-tile
 TN_TO_CFG = {2: 0, 1: 1, 3: 2, 4: 3, 5: 4, 6: 5, 7: 6, 8: 7, 9: 8, 10: 9, 11: 10, 12: 11}
-NCLASS = 20
+NCLASS = 22
 
 
 def main():

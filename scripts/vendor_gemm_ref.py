@@ -18,7 +18,7 @@ from tune_gemm import time_it, weights  # noqa: E402
 def main(path):
     shapes = {}
     for r in csv.DictReader(open(path)):
-        if int(r["class"]) not in (0, 1, 7, 9) and not 10 <= int(r["class"]) < 20:
+        if int(r["class"]) not in (0, 1, 7, 9) and not 10 <= int(r["class"]) < 22:
             continue
         m = dict(re.findall(r"(\w+)=(\d+)", r["tag"]))
         key = tuple(int(m[k]) for k in ("M", "N", "K", "ks", "st", "ups"))
