@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--min-gain", type=float, default=0.03)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--vae", action="store_true", help="tune the GEMMs of AutoencoderKL encode + decode of --batch images of 8*--latent px")
     ap.add_argument("--train", action="store_true", help="tune the GEMMs of one training forward + backward (use --batch 8) instead of the denoise pass")
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -47,7 +48,19 @@ def main():
     xin = torch.cat([lat, mask, mlat], 1); tt = torch.randint(0, 1000, (a.batch,), device=dev); tgt = torch.randn_like(lat)
     side = torch.cuda.Stream()
 
+    vae = D.AutoencoderKL(device=dev).requires_grad_(False) if a.vae else None
+    if a.vae:
+        from diffute_amd.synthetic import synth_images
+        img = synth_images(a.batch, 8 * a.latent, 8 * a.latent, device=dev)
+        zlat = torch.randn(a.batch, 4, a.latent, a.latent, device=dev)
+
     def run_pass():
+        if a.vae:
+            with torch.no_grad(), torch.cuda.stream(side):
+                for _ in range(a.steps):
+                    vae.encode(img); vae.decode(zlat)
+            torch.cuda.synchronize()
+            return
         if not a.train:
             D.denoise(unet, sched, lat, mask, mlat, ctx, a.steps)
             return
