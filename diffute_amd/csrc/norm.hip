@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void dmx_gn_apply_kernel(const GroupNormArgs 
 // 5..240 KB of bf16 - and keeps it in REGISTERS between the statistics and the normalisation: one read, one write,
 // one launch, no partials buffer and no grid-wide dependency.  Thread = (pixel lane r, unit `within` of the pixel's
 // cpg-channel segment); a unit is VEC dwords (2*VEC channels), so the per-thread channel affine sits in registers and
-// the pixel stride R is a constant.  Sum and sum of squares are taken in one pass over the registers.
+// the pixel stride R is a constant.  The variance is taken about the mean (second pass over the registers).
 // Blocks are dealt to XCDs round-robin, so XCD x gets the groups [x*G/8, (x+1)*G/8): a contiguous channel band whose
 // cache lines it shares with a neighbour only at the band edges.
 template <int VEC> struct GnVec;
