@@ -213,26 +213,33 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
     lp += lstep;
     __builtin_amdgcn_sched_barrier(0);               // issue each load before forming the next address
   }
-  // one pass over the registers for both moments (fp32 sums of <= 41k bf16 values: E[x^2] - mean^2 loses nothing that
-  // survives the bf16 rounding of the output; a second pass about the mean cost 10 % of this VALU-bound kernel)
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const bool ok = active && (r + k * R < p.HW);
+    float u = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const unsigned int w = gn_dw<VEC>(v[k], i);
+      u += __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
+    }
+    s += ok ? u : 0.f;
+  }
+  const float inv_n = 1.0f / ((float)p.HW * (float)cpg);
+  const float mean = gn_block_sum(s, red, t, nw) * inv_n;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < NU; ++k) {
     const bool ok = active && (r + k * R < p.HW);
-    float u = 0.f, uq = 0.f;
+    float u = 0.f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const unsigned int w = gn_dw<VEC>(v[k], i);
-      const float x0 = __uint_as_float(w << 16), x1 = __uint_as_float(w & 0xffff0000u);
-      u += x0 + x1;
-      uq = __builtin_fmaf(x0, x0, uq); uq = __builtin_fmaf(x1, x1, uq);
+      const float d0 = __uint_as_float(w << 16) - mean, d1 = __uint_as_float(w & 0xffff0000u) - mean;
+      u += d0 * d0 + d1 * d1;
     }
-    s += ok ? u : 0.f; q += ok ? uq : 0.f;
+    q += ok ? u : 0.f;
   }
-  const float inv_n = 1.0f / ((float)p.HW * (float)cpg);
-  const float mean = gn_block_sum(s, red, t, nw) * inv_n;
-  float var = gn_block_sum(q, red, t, nw) * inv_n - mean * mean;
-  var = var < 0.f ? 0.f : var;
+  const float var = gn_block_sum(q, red, t, nw) * inv_n;
   const float rstd = rsqrtf(var + p.eps);
   if (t < cpg) {
     const float a = rstd * p.gamma[g * cpg + t];
