@@ -5,8 +5,11 @@ reference calls as `trocr_model(pixel_values).last_hidden_state` (app.ipynb:546-
 train_diffute_v1.py:630-631,868-871; `trocr_model = VisionEncoderDecoderModel.from_pretrained(...).encoder`):
 patch embedding (conv k=stride=patch), [CLS] + learned position embeddings, pre-LayerNorm transformer blocks
 (x += dense(attn(LN_before x)); x += dense(gelu(dense(LN_after x)))), final LayerNorm.  The pooler of ViTModel does not
-touch last_hidden_state and is not restated.  Parity is unpinned by the reference (no tests, transformers absent here);
-parameter names follow the ViTModel state dict so real checkpoints load.
+touch last_hidden_state and is not restated.  PINNED against the reference's real dependency: scripts/pin_vit_oracle.py runs
+transformers' own `ViTModel` (installed in the build container) on seeded weights and commits its output as
+tests/golden/vit_transformers.npz; tests/test_host.py holds this restatement to it (and to the live ViTModel whenever
+transformers is importable).  Parameter names follow the checkpoint-era (transformers 4.x) ViTModel state dict that
+microsoft/trocr-* ships, so real checkpoints load.
 
 `emulate_bf16=True` rounds weights and every tensor the HIP path materialises to bf16 at the same points."""
 from collections import OrderedDict

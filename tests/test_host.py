@@ -250,3 +250,41 @@ def test_crop_ladder_and_origin_match_the_notebook_logic():
                 P.crop_origin(loc, cs, w, np.random.RandomState(9))
             continue
         assert P.crop_origin(loc, cs, w, np.random.RandomState(9)) == want
+
+
+def _vit_pin_cases():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pin_vit_oracle as PV
+    return PV
+
+
+def test_vit_oracle_pinned_to_transformers_fixture():
+    """N1 oracle pin: oracle/vit.py on the seeded weights reproduces what transformers' own ViTModel produced
+    (tests/golden/vit_transformers.npz, generated by scripts/pin_vit_oracle.py in the build container)."""
+    from oracle import vit as OVT
+    PV = _vit_pin_cases()
+    g = np.load(os.path.join(GOLD, "vit_transformers.npz"))
+    for name, (cfg, B) in PV.CASES.items():
+        assert str(g[f"{name}_cfg"]) == repr(sorted(cfg.items())), "fixture was generated for another config"
+        P = PV.seeded_state(cfg)
+        px = torch.from_numpy(g[f"{name}_pixels"])
+        assert px.shape[0] == B
+        ref = torch.from_numpy(g[f"{name}_last_hidden_state"])
+        out = OVT.vit_forward(P, cfg, px)
+        err = float((out - ref).norm() / ref.norm())
+        assert err <= 1e-5, f"{name}: oracle/vit.py vs transformers.ViTModel fixture rel-L2 {err:.2e}"
+
+
+def test_vit_oracle_against_live_transformers():
+    """the same pin against the installed transformers (any version whose ViTModel loads the mapped keys); skipped where
+    transformers is not importable"""
+    pytest.importorskip("transformers")
+    from oracle import vit as OVT
+    PV = _vit_pin_cases()
+    cfg, B = PV.CASES["tiny"]
+    P = PV.seeded_state(cfg)
+    px = torch.randn(B, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(5))
+    ref = PV.run_transformers(cfg, P, px)
+    out = OVT.vit_forward(P, cfg, px)
+    assert float((out - ref).norm() / ref.norm()) <= 1e-5
