@@ -62,6 +62,21 @@ def main():
     ap.add_argument("--mode", choices=("denoise", "train"), default="denoise",
                     help="denoise = BASELINE configs[1] (the headline metric); train = configs[3] DDP training step (scripts/bench_train.py)")
     args = ap.parse_args()
+    # ---- launcher contract: `--gpus N` is the number of ranks.  Under torchrun WORLD_SIZE must agree; a bare
+    # `python bench.py --gpus N` (N > 1) starts the N ranks itself as a CHILD torchrun - before this process has touched
+    # the GPU (never exec from a process that initialised HIP) - and forwards the child's output and exit code.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+    if int(env_world or "1") != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world or 1}; launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
     if args.mode == "train":                  # same launcher contract (torchrun env), per-GPU batch 8 at 512 px
         import runpy
         sys.argv = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "bench_train.py"),

@@ -298,7 +298,11 @@ static bool gn_slab_launch(const GroupNormArgs& a, hipStream_t stream, bool dry 
   const int nu = cdiv(a.HW, R);
   const int threads = cdiv(R * SU, 64) * 64;
   const dim3 grid(a.B * a.groups), block(threads);
-  static const int dbg = getenv("DMX_GN_SLAB_DBG") ? atoi(getenv("DMX_GN_SLAB_DBG")) : 0;   // measurement aid: 1 = no stores, 2 = no loads
+#ifdef DMX_GN_SLAB_PROBE      // probe builds only (results invalid): 1 = no stores, 2 = no loads
+  static const int dbg = getenv("DMX_GN_SLAB_DBG") ? atoi(getenv("DMX_GN_SLAB_DBG")) : 0;
+#else
+  constexpr int dbg = 0;
+#endif
 #define GN_SLAB(V_, N_)                                                                                      \
   if (vec == V_ && nu <= N_) {                                                                              \
     if (dry) return true;                                                                                   \

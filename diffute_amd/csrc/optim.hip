@@ -20,7 +20,7 @@ struct OptChunk { unsigned long long index; unsigned int count; unsigned int is_
 constexpr unsigned CHUNK = 65536;
 
 std::vector<OptChunk> build_chunks(const dmx_unet* u) {
-  struct R { size_t lo, hi; int bf; };
+  struct R { size_t lo, hi; int bf; size_t dst; };
   std::vector<R> rs;
   for (const ParamEntry& e : u->pt.entries()) {
     const PackRule& r = e.rule;
@@ -30,7 +30,7 @@ std::vector<OptChunk> build_chunks(const dmx_unet* u) {
       case PackRule::LINEAR: case PackRule::GEGLU_W: n = ((size_t)(r.rows - 1) * r.ld + r.cols) * 4; break;
       case PackRule::CONV: lo += (size_t)r.koff * 4; n = ((size_t)(r.rows - 1) * r.ld + (size_t)r.ks * r.ks * r.cols) * 4; break;
     }
-    rs.push_back({lo, lo + n, bf});
+    rs.push_back({lo, lo + n, bf, r.dst});
   }
   std::sort(rs.begin(), rs.end(), [](const R& a, const R& b) { return a.lo < b.lo; });
   std::vector<OptChunk> out;
@@ -40,7 +40,9 @@ std::vector<OptChunk> build_chunks(const dmx_unet* u) {
     if (lo >= hi) continue;
     covered = hi;
     for (size_t b = lo; b < hi; b += (size_t)CHUNK * 4) {
-      OptChunk c; c.index = b / 4; c.count = (unsigned)(std::min(hi, b + (size_t)CHUNK * 4) - b) / 4; c.is_bf16 = (unsigned)r.bf; c.arena_off = b / 2;
+      OptChunk c; c.index = b / 4; c.count = (unsigned)(std::min(hi, b + (size_t)CHUNK * 4) - b) / 4; c.is_bf16 = (unsigned)r.bf;
+      // gradient byte b <-> weights-arena byte: bf16 entries b/2; an fp32 entry at arena byte dst keeps 4-byte elements: dst + (b - 2*dst)
+      c.arena_off = r.bf ? b / 2 : r.dst + (b - 2 * r.dst);
       out.push_back(c);
     }
   }

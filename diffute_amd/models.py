@@ -165,11 +165,9 @@ class _HipModel(nn.Module):
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("diffute_amd: model parameters must be on the GPU (call .cuda()); there is no CPU path")
-        if getattr(self, "_fused", None) is not None and self._arena is not None:
-            return                                   # a fused optimizer updates the arena in place; the arena is authoritative
         sig = self._signature()
         if self._packed_sig == sig and self._arena is not None:
-            return
+            return                                   # (a fused optimizer updates the arena in place and leaves the Parameters alone)
         lib = _cabi.lib()
         k = self._kind
         nbytes = getattr(lib, f"dmx_{k}_arena_bytes")(self._h)
@@ -184,6 +182,9 @@ class _HipModel(nn.Module):
             _cabi.check(getattr(lib, f"dmx_{k}_load_param")(self._h, key.encode(), _cabi.ptr(src), st), f"load_param({key})")
         self._finalize(st)
         self._packed_sig = sig
+        fused = getattr(self, "_fused", None)
+        if fused is not None:                        # the Parameters changed under a fused optimizer (load_state_dict,
+            fused.reimport_masters()                 # broadcast_parameters, ...): they are the new master copy
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:
@@ -234,10 +235,10 @@ class UNet2DConditionModel(_HipModel):
     def __init__(self, seed=1234, device="cpu", **config):
         super().__init__()
         cfg = dict(SD2_INPAINT_UNET_CONFIG); cfg.update(config)
+        if isinstance(cfg["attention_head_dim"], int):       # diffusers accepts one int for every level
+            cfg["attention_head_dim"] = (cfg["attention_head_dim"],) * len(cfg["block_out_channels"])
         for k in ("block_out_channels", "attention_head_dim", "down_block_types", "up_block_types"):
             cfg[k] = tuple(cfg[k])
-        if isinstance(cfg["attention_head_dim"], int):
-            cfg["attention_head_dim"] = (cfg["attention_head_dim"],) * 4
         self.config = _Config(**cfg)
         if len(cfg["block_out_channels"]) != 4:
             raise ValueError("UNet2DConditionModel: exactly 4 resolution levels are supported")
@@ -300,8 +301,9 @@ class UNet2DConditionModel(_HipModel):
         _cabi.check(lib.dmx_unet_set_context(self._h, _cabi.ptr(ctx), int(ctx.dtype == torch.bfloat16), B, S,
                                              _cabi.ptr(sl["ctx_cache"]), sl["ctx_cache"].numel(),
                                              _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_set_context")
-        sl["ctx_key"] = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
-                         encoder_hidden_states.dtype)
+        # identity + version of the tensor object the K/V were projected from.  The strong reference keeps the allocator from
+        # handing the same address to a different tensor (a key on data_ptr would then silently reuse stale K/V).
+        sl["ctx_key"] = (encoder_hidden_states, encoder_hidden_states._version)
         sl["ctx_shape"] = (B, S)
 
     def forward_parts(self, parts, timesteps_dev, out=None, graph=False, slot=0):
@@ -403,7 +405,10 @@ class UNet2DConditionModel(_HipModel):
                 for ev in tb["events"]:
                     ev.record()                                # materialise the hipEvent_t handles
             ev_arr = (ctypes.c_void_p * n_ev)(*[ev.cuda_event for ev in tb["events"]])
+        fused = getattr(self, "_fused", None)
         with torch.cuda.stream(tb["fwd_stream"]):
+            if fused is not None:
+                fused.before_backward(tb["grads"])             # gradient accumulation: stash what earlier backwards left
             _cabi.check(lib.dmx_unet_train_backward(self._h, _cabi.ptr(tb["grads"]), _cabi.ptr(dpred), ev_arr, n_ev, _cabi.current_stream()),
                         "unet_train_backward")
         if sync is not None:
@@ -415,7 +420,9 @@ class UNet2DConditionModel(_HipModel):
                 reduce_buckets(tb["grads"], self._sync_plan(tb), sync["dist"], group=sync["group"],
                                wait_bucket=lambda i: side.wait_event(tb["events"][i]))
             tb["fwd_stream"].wait_stream(side)
-        if getattr(self, "_fused", None) is not None:      # the fused optimizer reads the gradient arena directly
+        if fused is not None:                              # the fused optimizer reads the gradient arena directly
+            with torch.cuda.stream(tb["fwd_stream"]):
+                fused.after_backward(tb["grads"])
             torch.cuda.current_stream(dpred.device).wait_stream(tb["fwd_stream"])
             return [None] * len(self._keys)
         out = []
@@ -448,9 +455,8 @@ class UNet2DConditionModel(_HipModel):
                 out = out.to(sample.dtype)
             return UNet2DConditionOutput(sample=out) if return_dict else (out,)
         self._ensure_packed()
-        key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
-               encoder_hidden_states.dtype)
-        if key != self._slot(0)["ctx_key"]:
+        ck = self._slot(0)["ctx_key"]
+        if ck is None or ck[0] is not encoder_hidden_states or ck[1] != encoder_hidden_states._version:
             self.set_context(encoder_hidden_states)
         B = sample.shape[0]
         if not torch.is_tensor(timestep):

@@ -17,33 +17,72 @@ import torch
 from . import _cabi
 
 
-class FusedAdamW:
+class FusedAdamW(torch.optim.Optimizer):
+    """Drop-in for `torch.optim.AdamW(unet.parameters(), ...)` in the reference's loop (train_diffute_v1.py:721-727,
+    :925-933): a torch Optimizer (so `get_scheduler(..., optimizer=optimizer)` / any LRScheduler can drive
+    `param_groups[0]["lr"]`, :745-750), `step()`, `zero_grad()`, `state_dict()` / `load_state_dict()`.  Gradient
+    accumulation (`accelerator.accumulate(unet)`, :873) works: every backward before the next `step()` / `zero_grad()`
+    ADDS to the gradient arena."""
+
     def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0,
                  ema_decay=None, ema_min_decay=0.0, ema_update_after_step=0, ema_use_warmup=False, ema_inv_gamma=1.0, ema_power=2.0 / 3.0):
+        unet._ensure_packed()
+        super().__init__(unet._param_list(), dict(lr=float(lr), betas=tuple(betas), eps=float(eps), weight_decay=float(weight_decay)))
         self.unet = unet
         self.ema_decay, self.ema_min_decay, self.ema_update_after_step = ema_decay, float(ema_min_decay), int(ema_update_after_step)
         self.ema_use_warmup, self.ema_inv_gamma, self.ema_power = bool(ema_use_warmup), float(ema_inv_gamma), float(ema_power)
-        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = float(lr), tuple(betas), float(eps), float(weight_decay), float(max_grad_norm or 0.0)
+        self.max_grad_norm = float(max_grad_norm or 0.0)
         self.t = 0
         lib = _cabi.lib()
-        unet._ensure_packed()
         dev = unet.device
         n = lib.dmx_unet_grad_bytes(unet._h) // 4
         self.masters = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        st = _cabi.current_stream()
-        for k, p in zip(unet._keys, unet._param_list()):
-            src = p.detach().to(torch.float32).contiguous()
-            _cabi.check(lib.dmx_unet_master_import(unet._h, _cabi.ptr(self.masters), k.encode(), _cabi.ptr(src), st), f"master_import({k})")
+        self._import_masters()
         self.ema = self.masters.clone() if ema_decay is not None else None      # shadow parameters start as a copy of the model
+        st = _cabi.current_stream()
         self.nchunks = lib.dmx_unet_optim_chunks(unet._h)
         self.table = torch.empty(lib.dmx_unet_optim_table_bytes(unet._h), dtype=torch.uint8, device=dev)
         _cabi.check(lib.dmx_unet_optim_table(unet._h, _cabi.ptr(self.table), self.table.numel(), st), "optim_table")
         self.scalars = torch.zeros(2, dtype=torch.float32, device=dev)          # (|g| before clipping, clip coefficient)
         self.ws = torch.empty(self.nchunks, dtype=torch.float32, device=dev)
         self.dirty = False
+        self._pending = 0                       # backward passes since the last step() / zero_grad()
+        self._acc = None                        # stash of the accumulated gradient while a further backward overwrites the arena
         unet._fused = self                      # the backward stops exporting per-parameter gradients; the arena is authoritative
+
+    # hyper-parameters live in param_groups[0] like in any torch optimizer (LR schedulers write "lr" there)
+    @property
+    def lr(self):
+        return float(self.param_groups[0]["lr"])
+
+    @property
+    def betas(self):
+        return tuple(self.param_groups[0]["betas"])
+
+    @property
+    def eps(self):
+        return float(self.param_groups[0]["eps"])
+
+    @property
+    def weight_decay(self):
+        return float(self.param_groups[0]["weight_decay"])
+
+    def _import_masters(self):
+        lib = _cabi.lib()
+        u = self.unet
+        st = _cabi.current_stream()
+        for k, p in zip(u._keys, u._param_list()):
+            src = p.detach().to(torch.float32).contiguous()
+            _cabi.check(lib.dmx_unet_master_import(u._h, _cabi.ptr(self.masters), k.encode(), _cabi.ptr(src), st), f"master_import({k})")
+
+    def reimport_masters(self):
+        """the torch Parameters were changed from outside (load_state_dict, broadcast_parameters): they replace the master
+        copy; the Adam moments are kept (what torch.optim.AdamW does when parameters are overwritten in place).  Called by
+        UNet2DConditionModel._ensure_packed, which has just re-packed the weights arena from the same Parameters."""
+        self._import_masters()
+        self.dirty = False
 
     @property
     def grad_norm(self):
@@ -57,10 +96,29 @@ class FusedAdamW:
         cur = 1.0 - (1.0 + step / self.ema_inv_gamma) ** -self.ema_power if self.ema_use_warmup else (1.0 + step) / (10.0 + step)
         return max(min(cur, float(self.ema_decay)), self.ema_min_decay)
 
-    def zero_grad(self, set_to_none=True):
-        """the backward overwrites the gradient arena; nothing to clear"""
+    # ---- gradient accumulation: the HIP backward WRITES the arena, so a backward that follows another one without a
+    # step() in between first stashes the arena and adds the stash back afterwards (UNet2DConditionModel._train_backward)
+    def before_backward(self, grads):
+        if self._pending > 0:
+            if self._acc is None:
+                self._acc = torch.empty_like(grads)
+            self._acc.copy_(grads)
 
-    def step(self):
+    def after_backward(self, grads):
+        if self._pending > 0:
+            grads.add_(self._acc)
+        self._pending += 1
+
+    def zero_grad(self, set_to_none=True):
+        """drops the accumulated gradient: the next backward starts from zero"""
+        self._pending = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("FusedAdamW.step: closures are not supported")
+        if self._pending == 0:
+            raise RuntimeError("FusedAdamW.step() without a backward pass since the last step() / zero_grad()")
         lib = _cabi.lib()
         u = self.unet
         tb = u._tb
@@ -77,6 +135,37 @@ class FusedAdamW:
         for sl in u._slots.values():
             sl["ctx_key"] = None                                     # cached context K/V were projected with the old weights
         self.dirty = True
+        self._pending = 0
+
+    # ---- checkpointing (accelerator.save_state / load_state, train_diffute_v1.py:664-690,955): packed arenas + hyper-parameters
+    def state_dict(self):
+        st = dict(step=self.t, masters=self.masters.clone(), exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone())
+        if self.ema is not None:
+            st["ema"] = self.ema.clone()
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        return dict(state=st, param_groups=groups, layout="diffute_amd packed fp32 arenas (dmx_unet_grad_range)")
+
+    def load_state_dict(self, sd):
+        st = sd["state"]
+        if st["masters"].numel() != self.masters.numel():
+            raise ValueError("FusedAdamW.load_state_dict: arena size mismatch (different UNet config)")
+        self.t = int(st["step"])
+        self.masters.copy_(st["masters"]); self.exp_avg.copy_(st["exp_avg"]); self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        if self.ema is not None and "ema" in st:
+            self.ema.copy_(st["ema"])
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in src.items() if k != "params"})
+        # the loaded masters become the weights: Parameters first, then the packed arena + derived copies from them
+        self.dirty = True
+        self.sync_to_model()
+        self.unet._packed_sig = None
+        fused, self.unet._fused = self.unet._fused, None        # re-pack without re-importing the masters we just loaded
+        try:
+            self.unet._ensure_packed()
+        finally:
+            self.unet._fused = fused
+        self.unet._arena_version = getattr(self.unet, "_arena_version", 0) + 1   # transposed weights follow at the next training forward
+        self._pending = 0
 
     def ema_state_dict(self):
         """the EMA shadow parameters as fp32 tensors in torch layouts (what `ema_unet.save_pretrained` would store)"""

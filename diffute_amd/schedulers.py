@@ -39,6 +39,18 @@ class _SchedulerBase:
 
     def __init__(self, **config):
         cfg = dict(SD2_SCHEDULER_CONFIG); cfg.update(config)
+        # options of the diffusers schedulers whose arithmetic is NOT implemented by the step kernels: refuse them instead of
+        # silently computing something else (DDPMScheduler's own default is clip_sample=True; SD2's scheduler config sets False)
+        if cfg.get("clip_sample"):
+            raise NotImplementedError("clip_sample=True is not implemented (the SD2-inpainting scheduler config uses clip_sample=false)")
+        if cfg.get("thresholding"):
+            raise NotImplementedError("thresholding=True is not implemented")
+        if cfg.get("variance_type", "fixed_small") != "fixed_small":
+            raise NotImplementedError(f"variance_type={cfg['variance_type']!r} is not implemented (only 'fixed_small')")
+        if cfg.get("timestep_spacing", "leading") != "leading":
+            raise NotImplementedError(f"timestep_spacing={cfg['timestep_spacing']!r} is not implemented (only 'leading')")
+        if cfg["prediction_type"] not in ("epsilon", "v_prediction"):
+            raise NotImplementedError(f"prediction_type={cfg['prediction_type']!r} is not implemented")
         self.config = _Config(**cfg)
         N = cfg["num_train_timesteps"]
         self.num_train_timesteps = N                      # read directly at train_diffute_v1.py:892
@@ -61,7 +73,7 @@ class _SchedulerBase:
         d = pretrained_model_name_or_path if subfolder is None else os.path.join(pretrained_model_name_or_path, subfolder)
         with open(os.path.join(d, "scheduler_config.json")) as f:
             cfg = json.load(f)
-        known = set(SD2_SCHEDULER_CONFIG)
+        known = set(SD2_SCHEDULER_CONFIG) | {"thresholding"}
         return cls(**{k: v for k, v in cfg.items() if k in known})
 
     def save_pretrained(self, save_directory):

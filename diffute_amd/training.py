@@ -7,8 +7,9 @@
     loss                      : mse_loss(pred.float(), target.float())                            (:918)
     backward / clip / AdamW   : loss.backward(); clip_grad_norm_(unet.parameters(), 1.0); optimizer.step()   (:925-930)
 
-Every FLOP of the models runs in the HIP library; torch provides the optimizer arithmetic on the fp32 master
-parameters (the fused multi-tensor AdamW is SURVEY.md 8f N3, not built yet) and the autograd plumbing.  With
+Every FLOP of the models runs in the HIP library; torch provides the autograd plumbing.  The optimizer is either
+diffute_amd.FusedAdamW (clipping + AdamW + EMA as one HIP pass over the packed fp32 arenas) or any
+torch optimizer over `unet.parameters()` (the backward then exports per-parameter gradients into `.grad`).  With
 `dist` set, gradients are averaged across ranks inside the backward (bucketed RCCL all-reduce of the packed gradient
 arena on a side stream, UNet2DConditionModel.set_gradient_sync)."""
 import torch

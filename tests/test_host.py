@@ -288,3 +288,17 @@ def test_vit_oracle_against_live_transformers():
     ref = PV.run_transformers(cfg, P, px)
     out = OVT.vit_forward(P, cfg, px)
     assert float((out - ref).norm() / ref.norm()) <= 1e-5
+
+
+def test_config_edge_cases_of_from_pretrained():
+    """a diffusers config.json may carry `attention_head_dim` as ONE int; scheduler options whose arithmetic the step
+    kernels do not implement are refused instead of silently ignored (DDPMScheduler's own default is clip_sample=True)."""
+    import diffute_amd as D
+    u = D.UNet2DConditionModel(block_out_channels=(64, 64, 64, 64), attention_head_dim=1, cross_attention_dim=128)
+    assert u.config.attention_head_dim == (1, 1, 1, 1)
+    for bad in (dict(clip_sample=True), dict(thresholding=True), dict(variance_type="learned_range"),
+                dict(timestep_spacing="trailing"), dict(prediction_type="sample"), dict(beta_schedule="squaredcos_cap_v2")):
+        for cls in (D.DDPMScheduler, D.DDIMScheduler):
+            with pytest.raises(NotImplementedError):
+                cls(**bad)
+    assert D.DDPMScheduler(clip_sample=False, variance_type="fixed_small").config.clip_sample is False

@@ -569,3 +569,82 @@ def test_training_loop_reduces_loss(cuda):
     assert losses[-1] < 0.66 * losses[0], f"loss did not fall: {losses[0]:.4f} -> {losses[-1]:.4f}"
     w1 = unet.state_dict()["mid_block.resnets.0.conv1.weight"]
     assert float((w1 - w0).abs().max()) > 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ contract details (round-1 advisor findings)
+def test_context_cache_is_keyed_on_the_tensor_object(cuda, tiny_unet):
+    """unet(sample, t, ehs) caches the cross-attention K/V of `ehs`; a NEW tensor that the caching allocator places at the
+    freed address of an earlier one (same shape, _version 0) must not hit the old entry."""
+    from diffute_amd.synthetic import synth_inputs
+    lat, mask, mlat, ctx = synth_inputs(1, 8, 8, 20, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1); t = torch.tensor(500)
+    with torch.no_grad():
+        want_b = tiny_unet(x, t, (ctx * -0.5).contiguous()).sample.clone()
+        e1 = ctx.clone(); p1 = e1.data_ptr()
+        ya = tiny_unet(x, t, e1).sample.clone()
+        del e1
+        e2 = torch.empty_like(ctx); e2.copy_(ctx * -0.5)           # usually lands on e1's address
+        same_addr = e2.data_ptr() == p1
+        yb = tiny_unet(x, t, e2).sample
+    assert torch.equal(yb, want_b) and not torch.equal(ya, yb), f"stale context K/V reused (same address: {same_addr})"
+    # in-place edits of the same tensor object are seen through _version
+    with torch.no_grad():
+        e2.mul_(-2.0)                                              # now == ctx
+        yc = tiny_unet(x, t, e2).sample
+    assert torch.equal(yc, ya)
+
+
+def test_fused_adamw_optimizer_contract(cuda):
+    """FusedAdamW inside the reference's loop shape (train_diffute_v1.py:745-750, :873, :925-933): gradient accumulation over
+    two micro-batches == one step on their summed loss; an LR scheduler drives param_groups; state_dict()/load_state_dict()
+    round-trip the packed state; load_state_dict on the MODEL after the optimizer exists reaches the arena and the masters."""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from diffute_amd.synthetic import synth_inputs
+    lat, mask, mlat, ctx = synth_inputs(2, 8, 8, 20, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1); t = torch.tensor([500, 40], device=cuda); target = torch.zeros(2, 4, 8, 8, device=cuda)
+    hp = dict(lr=1e-3, weight_decay=1e-2, max_grad_norm=0.0)
+    a = D.UNet2DConditionModel(**TINY_UNET).cuda(); oa = D.FusedAdamW(a, **hp)
+    b = D.UNet2DConditionModel(**TINY_UNET).cuda(); ob = D.FusedAdamW(b, **hp)
+    assert isinstance(oa, torch.optim.Optimizer)
+    # a: two accumulated micro-batches (each sample's loss / 2); b: the batch of two in one backward (mean over both)
+    for i in range(2):
+        (mse_loss(a(x[i:i + 1].contiguous(), t[i:i + 1].contiguous(), ctx[i:i + 1].contiguous()).sample, target[i:i + 1]) * 0.5).backward()
+    mse_loss(b(x, t, ctx).sample, target).backward()
+    def flat_grads(m):                    # the arena also holds non-gradient regions (derived copies, row padding): export per parameter
+        from diffute_amd import _cabi
+        out = []
+        for k, p in zip(m._keys, m._param_list()):
+            g = torch.empty(p.shape, dtype=torch.float32, device=cuda)
+            _cabi.check(_cabi.lib().dmx_unet_grad_export(m._h, _cabi.ptr(m._tb["grads"]), k.encode(), _cabi.ptr(g), _cabi.current_stream()), "grad_export")
+            out.append(g.reshape(-1))
+        return torch.cat(out)
+    ga = flat_grads(a); gb = flat_grads(b)
+    assert rel_l2(ga, gb) < 2e-2, f"accumulated gradient differs from the batched one: {rel_l2(ga, gb):.2e}"
+    oa.step(); ob.step()
+    with pytest.raises(RuntimeError):
+        oa.step()                                                   # no backward since the last step
+    # zero_grad drops what was accumulated
+    (mse_loss(a(x, t, ctx).sample, target)).backward(); g1 = flat_grads(a)
+    oa.zero_grad()
+    (mse_loss(a(x, t, ctx).sample, target)).backward()
+    assert torch.equal(flat_grads(a), g1)
+    oa.step()
+    # LR scheduler (get_scheduler("constant_with_warmup") is a LambdaLR)
+    sch = torch.optim.lr_scheduler.LambdaLR(oa, lambda s: min(1.0, (s + 1) / 4))
+    assert abs(oa.lr - 0.25e-3) < 1e-12
+    mse_loss(a(x, t, ctx).sample, target).backward(); oa.step(); sch.step()
+    assert abs(oa.lr - 0.5e-3) < 1e-12
+    # optimizer checkpoint round trip: a fresh model + optimizer continue bit-identically
+    sd_opt = oa.state_dict(); sd_model = {k: v.clone() for k, v in a.state_dict().items()}
+    c = D.UNet2DConditionModel(**TINY_UNET, seed=99).cuda(); oc = D.FusedAdamW(c, **hp)
+    c.load_state_dict(sd_model)                                     # AFTER the optimizer was built: must reach arena + masters
+    with torch.no_grad():
+        assert torch.equal(c.requires_grad_(False)(x, t, ctx).sample, a.requires_grad_(False)(x, t, ctx).sample)
+    a.requires_grad_(True); c.requires_grad_(True)
+    oc.load_state_dict(sd_opt)
+    assert oc.t == oa.t and abs(oc.lr - oa.lr) < 1e-12
+    for m, o in ((a, oa), (c, oc)):
+        mse_loss(m(x, t, ctx).sample, target).backward(); o.step()
+    sa, sc = a.state_dict(), c.state_dict()
+    assert all(torch.equal(sa[k], sc[k]) for k in sa), "resumed run diverged from the original"
