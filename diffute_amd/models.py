@@ -33,6 +33,28 @@ SD_VAE_CONFIG = dict(
     layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215, act_fn="silu", sample_size=512)
 
 
+# diffusers config.json keys whose non-default values select arithmetic this library does not implement: a checkpoint that
+# sets one of them differently is refused by from_pretrained / the constructor instead of being run as something else.
+_UNET_ONLY_SUPPORTED = dict(
+    act_fn="silu", center_input_sample=False, conv_in_kernel=3, conv_out_kernel=3, downsample_padding=1, dual_cross_attention=False,
+    flip_sin_to_cos=True, mid_block_scale_factor=1, mid_block_type="UNetMidBlock2DCrossAttn", only_cross_attention=False,
+    resnet_out_scale_factor=1.0, resnet_skip_time_act=False, resnet_time_scale_shift="default", time_embedding_type="positional",
+    upcast_attention=False, use_linear_projection=True, class_embeddings_concat=False)
+_UNET_MUST_BE_NONE = ("addition_embed_type", "class_embed_type", "cross_attention_norm", "encoder_hid_dim", "mid_block_only_cross_attention",
+                      "num_class_embeds", "projection_class_embeddings_input_dim", "time_cond_proj_dim", "time_embedding_act_fn",
+                      "time_embedding_dim", "timestep_post_act")
+_VAE_ONLY_SUPPORTED = dict(act_fn="silu")
+
+
+def _check_supported(kind, cfg, only, must_be_none=()):
+    for k, want in only.items():
+        if k in cfg and cfg[k] is not None and cfg[k] != want:
+            raise NotImplementedError(f"{kind}: config {k}={cfg[k]!r} is not implemented (only {want!r})")
+    for k in must_be_none:
+        if cfg.get(k) is not None:
+            raise NotImplementedError(f"{kind}: config {k}={cfg[k]!r} is not implemented (only null)")
+
+
 class _Config(SimpleNamespace):
     def __getitem__(self, k):
         return getattr(self, k)
@@ -225,7 +247,13 @@ class _HipModel(nn.Module):
 
     @staticmethod
     def _convert_legacy_keys(sd):
-        return sd
+        """Linear weights some exporters store as 1x1 convolutions ([C_out, C_in, 1, 1]) are squeezed."""
+        out = OrderedDict()
+        for k, v in sd.items():
+            if v.ndim == 4 and v.shape[2:] == (1, 1) and (k.endswith("proj_in.weight") or k.endswith("proj_out.weight")):
+                v = v[:, :, 0, 0]
+            out[k] = v
+        return out
 
 
 class UNet2DConditionModel(_HipModel):
@@ -235,6 +263,10 @@ class UNet2DConditionModel(_HipModel):
     def __init__(self, seed=1234, device="cpu", **config):
         super().__init__()
         cfg = dict(SD2_INPAINT_UNET_CONFIG); cfg.update(config)
+        _check_supported("UNet2DConditionModel", cfg, _UNET_ONLY_SUPPORTED, _UNET_MUST_BE_NONE)
+        for bt in tuple(cfg["down_block_types"]) + tuple(cfg["up_block_types"]):
+            if bt not in ("CrossAttnDownBlock2D", "DownBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"):
+                raise NotImplementedError(f"UNet2DConditionModel: block type {bt!r} is not implemented")
         if isinstance(cfg["attention_head_dim"], int):       # diffusers accepts one int for every level
             cfg["attention_head_dim"] = (cfg["attention_head_dim"],) * len(cfg["block_out_channels"])
         for k in ("block_out_channels", "attention_head_dim", "down_block_types", "up_block_types"):
@@ -531,6 +563,12 @@ class AutoencoderKL(_HipModel):
     def __init__(self, seed=4321, device="cpu", **config):
         super().__init__()
         cfg = dict(SD_VAE_CONFIG); cfg.update(config)
+        _check_supported("AutoencoderKL", cfg, _VAE_ONLY_SUPPORTED)
+        for k, want in (("down_block_types", "DownEncoderBlock2D"), ("up_block_types", "UpDecoderBlock2D")):
+            if k in cfg:
+                cfg[k] = tuple(cfg[k])
+                if any(b != want for b in cfg[k]) or len(cfg[k]) != len(cfg["block_out_channels"]):
+                    raise NotImplementedError(f"AutoencoderKL: {k}={cfg[k]!r} is not implemented (only {want!r} per level)")
         cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
         self.config = _Config(**cfg)
         c = _cabi.VAEConfig()

@@ -110,16 +110,19 @@ def denoise(unet, scheduler, latents, mask, masked_image_latents, encoder_hidden
 
 @torch.no_grad()
 def edit_latents(unet, vae, scheduler, image, masked_image, mask, encoder_hidden_states, num_inference_steps,
-                 init_latents=None, generator=None):
+                 init_latents=None, generator=None, enc_noise=None, variance_noise=None):
     """The model part of text_editing() (app.ipynb:779-819): VAE-encode the masked crop, downsample the
-    mask, denoise from seeded noise, VAE-decode.  Pre/post-processing (crop, resize, paste) is out of scope."""
+    mask, denoise from seeded noise, VAE-decode.  `image` is unused by the arithmetic (the reference's encode of it,
+    app.ipynb:781, is dead code: its result is overwritten at :798); enc_noise / variance_noise inject the two device-RNG
+    draws (latent_dist.sample(), DDPMScheduler.step) for tests.  Crop / resize / paste: diffute_amd.prepost."""
     sf = vae.config.scaling_factor
     f = 2 ** (len(vae.config.block_out_channels) - 1)
     m = mask_to_latent(mask, f)
-    mlat = vae.encode(masked_image).latent_dist.sample(generator=generator) * sf          # app.ipynb:793-794
+    dist = vae.encode(masked_image).latent_dist
+    mlat = (dist.sample(noise=enc_noise) if enc_noise is not None else dist.sample(generator=generator)) * sf   # app.ipynb:793-794
     B, _, H, W = masked_image.shape
     if init_latents is None:
         init_latents = torch.randn((B, vae.config.latent_channels, H // f, W // f),
                                    generator=torch.manual_seed(0), dtype=torch.float32).to(masked_image.device)  # :798
-    lat = denoise(unet, scheduler, init_latents, m, mlat, encoder_hidden_states, num_inference_steps)
+    lat = denoise(unet, scheduler, init_latents, m, mlat, encoder_hidden_states, num_inference_steps, variance_noise=variance_noise)
     return vae.decode(lat / sf).sample                                                    # app.ipynb:818-819

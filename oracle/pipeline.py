@@ -89,3 +89,26 @@ def vae_train_grads(P, cfg, x, target, emulate_bf16=False):
         loss = torch.mean((recon.float() - target.float()) ** 2)
         loss.backward()
     return float(loss.detach()), recon.detach(), {k: p.grad for k, p in Pg.items()}
+
+
+def initial_latents(shape, seed=0):
+    """P2 (app.ipynb:796-801): `randn_tensor(shape, generator=torch.manual_seed(0), dtype=fp32)` - a CPU draw (the
+    generator is a CPU generator, so diffusers' randn_tensor creates the tensor on the CPU and moves it afterwards)."""
+    return torch.randn(tuple(shape), generator=torch.manual_seed(seed), dtype=torch.float32)
+
+
+@torch.no_grad()
+def edit_latents(Pu, ucfg, Pv, vcfg, masked_image, mask, ctx, steps, enc_noise, scheduler="ddim", noise=None,
+                 emulate_bf16=False, init=None):
+    """The model part of text_editing() (app.ipynb:779-819) with the one device-RNG draw injected (`enc_noise` stands for
+    latent_dist.sample()'s randn, :793): masked-image latents = vae.encode(masked).sample() * sf, mask -> latent grid
+    (nearest), initial latents = seed-0 CPU randn * init_noise_sigma (=1), denoise loop, vae.decode(latents / sf)."""
+    from .vae import vae_decode
+    sf = vcfg["scaling_factor"]
+    f = 2 ** (len(vcfg["block_out_channels"]) - 1)
+    m = mask_to_latent(mask, f)
+    mlat = gaussian_sample(vae_encode_moments(Pv, vcfg, masked_image, emulate_bf16=emulate_bf16), enc_noise) * sf
+    B, _, H, W = masked_image.shape
+    lat0 = initial_latents((B, vcfg["latent_channels"], H // f, W // f)) if init is None else init
+    lat = denoise(Pu, ucfg, lat0, m, mlat, ctx, steps, scheduler, noise=noise, emulate_bf16=emulate_bf16)
+    return vae_decode(Pv, vcfg, lat / sf, emulate_bf16=emulate_bf16), lat, mlat

@@ -648,3 +648,28 @@ def test_fused_adamw_optimizer_contract(cuda):
         mse_loss(m(x, t, ctx).sample, target).backward(); o.step()
     sa, sc = a.state_dict(), c.state_dict()
     assert all(torch.equal(sa[k], sc[k]) for k in sa), "resumed run diverged from the original"
+
+
+def test_edit_latents_end_to_end(cuda, tiny_unet, tiny_vae):
+    """P1 + P2 + P3 + P4 + T2 + T3 in the order of text_editing() (app.ipynb:779-819): encode the masked crop (injected
+    sampling noise), downsample the mask, start from the seed-0 CPU randn, denoise, decode - product (HIP) vs oracle."""
+    import diffute_amd as D
+    from diffute_amd.init import normal
+    from diffute_amd.synthetic import text_crop_images
+    from oracle import pipeline as OP, unet as OU, vae as OV
+    img = text_crop_images(1, 128, 128, device=cuda)
+    mask = torch.zeros(1, 1, 128, 128, device=cuda); mask[:, :, 48:80, 16:112] = 1.0
+    masked = img * (mask < 0.5)
+    ctx = normal(2, 13, 77 * 128, cuda).reshape(1, 77, 128)
+    en = normal(4, 71, 4 * 16 * 16, cuda).reshape(1, 4, 16, 16)
+    out = D.edit_latents(tiny_unet, tiny_vae, D.DDIMScheduler(), img, masked, mask, ctx, 3, enc_noise=en)
+    Pu = {k: v.detach().cpu() for k, v in tiny_unet.state_dict().items()}
+    Pv = {k: v.detach().cpu() for k, v in tiny_vae.state_dict().items()}
+    ref, lat, mlat = OP.edit_latents(Pu, OU.TINY_UNET, Pv, OV.TINY_VAE, masked.cpu(), mask.cpu(), ctx.cpu(), 3, en.cpu(), emulate_bf16=True)
+    assert out.shape == (1, 3, 128, 128)
+    e = assert_close(out, ref, 4e-2, "edit_latents (encode -> 3 DDIM steps from the seed-0 latents -> decode) vs bf16-emulating oracle")
+    print(f"edit_latents end to end rel-L2 {e:.2e}")
+    # explicit init_latents == the default seed-0 draw
+    init = OP.initial_latents((1, 4, 16, 16)).to(cuda)
+    out2 = D.edit_latents(tiny_unet, tiny_vae, D.DDIMScheduler(), img, masked, mask, ctx, 3, enc_noise=en, init_latents=init)
+    assert torch.equal(out, out2)
