@@ -22,6 +22,8 @@ class GemmDesc(ctypes.Structure):
         ("bias", c_void_p), ("rowbias", c_void_p), ("rows_per_group", c_int), ("ldrb", c_int),
         ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("geglu", c_int),
         ("force_tn", c_int), ("force_splitk", c_int), ("group_m", c_int), ("timing", c_void_p), ("dbg", c_int), ("act", c_int),
+        ("rowstats_out", c_void_p), ("ln_stats", c_void_p), ("ln_tiles", c_int), ("ln_c1", c_void_p), ("ln_c2", c_void_p),
+        ("ln_C", c_int), ("ln_eps", c_float),
     ]
 
 
@@ -47,6 +49,7 @@ _PROTOS = {
     "dmx_last_error": (c_char_p, []),
     "dmx_conv_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "dmx_conv_gemm": (c_int, [POINTER(GemmDesc), _P, c_size_t, _P]),
+    "dmx_conv_gemm_rowstats_tiles": (c_int, [POINTER(GemmDesc)]),
     "dmx_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(GemmDesc), c_int]),
     "dmx_conv_wgrad": (c_int, [POINTER(GemmDesc), _P, c_int, _P, c_int, _P, c_size_t, _P]),
     "dmx_colsum_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -19,7 +19,15 @@ static GemmArgs to_args(const dmx_gemm_desc* d) {
   a.bias = d->bias; a.rowbias = d->rowbias; a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1; a.ldrb = d->ldrb;
   a.res = (const bf16*)d->res; a.ldres = d->ldres; a.out = d->out; a.ldo = d->ldo; a.out_f32 = d->out_f32; a.geglu = d->geglu;
   a.force_tn = d->force_tn; a.force_splitk = d->force_splitk; a.group_m = d->group_m; a.timing = d->timing; a.dbg = d->dbg; a.act = d->act;
+  a.rowstats_out = d->rowstats_out; a.ln_stats = d->ln_stats; a.ln_tiles = d->ln_tiles; a.ln_c1 = d->ln_c1; a.ln_c2 = d->ln_c2;
+  a.ln_C = d->ln_C; a.ln_eps = d->ln_eps;
   return a;
+}
+extern "C" int dmx_conv_gemm_rowstats_tiles(const dmx_gemm_desc* d) {
+  if (!d) return 0;
+  GemmArgs a = to_args(d);
+  if (!a.rowstats_out) a.rowstats_out = (float*)8;      // the plan depends on whether statistics are emitted
+  return dmx_gemm_tiles_n(a);
 }
 extern "C" size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d) { return d ? dmx_gemm_workspace_bytes(to_args(d)) : 0; }
 extern "C" int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {

@@ -786,7 +786,7 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[12] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[15] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
@@ -802,7 +802,14 @@ static const TileCfg kCfg[12] = {            // measured (scripts/gemm_timeline.
                                             // count of this UNet (320 k), so no column of a tile is wasted; force_tn = 11 / tuned table
     {128, 320, 64, 256, 2.00, 10.0},        // 128x320x64, eight waves (4 x 2), 32x160 sub-tiles, 2-buffer ring (112 KB, 1 block/CU): five whole
                                             // GEGLU groups per tile - the feed-forward GEMMs (N = 8C) tile without a partial round; force_tn = 12
+    // 12..14: the persistent direct-GEMM kernel of lin.hip (linear layers; no split-K): force_tn = 13 / 14 / 15 or the tuned table
+    {128, 160, 64, 256, 1.0, 5.0},          // 4 waves x (32 x 160), 3-stage ring
+    {128, 64, 64, 256, 0.6, 5.0},           // 4 waves x (32 x 64), 4-stage ring (small M: more tiles)
+    {128, 256, 32, 256, 1.2, 5.0},          // 8 waves (4 x 2) x (32 x 128), 4-stage ring of 32-deep K-tiles: GEGLU feed-forward and other wide-N linears
 };
+int dmx_lin_launch(const GemmArgs& a, int lin, hipStream_t stream);
+bool dmx_lin_applicable(const GemmArgs& a, int lin);
+int dmx_lin_cfg_strips(int lin);
 
 static double plan_cost(const GemmArgs& a, int c, int sk) {
   const TileCfg& T = kCfg[c];
@@ -839,9 +846,10 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
   if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
     const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
     for (const TunedPlan& tp : g_plan_overrides)
-      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 12 && !(tp.cfg >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
+      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 15 && !(tp.cfg >= 12 && !dmx_lin_applicable(a, tp.cfg - 12)) && !(tp.cfg >= 10 && tp.cfg < 12 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
           !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
         const int bk = kCfg[tp.cfg].bk, nkt = a.K / bk;
+        if (tp.cfg >= 12) { *cfg_out = tp.cfg; *splitk_out = 1; *ktps_out = nkt; return; }
         if (a.K % bk || a.Cin % bk || a.cx0 % bk || a.Ktaps % bk || (a.Ktaps < a.K && a.cs0 % bk) || tp.sk < 1 || (tp.sk > 1 && nkt / tp.sk < 4)) break;   // not applicable: normal plan
         int ktps = cdiv(nkt, tp.sk);
         *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
@@ -849,13 +857,18 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
       }
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) &&
-          !(tp.cfg >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
+          !(tp.cfg >= 12 && !dmx_lin_applicable(a, tp.cfg - 12)) &&
+          !(tp.cfg >= 10 && tp.cfg < 12 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
           !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
         const int nkt = a.K / kCfg[tp.cfg].bk;
+        if (tp.cfg >= 12) { *cfg_out = tp.cfg; *splitk_out = 1; *ktps_out = nkt; return; }
         int ktps = cdiv(nkt, tp.sk);
         *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
         return;
       }
+  }
+  if (a.force_tn >= 13 && a.force_tn <= 15 && dmx_lin_applicable(a, a.force_tn - 13)) {
+    *cfg_out = a.force_tn - 1; *splitk_out = 1; *ktps_out = a.K / kCfg[a.force_tn - 1].bk; return;
   }
   for (int c = 0; c < 12; ++c) {
     const TileCfg& T = kCfg[c];
@@ -896,7 +909,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
 int dmx_gemm_tiles_n(const GemmArgs& a) {
   int c, sk, ktps;
   dmx_gemm_plan(a, &c, &sk, &ktps);
-  return cdiv(a.N, kCfg[c].bn);
+  return cdiv(a.N, kCfg[c].bn) * (c >= 12 ? dmx_lin_cfg_strips(c - 12) : 1);     // lin.hip emits one row-statistics partial per wave column strip
 }
 
 size_t dmx_gemm_workspace_bytes(const GemmArgs& a) {
@@ -949,6 +962,14 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     a.partial = (float*)workspace;
   }
   const TileCfg& T = kCfg[c];
+  if (c >= 12) {
+    const double flops = 2.0 * a.M * (double)a.N * a.K;
+    const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * (a.geglu ? a.N / 2 : a.N));
+    char tag[96];
+    snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=1 st=1 ups=0 tn=%d sk=1", a.M, a.N, a.K, c + 1);
+    ProfScope ps((ProfClass)(PROF_GEMM_CFG0 + c), stream, flops, bytes, tag);
+    return dmx_lin_launch(a, c - 12, stream);
+  }
   dim3 grid((a.ups2 ? 4 * cdiv(a.M4, T.bm) : cdiv(a.M, T.bm)) * cdiv(a.N, T.bn), sk, 1);
   // algorithmic work of this launch: 2*M*N*K flops; bytes = activations read once + weights + output
   const double flops = 2.0 * a.M * (double)a.N * a.K;

@@ -6,7 +6,7 @@
 // Optional per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg).
 enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN = 3, PROF_GNORM = 4, PROF_LNORM = 5,
                  PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_WGRAD = 8, PROF_GEMM256WS = 9,
-                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_NCLASS = 22 };
+                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_NCLASS = 25 };
 struct ProfScope {
   ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag = nullptr);
   ~ProfScope();

@@ -115,8 +115,11 @@ def conv_ups2x(x, wp, N, bias=None, force_tn=0, force_splitk=0):
 
 
 def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=None, rowbias=None,
-              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0, dbg=0, act=0):
-    """Fused conv / linear.  x0 (and x1) NHWC bf16; w packed bf16 [N][K].  Returns NHWC (bf16 or fp32)."""
+              res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0, dbg=0, act=0,
+              rowstats=False, ln=None):
+    """Fused conv / linear.  x0 (and x1) NHWC bf16; w packed bf16 [N][K].  Returns NHWC (bf16 or fp32).
+    rowstats=True: also returns the per-row (sum, sumsq) partials [tiles][M][2] of the rounded output (folded-LayerNorm
+    producer); ln=(stats, c1, c2, eps): folded-LayerNorm consumer (w must already be W*diag(gamma))."""
     B, H, W, C0 = x0.shape
     Cin = C0 + (x1.shape[-1] if x1 is not None else 0)
     OH, OW = H, W
@@ -152,10 +155,17 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
     d.force_tn = force_tn; d.force_splitk = force_splitk; d.group_m = group_m; d.dbg = dbg; d.act = act
     if timing is not None:
         d.timing = timing.data_ptr()
+    if ln is not None:
+        st, c1, c2, eps = ln
+        d.ln_stats = st.data_ptr(); d.ln_tiles = st.shape[0]; d.ln_c1 = c1.data_ptr(); d.ln_c2 = c2.data_ptr(); d.ln_C = K; d.ln_eps = eps
+    stats = None
+    if rowstats:
+        stats = torch.zeros(lib().dmx_conv_gemm_rowstats_tiles(ctypes.byref(d)), d.M, 2, dtype=torch.float32, device=x0.device)
+        d.rowstats_out = stats.data_ptr()
     wsb = lib().dmx_conv_gemm_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x0.device)
     check(lib().dmx_conv_gemm(ctypes.byref(d), ptr(ws), wsb, current_stream()), "conv_gemm")
-    return out
+    return (out, stats) if rowstats else out
 
 
 def _gather_desc(x0, x1, ksize, stride, pad, ups, direct):
@@ -202,12 +212,16 @@ def colsum(dy, groups=1, into=None):
     return out
 
 
-def linear(x, w, bias=None, res=None, geglu=False, out_f32=False, act=0):
+def linear(x, w, bias=None, res=None, geglu=False, out_f32=False, act=0, force_tn=0, rowstats=False, ln=None, timing=None, dbg=0):
     """x [..., K] bf16 (2-D view [rows][K]) @ w[N][K]^T."""
     K = x.shape[-1]
     x4 = x.reshape(1, 1, -1, K)
     r4 = None if res is None else res.reshape(1, 1, -1, res.shape[-1])
-    y = conv_gemm(x4, w, w.shape[0], ksize=1, pad=0, bias=bias, res=r4, geglu=geglu, out_f32=out_f32, act=act)
+    y = conv_gemm(x4, w, w.shape[0], ksize=1, pad=0, bias=bias, res=r4, geglu=geglu, out_f32=out_f32, act=act, force_tn=force_tn,
+                  rowstats=rowstats, ln=ln, timing=timing, dbg=dbg)
+    if rowstats:
+        y, st = y
+        return y.reshape(*x.shape[:-1], y.shape[-1]), st
     return y.reshape(*x.shape[:-1], y.shape[-1])
 
 

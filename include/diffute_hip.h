@@ -74,8 +74,17 @@ typedef struct dmx_gemm_desc {
                                        timestamps in 10 ns ticks (measurement aid), normally NULL */
   int dbg;                          /* measurement aid, must be 0: bit0 skips the MFMA phase, bit1 the DMA refills */
   int act;                          /* 1: exact (erf) GELU after the bias (ViT MLP fc1), bf16 output only             */
+  /* Folded LayerNorm (diffusers BasicTransformerBlock norm1/2/3 in front of attn1.to_q|k|v, attn2.to_q, ff.net.0.proj,
+   * reached from unet(...) app.ipynb:814): the GEMM that PRODUCES the residual stream also emits, per output row, partial
+   * (sum, sum of squares) of its rounded output - rowstats_out [dmx_conv_gemm_rowstats_tiles(d)][M][2] fp32 - and the GEMM
+   * that CONSUMES LayerNorm(x) runs on the raw rows with w = W*diag(gamma) and finishes
+   * y = rstd*(acc - mean*ln_c1[n]) + ln_c2[n]   (ln_c1[n] = sum_k w[n][k], ln_c2[n] = sum_k beta[k] W[n][k] + bias[n]). */
+  float* rowstats_out;              /* producer side, or NULL                                                          */
+  const float* ln_stats; int ln_tiles;   /* consumer side: the producer's partials and how many it wrote per row       */
+  const float* ln_c1; const float* ln_c2; int ln_C; float ln_eps;   /* ln_C = normalised feature count (= K)           */
 } dmx_gemm_desc;
 size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d);
+int dmx_conv_gemm_rowstats_tiles(const dmx_gemm_desc* d);   /* partials per row that dmx_conv_gemm(d) will write to rowstats_out */
 int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
 /* K10 (Upsample2D: F.interpolate(scale 2, nearest) + conv3x3, the diffusers call inside pipeline_diffute.py's unet(...),
@@ -90,7 +99,7 @@ int dmx_conv_ups2x(const void* x, int ldx, int B, int IH, int IW, int Cin, const
                    void* out, int ldo, int force_tn, int force_splitk, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
 /* Tuning aid (scripts/tune_in_situ.py): override the tile plan of every GEMM with this (M, N, K, stride, ups) signature
- * (ups: 0, 1, or 2 for the phase-decomposed upsample conv) by template instance `cfg` (0..9) and split-K factor; cfg < 0
+ * (ups: 0, 1, or 2 for the phase-decomposed upsample conv) by template instance `cfg` (0..11: gemm.hip tiles; 12..14: the persistent linear kernel of lin.hip) and split-K factor; cfg < 0
  * clears all overrides.  Not thread-safe; captured hipGraphs keep the plan they were captured with. */
 int dmx_gemm_plan_override(int M, int N, int K, int stride, int ups, int cfg, int splitk);
 

@@ -10,11 +10,11 @@ from diffute_amd import ops  # noqa: E402
 
 dev = torch.device("cuda")
 import itertools
-cases = [(M, N, K, tn, dbg) for (M, N, K) in [(16384, 320, 320), (4096, 640, 640), (1024, 1280, 1280)] for tn in (1, 8) for dbg in (0,)]
+cases = [(M, N, K, tn, dbg) for (M, N, K) in [(16384, 320, 320), (4096, 640, 640), (1024, 1280, 1280), (16384, 2560, 320), (16384, 320, 2880)] for tn in (8, 9, 10, 11, 12) for dbg in (0,)]
 for (M, N, K, tn, dbg) in cases:
     x = torch.randn(1, 1, M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
-    bm, bn, bk = {1: (128, 64, 32), 2: (128, 128, 32), 3: (256, 128, 64), 4: (128, 64, 64), 5: (128, 128, 64), 6: (256, 256, 32), 7: (256, 128, 64), 8: (128, 64, 64)}[tn]
+    bm, bn, bk = {1: (128, 64, 32), 2: (128, 128, 32), 3: (256, 128, 64), 4: (128, 64, 64), 5: (128, 128, 64), 6: (256, 256, 32), 7: (256, 128, 64), 8: (128, 64, 64), 9: (128, 128, 32), 10: (128, 128, 64), 11: (128, 160, 64), 12: (128, 320, 64)}[tn]
     nb = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     tim = torch.zeros(nb, 4, dtype=torch.int64, device=dev)
     for _ in range(3):

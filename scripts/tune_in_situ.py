@@ -22,9 +22,9 @@ import diffute_amd as D                                  # noqa: E402
 from diffute_amd import _cabi                            # noqa: E402
 from diffute_amd.synthetic import synth_inputs           # noqa: E402
 
-CFG_BK = {0: 32, 1: 32, 2: 64, 3: 64, 4: 64, 5: 32, 6: 64, 7: 64, 8: 32, 9: 64, 10: 64, 11: 64}   # template instance -> K-tile
-TN_TO_CFG = {2: 0, 1: 1, 3: 2, 4: 3, 5: 4, 6: 5, 7: 6, 8: 7, 9: 8, 10: 9, 11: 10, 12: 11}
-NCLASS = 22
+CFG_BK = {0: 32, 1: 32, 2: 64, 3: 64, 4: 64, 5: 32, 6: 64, 7: 64, 8: 32, 9: 64, 10: 64, 11: 64, 12: 64, 13: 64, 14: 32}   # template instance -> K-tile (12..14: lin.hip)
+TN_TO_CFG = {2: 0, 1: 1, 3: 2, 4: 3, 5: 4, 6: 5, 7: 6, 8: 7, 9: 8, 10: 9, 11: 10, 12: 11, 13: 12, 14: 13, 15: 14}
+NCLASS = 25
 
 
 def main():
@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--min-gain", type=float, default=0.03)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--only-cfgs", default="", help="comma-separated template instances to try (default: all)")
     ap.add_argument("--vae", action="store_true", help="tune the GEMMs of AutoencoderKL encode + decode of --batch images of 8*--latent px")
     ap.add_argument("--train", action="store_true", help="tune the GEMMs of one training forward + backward (use --batch 8) instead of the denoise pass")
     a = ap.parse_args()
@@ -110,11 +111,14 @@ def main():
         n0, ms0, tn0, sk0 = base[key]
         cfg0 = TN_TO_CFG[tn0]
         cands = []
+        only = [int(c) for c in a.only_cfgs.split(",")] if a.only_cfgs else None
         for cfg, bk in CFG_BK.items():
-            if K % bk:
+            if K % bk or (only is not None and cfg not in only):
                 continue
             nkt = K // bk
             for sk in (1, 2, 3, 4, 6, 8, 12, 16):
+                if sk > 1 and cfg >= 12:
+                    continue                               # the persistent linear kernel has no split-K
                 if sk > 1 and nkt // sk < (4 if bk == 64 else 8):
                     continue
                 if (cfg, sk) != (cfg0, sk0):
