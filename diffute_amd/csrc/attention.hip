@@ -13,6 +13,7 @@
 // so the P·V A-operand is two ds_read_b64 per MFMA.  Online softmax in fp32 (exp2 domain).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define KROW 72      // K tile row stride in elements (144 B: conflict-free ds_read_b128)
 #define VROW 68      // V^T tile row stride in elements (136 B: conflict-free ds_read_b64)
@@ -32,40 +33,52 @@
                : "=&v"(V[0]), "=&v"(V[1]), "=&v"(V[2]), "=&v"(V[3]), "=&v"(V[4]), "=&v"(V[5]), "=&v"(V[6]), "=&v"(V[7]) \
                : "v"(A), "i"(O0), "i"(O1), "i"(O2), "i"(O3), "i"(O4), "i"(O5), "i"(O6), "i"(O7) : "memory")
 
-template <bool VROWMAJOR>
-__global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) {
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+// R = 32-row query sub-blocks per wave (1 or 2), NW = waves per block: a block covers 32*R*NW query rows and streams the K/V
+// tiles ONCE for all of them.  R = 2 halves the K/V traffic out of L2 per query row (the S = 4096 self-attention of the
+// 64x64 level is bound by exactly that: every 128-row block re-streams the head's whole K/V), halves the LDS fragment
+// reads per MFMA (a K / V fragment feeds both sub-blocks) and gives the scheduler two independent softmax / MFMA chains
+// to interleave inside one wave.
+template <bool VROWMAJOR, int R, int NW>
+__global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_attn_d64_kernel(const AttnArgs p) {
+  constexpr int NT = 64 * NW, SL = 512 / NT;          // staging loads per thread per operand per tile (64 rows x 8 pieces)
   __shared__ __attribute__((aligned(16))) char smem[2 * (KT_BYTES + VT_BYTES)];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * R * NW) + wave * (32 * R);
   const float sl2 = p.scale * 1.4426950408889634f;
   const float thr = 8.0f / sl2;                      // defer-max threshold in raw-score units
 
-  // ---- Q fragment (MFMA B operand): query lr, d = 16*kk + 8*lh .. +8
-  bf16x8 qf[4];
-  {
-    int qrow = q0 + lr; if (qrow >= p.Sq) qrow = p.Sq - 1;
+  // ---- Q fragments (MFMA B operand): sub-block j, query lr, d = 16*kk + 8*lh .. +8
+  bf16x8 qf[R][4];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    int qrow = q0 + 32 * j + lr; if (qrow >= p.Sq) qrow = p.Sq - 1;
     const bf16* qp = p.q + ((size_t)b * p.Sq + qrow) * p.ldq + h * 64 + 8 * lh;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
+    for (int kk = 0; kk < 4; ++kk) qf[j][kk] = *(const bf16x8*)(qp + 16 * kk);
   }
 
-  // ---- staging assignment: chunk c = t + 256*i -> row c>>3, 16-byte piece c&7
+  // ---- staging assignment: chunk c = t + NT*i -> row c>>3, 16-byte piece c&7
   const int srow0 = t >> 3, spc = t & 7;
+  constexpr int SROWS = NT / 8;                       // rows covered per staging pass
   const bf16* kbase = p.k + (size_t)b * p.kv_rows * p.ldk + h * 64 + spc * 8;
   const bf16* vbase = VROWMAJOR ? (p.v + (size_t)b * p.kv_rows * p.ldv + h * 64 + spc * 8)
                                 : (p.vt + (size_t)(h * 64) * p.ldvt + (size_t)b * p.skv_stride + spc * 8);
-  u32x4 kreg[2], vreg[2];
+  u32x4 kreg[SL], vreg[SL];
   auto load_tile = [&](int kv0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = kv0 + srow0 + 32 * i; if (key >= p.Skv) key = p.Skv - 1;
+    for (int i = 0; i < SL; ++i) {
+      int key = kv0 + srow0 + SROWS * i; if (key >= p.Skv) key = p.Skv - 1;
       kreg[i] = *(const u32x4*)(kbase + (size_t)key * p.ldk);
       if (VROWMAJOR) {
         vreg[i] = *(const u32x4*)(vbase + (size_t)key * p.ldv);          // row = key (clamped: P is 0 past Skv)
       } else {
-        const int d = srow0 + 32 * i;
+        const int d = srow0 + SROWS * i;
         if (kv0 + spc * 8 < p.Skv) vreg[i] = *(const u32x4*)(vbase + (size_t)d * p.ldvt + kv0);
         else vreg[i] = (u32x4){0u, 0u, 0u, 0u};
       }
@@ -75,8 +88,8 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
     char* ks = smem + buf * (KT_BYTES + VT_BYTES);
     char* vs = ks + KT_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = srow0 + 32 * i;
+    for (int i = 0; i < SL; ++i) {
+      const int r = srow0 + SROWS * i;
       *(u32x4*)(ks + r * (KROW * 2) + spc * 16) = kreg[i];
       if (VROWMAJOR) {
         *(u32x4*)(vs + r * VRS + spc * 16) = vreg[i];
@@ -88,10 +101,14 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
     }
   };
 
-  f32x16 o[2];
+  f32x16 o[R][2];
+  float m_run[R], l_run[R];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int j = 0; j < R; ++j) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
+    m_run[j] = -INFINITY; l_run[j] = 0.f;
+  }
 
   const int ntiles = (p.Skv + 63) / 64;
   load_tile(0);
@@ -103,88 +120,90 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
     const char* ks = smem + (it & 1) * (KT_BYTES + VT_BYTES);
     const char* vs = ks + KT_BYTES;
 
-    // ---- S^T = K Q^T : s[kt][r] = score(query lr, key kv0 + 32kt + (r&3) + 8(r>>2) + 4lh)
-    f32x16 s[2];
+    // ---- S^T = K Q^T : s[j][kt][r] = score(query 32j + lr, key kv0 + 32kt + (r&3) + 8(r>>2) + 4lh); a K fragment feeds all sub-blocks
+    f32x16 s[R][2];
+    {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // folds to the inline constant 0 of the first MFMA
+      bf16x8 kf[2][4];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+      for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
+        for (int kt = 0; kt < 2; ++kt) kf[kt][kk] = *(const bf16x8*)(ks + (32 * kt + lr) * (KROW * 2) + (2 * kk + lh) * 16);
+      // kk outer, key-half inner: consecutive MFMAs go to DIFFERENT accumulators (a dependent 32x32x16 chain issues every 64 cycles, independent ones every 32)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8 kf = *(const bf16x8*)(ks + (32 * kt + lr) * (KROW * 2) + (2 * kk + lh) * 16);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt], 0, 0, 0);
-      }
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int j = 0; j < R; ++j) s[j][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][kk], qf[j][kk], kk == 0 ? zero : s[j][kt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // all eight fragment reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * R, 0);         // ... then the MFMAs in the order written
     }
     // ---- online softmax on the RAW scores: p = exp2(s*c - m*c) with c = scale*log2(e) folded into one fma per
     // score (no separate scaling pass); the running max is only raised - and O / l rescaled - when a score exceeds
     // it by more than 8/c (p stays <= 2^8: harmless in bf16/fp32, saves the O-wide rescale on almost every tile).
-    float mx = -INFINITY;
-    if (kv0 + 64 > p.Skv) {
+    bf16x8 pf[R][4];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      float mx = -INFINITY;
+      if (kv0 + 64 > p.Skv) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (key >= p.Skv) s[j][kt][r] = -INFINITY;
+          }
+      }
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= p.Skv) s[kt][r] = -INFINITY;
-        }
-    }
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (!__all(mx <= m_run[j] + thr)) {                // wave-uniform: some query row needs a higher reference max
+        const float m_new = fmaxf(m_run[j], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[j] - m_new) * sl2);
+        m_run[j] = m_new;
+        l_run[j] *= alpha;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (!__all(mx <= m_run + thr)) {                   // wave-uniform: some query row needs a higher reference max
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-    }
-    const float mc = -m_run * sl2;
-    float psum = 0.f;
-    bf16x8 pf[4];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        unsigned int w[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][8 * u + 2 * e], sl2, mc));
-          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][8 * u + 2 * e + 1], sl2, mc));
-          psum += p0 + p1;
-          w[e] = pack_bf2(p0, p1);
-        }
-        u32x4 wv = {w[0], w[1], w[2], w[3]};
-        pf[2 * kt + u] = __builtin_bit_cast(bf16x8, wv);
+        for (int i = 0; i < 16; ++i) { o[j][0][i] *= alpha; o[j][1][i] *= alpha; }
       }
-    l_run += psum;
+      const float mc = -m_run[j] * sl2;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          unsigned int w[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kt][8 * u + 2 * e], sl2, mc));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kt][8 * u + 2 * e + 1], sl2, mc));
+            psum += p0 + p1;
+            w[e] = pack_bf2(p0, p1);
+          }
+          u32x4 wv = {w[0], w[1], w[2], w[3]};
+          pf[j][2 * kt + u] = __builtin_bit_cast(bf16x8, wv);
+        }
+      l_run[j] += psum;
+    }
 
-    // ---- O^T += V^T P^T : k-slot e of step s4 <-> key 16*s4 + 4lh + (e&3) + 8(e>>2)
+    // ---- O^T += V^T P^T : k-slot e of step s4 <-> key 16*s4 + 4lh + (e&3) + 8(e>>2); a V fragment feeds all sub-blocks
     if (VROWMAJOR) {
       // V tile is [key][d]; the MFMA A operand (rows d, k-slots = keys) comes from LDS transpose reads:
       // group g = lane>>4 covers d = 32dt + 16(g&1) + 0..15 and key-half lh = g>>1; two reads per operand.
       const int p16 = lane & 15, g = lane >> 4;
-      const unsigned va = (unsigned)(unsigned long long)(const void*)vs +
-                          (unsigned)((4 * (g >> 1) + (p16 >> 2)) * VRS + (16 * (g & 1) + 4 * (p16 & 3)) * 2);
-      unsigned long long v0[8], v1[8];
-      DMX_TR8(v0, va, 0 * VRS, 8 * VRS, 16 * VRS, 24 * VRS, 32 * VRS, 40 * VRS, 48 * VRS, 56 * VRS);
-      DMX_TR8(v1, va, 64 + 0 * VRS, 64 + 8 * VRS, 64 + 16 * VRS, 64 + 24 * VRS, 64 + 32 * VRS, 64 + 40 * VRS, 64 + 48 * VRS, 64 + 56 * VRS);
-      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      const char* va = vs + (4 * (g >> 1) + (p16 >> 2)) * VRS + (16 * (g & 1) + 4 * (p16 & 3)) * 2;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const u32x4 vv = {(unsigned)v0[2 * s4], (unsigned)(v0[2 * s4] >> 32), (unsigned)v0[2 * s4 + 1], (unsigned)(v0[2 * s4 + 1] >> 32)};
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s4], o[0], 0, 0, 0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const u32x4 vv = {(unsigned)v1[2 * s4], (unsigned)(v1[2 * s4] >> 32), (unsigned)v1[2 * s4 + 1], (unsigned)(v1[2 * s4 + 1] >> 32)};
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s4], o[1], 0, 0, 0);
-      }
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(va + 64 * dt + (2 * s4) * 8 * VRS));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(va + 64 * dt + (2 * s4 + 1) * 8 * VRS));
+          const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int j = 0; j < R; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j][s4], o[j][dt], 0, 0, 0);
+        }
     } else {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -194,7 +213,8 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
           const u32x2 lo = *(const u32x2*)vp;
           const u32x2 hi = *(const u32x2*)(vp + 16);
           const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s4], o[dt], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < R; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j][s4], o[j][dt], 0, 0, 0);
         }
     }
 
@@ -202,37 +222,55 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_d64_kernel(const AttnArgs p) 
     __syncthreads();
   }
 
-  // ---- normalise and store: lane holds query lr, d = 32dt + 8g + 4lh + e
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  const int qrow = q0 + lr;
-  // training: keep the row's log2-sum-exp of the scaled scores, P = exp2(s*scale*log2e - lse)
-  if (p.lse && qrow < p.Sq && lh == 0) p.lse[((size_t)b * p.H + h) * p.Sq + qrow] = m_run * sl2 + log2f(l_tot);
-  if (qrow < p.Sq) {
-    bf16* op = p.o + ((size_t)b * p.Sq + qrow) * p.ldo + h * 64 + 4 * lh;
+  // ---- normalise and store: lane holds query 32j + lr, d = 32dt + 8g + 4lh + e
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int j = 0; j < R; ++j) {
+    const float l_tot = l_run[j] + __shfl_xor(l_run[j], 32);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + 32 * j + lr;
+    // training: keep the row's log2-sum-exp of the scaled scores, P = exp2(s*scale*log2e - lse)
+    if (p.lse && qrow < p.Sq && lh == 0) p.lse[((size_t)b * p.H + h) * p.Sq + qrow] = m_run[j] * sl2 + log2f(l_tot);
+    if (qrow < p.Sq) {
+      bf16* op = p.o + ((size_t)b * p.Sq + qrow) * p.ldo + h * 64 + 4 * lh;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 pk = {pack_bf2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv),
-                    pack_bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv)};
-        *(u32x2*)(op + 32 * dt + 8 * g) = pk;
-      }
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 pk = {pack_bf2(o[j][dt][4 * g] * inv, o[j][dt][4 * g + 1] * inv),
+                      pack_bf2(o[j][dt][4 * g + 2] * inv, o[j][dt][4 * g + 3] * inv)};
+          *(u32x2*)(op + 32 * dt + 8 * g) = pk;
+        }
+    }
   }
+}
+
+// block shape: 128 query rows (4 waves x 32) by default; 256 rows (4 waves x 64) once the grid still covers the chip with
+// the larger blocks (the 64x64-level and 768-px self / cross attention), DMX_ATTN_ROWS=128|256 pins it (measurement aid)
+static int attn_rows_per_block(const AttnArgs& a) {
+  static const int pin = getenv("DMX_ATTN_ROWS") ? atoi(getenv("DMX_ATTN_ROWS")) : 0;
+  if (pin == 128 || pin == 256) return pin;
+  const long blocks256 = (long)cdiv(a.Sq, 256) * a.H * a.B;
+  (void)blocks256;
+  return 128;                                        // measured: the 256-row blocks lose on every shape of the pass (fewer, fatter waves per SIMD)
 }
 
 int dmx_attention_launch(const AttnArgs& a, hipStream_t stream) {
   DMX_REQUIRE(a.B > 0 && a.H > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
   DMX_REQUIRE(a.kv_rows >= a.Skv, "attention: kv_rows=%d < Skv=%d", a.kv_rows, a.Skv);
   DMX_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "attention: strides must be multiples of 8 (ldq=%d ldk=%d)", a.ldq, a.ldk);
-  dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
+  const int rows = attn_rows_per_block(a);
+  dim3 grid(cdiv(a.Sq, rows), a.H, a.B);
   if (a.v) {
     DMX_REQUIRE(a.ldv % 8 == 0, "attention: ldv=%d must be a multiple of 8", a.ldv);
-    hipLaunchKernelGGL(dmx_attn_d64_kernel<true>, grid, dim3(256), 0, stream, a);
+    static const int r2 = getenv("DMX_ATTN_R2") ? 1 : 0;       // measurement aid: 4 waves x 64 rows instead of 8 waves x 32 rows
+    if (rows == 256 && r2) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 2, 4>), grid, dim3(256), 0, stream, a);
+    else if (rows == 256) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 8>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4>), grid, dim3(256), 0, stream, a);
   } else {
+    grid = dim3(cdiv(a.Sq, 128), a.H, a.B);
     DMX_REQUIRE(a.vt && a.ldvt % 8 == 0 && a.skv_stride % 8 == 0, "attention: V^T strides must be multiples of 8 (ldvt=%d skv_stride=%d)", a.ldvt, a.skv_stride);
     DMX_REQUIRE(a.skv_stride >= (a.Skv + 7) / 8 * 8, "attention: skv_stride=%d < Skv=%d rounded to 8", a.skv_stride, a.Skv);
-    hipLaunchKernelGGL(dmx_attn_d64_kernel<false>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((dmx_attn_d64_kernel<false, 1, 4>), grid, dim3(256), 0, stream, a);
   }
   return dmx_check_launch("dmx_attn_d64_kernel");
 }

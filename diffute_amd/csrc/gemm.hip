@@ -736,34 +736,43 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
   }
 }
 
-// split-K second pass: sum partials in fixed order, then the same epilogue.
+// split-K second pass: sum partials in fixed order, then the same epilogue.  One float4 per thread; the partial loads of a
+// thread are issued four at a time (independent, all in flight) and summed in split order - the pass is latency-bound,
+// not bandwidth-bound (a few MB), so what matters is loads in flight per thread and enough blocks to cover the chip.
 __global__ __launch_bounds__(256) void dmx_splitk_reduce_kernel(const GemmArgs p) {
   const size_t total4 = (size_t)p.M * p.N / 4;
   const size_t MN = (size_t)p.M * p.N;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t e0 = i * 4;
-    const int m = (int)(e0 / p.N);
-    const int n = (int)(e0 - (size_t)m * p.N);
-    f32x4 s = *(const f32x4*)(p.partial + e0);
-    for (int k = 1; k < p.splitk; ++k) {
-      const f32x4 q = *(const f32x4*)(p.partial + (size_t)k * MN + e0);
-      s += q;
-    }
-    float v[4] = {s[0], s[1], s[2], s[3]};
-    if (p.bias) { const f32x4 bv = *(const f32x4*)(p.bias + n); for (int e = 0; e < 4; ++e) v[e] += bv[e]; }
-    if (p.rowbias) { const f32x4 bv = *(const f32x4*)(p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb + n); for (int e = 0; e < 4; ++e) v[e] += bv[e]; }
-    if (p.res) {
-      const u32x2 rv = *(const u32x2*)(p.res + (size_t)m * p.ldres + n);
-      v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
-      v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
-    }
-    if (p.out_f32) {
-      f32x4 o = {v[0], v[1], v[2], v[3]};
-      *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = o;
-    } else {
-      u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-      *(u32x2*)((bf16*)p.out + (size_t)m * p.ldo + n) = pk;
-    }
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const size_t e0 = i * 4;
+  const int m = (int)(e0 / p.N);
+  const int n = (int)(e0 - (size_t)m * p.N);
+  // epilogue operands first: their latency overlaps the partial loads
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+  u32x2 rv = {0u, 0u};
+  if (p.bias) bv = *(const f32x4*)(p.bias + n);
+  if (p.rowbias) rb = *(const f32x4*)(p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb + n);
+  if (p.res) rv = *(const u32x2*)(p.res + (size_t)m * p.ldres + n);
+  const float* q = p.partial + e0;
+  f32x4 s = *(const f32x4*)q;
+  int k = 1;
+  for (; k + 3 < p.splitk; k += 4) {
+    const f32x4 a0 = *(const f32x4*)(q + (size_t)k * MN), a1 = *(const f32x4*)(q + (size_t)(k + 1) * MN);
+    const f32x4 a2 = *(const f32x4*)(q + (size_t)(k + 2) * MN), a3 = *(const f32x4*)(q + (size_t)(k + 3) * MN);
+    s += a0; s += a1; s += a2; s += a3;
+  }
+  for (; k < p.splitk; ++k) s += *(const f32x4*)(q + (size_t)k * MN);
+  float v[4] = {s[0] + bv[0] + rb[0], s[1] + bv[1] + rb[1], s[2] + bv[2] + rb[2], s[3] + bv[3] + rb[3]};
+  if (p.res) {
+    v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
+    v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+  }
+  if (p.out_f32) {
+    f32x4 o = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = o;
+  } else {
+    u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *(u32x2*)((bf16*)p.out + (size_t)m * p.ldo + n) = pk;
   }
 }
 
@@ -995,8 +1004,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   if (rc) return rc;
   if (sk > 1) {
     const size_t total4 = (size_t)a.M * a.N / 4;
-    int blocks = (int)((total4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = (int)((total4 + 255) / 256);
     ProfScope ps(PROF_SPLITK, stream, 0.0, 4.0 * sk * (double)a.M * a.N, tag);
     hipLaunchKernelGGL(dmx_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
     rc = dmx_check_launch("dmx_splitk_reduce_kernel");
