@@ -67,6 +67,7 @@ _PROTOS = {
     "dmx_layernorm": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P]),
     "dmx_attention_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "dmx_attention_fwd_v": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "dmx_attention_wide": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "dmx_attention_fwd_train": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "dmx_attention_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dmx_attention_bwd": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int,

@@ -161,6 +161,14 @@ extern "C" int dmx_attention_fwd(const void* q, int ldq, const void* k, int ldk,
   a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
   return dmx_attention_launch(a, (hipStream_t)stream);
 }
+extern "C" int dmx_attention_wide(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                                  void* o, int ldo, int B, int Sq, int Skv, int D, float scale, dmx_stream_t stream) {
+  DMX_REQUIRE(q && k && v && o, "attention_wide: null argument");
+  AttnWideArgs a{};
+  a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.v = (const bf16*)v; a.ldv = ldv; a.kv_rows = kv_rows;
+  a.o = (bf16*)o; a.ldo = ldo; a.B = B; a.Sq = Sq; a.Skv = Skv; a.D = D; a.scale = scale;
+  return dmx_attention_wide_launch(a, (hipStream_t)stream);
+}
 extern "C" int dmx_attention_fwd_v(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
                                    void* o, int ldo, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream) {
   DMX_REQUIRE(q && k && v && o, "attention: null argument");

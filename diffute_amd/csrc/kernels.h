@@ -140,6 +140,20 @@ struct AttnArgs {
 };
 int dmx_attention_launch(const AttnArgs& a, hipStream_t stream);
 
+// ------------------------------------------------------------------ attention_wide.hip (single head, d = 128 / 256 / 512: the VAE mid block)
+struct AttnWideArgs {
+  const bf16* q; int ldq;        // row (b*Sq + s), d contiguous
+  const bf16* k; int ldk;        // row (b*kv_rows + s)
+  const bf16* v; int ldv;        // row-major V, row (b*kv_rows + s)
+  int kv_rows;
+  bf16* o; int ldo;
+  int B, Sq, Skv, D;
+  float scale;
+  const bf16* zeros;             // filled by the launcher
+};
+bool dmx_attention_wide_supported(int D);
+int dmx_attention_wide_launch(AttnWideArgs a, hipStream_t stream);
+
 // ------------------------------------------------------------------ attention_bwd.hip (training)
 struct AttnBwdArgs {
   const bf16* q; int ldq; const bf16* k; int ldk; const bf16* v; int ldv; int kv_rows;   // as the forward (row-major V)

@@ -4,8 +4,9 @@
 // >95% of the FLOPs are the 3x3 convolutions (implicit GEMM on MFMA), GroupNorm+SiLU is the
 // HBM-bound remainder.  The asymmetric (0,1,0,1) pad of the encoder's stride-2 convs and the
 // decoder's nearest x2 upsamples are folded into the conv gather.  The single-head d=512
-// mid-block attention runs as QK^T GEMM -> fp32 row softmax -> PV GEMM per sample.
+// mid-block attention is one fused flash-style kernel (attention_wide.hip).
 #include <stdlib.h>
+#include <stdio.h>
 #include <math.h>
 #include "vae_model.h"
 
@@ -26,31 +27,32 @@ void big_conv(ParamTable& pt, CW& c, const std::string& p, int cout, int cin) {
 void attn_build(ParamTable& pt, AttnW& a, const std::string& p, int C) {
   a.C = C;
   a.gg = pt.f32(p + "group_norm.weight", C); a.gb = pt.f32(p + "group_norm.bias", C);
-  a.wq = pt.linear(p + "to_q.weight", C, C); a.bq = pt.f32(p + "to_q.bias", C);
-  a.wk = pt.linear(p + "to_k.weight", C, C); a.bk = pt.f32(p + "to_k.bias", C);
-  a.wv = pt.linear(p + "to_v.weight", C, C); a.bv = pt.f32(p + "to_v.bias", C);
+  // to_q | to_k | to_v stacked (one GEMM with N = 3C; the fused attention kernel reads the three column ranges in place)
+  a.wq = pt.reserve((size_t)3 * C * C * 2); a.wk = a.wq + (size_t)C * C * 2; a.wv = a.wk + (size_t)C * C * 2;
+  a.bq = pt.reserve((size_t)3 * C * 4); a.bk = a.bq + (size_t)C * 4; a.bv = a.bk + (size_t)C * 4;
+  pt.linear_at(p + "to_q.weight", C, C, a.wq, C); pt.f32_at(p + "to_q.bias", C, a.bq);
+  pt.linear_at(p + "to_k.weight", C, C, a.wk, C); pt.f32_at(p + "to_k.bias", C, a.bk);
+  pt.linear_at(p + "to_v.weight", C, C, a.wv, C); pt.f32_at(p + "to_v.bias", C, a.bv);
   a.wo = pt.linear(p + "to_out.0.weight", C, C); a.bo = pt.f32(p + "to_out.0.bias", C);
 }
 
-// single-head attention over H*W tokens with d = C (softmax in fp32)
+// single-head attention over H*W tokens with d = C: GroupNorm -> q|k|v (one GEMM) -> fused flash-style attention
+// (attention_wide.hip: nothing of size S x S is materialised) -> to_out + residual
 Tn attn_run(Exec& ex, const dmx_vae* v, const AttnW& w, const Tn& x, int G) {
-  const int C = w.C, S = x.H * x.W, M = x.rows();
+  const int C = w.C, S = x.H * x.W;
   Tn n = ex.groupnorm(x, nullptr, v->at<float>(w.gg), v->at<float>(w.gb), G, 1e-6f, false);
-  Tn q = ex.linear(n, v->at<bf16>(w.wq), C, v->at<float>(w.bq), nullptr, false);
-  Tn k = ex.linear(n, v->at<bf16>(w.wk), C, v->at<float>(w.bk), nullptr, false);
-  bf16* vt = (bf16*)ex.raw((size_t)C * M * 2);                     // V^T (bias added after P.V: rows of P sum to 1)
-  ex.gemm_raw(v->at<bf16>(w.wv), C, C, n.p, n.ld, M, C, nullptr, vt, M, 0);
+  Tn qkv = ex.linear(n, v->at<bf16>(w.wq), 3 * C, v->at<float>(w.bq), nullptr, false);
   ex.drop(n);
   Tn a = ex.make(x.B, x.H, x.W, C);
-  float* sc = (float*)ex.raw((size_t)S * S * 4);
-  bf16* pr = (bf16*)ex.raw((size_t)S * S * 2);
-  const float scale = 1.0f / sqrtf((float)C);
-  for (int b = 0; b < x.B; ++b) {
-    ex.gemm_raw(q.p + (size_t)b * S * C, C, S, k.p + (size_t)b * S * C, C, S, C, nullptr, sc, S, 1);
-    if (!ex.dry && !ex.rc) ex.rc = dmx_softmax_rows_launch(sc, S, pr, S, S, S, scale, ex.stream);
-    ex.gemm_raw(pr, S, S, vt + (size_t)b * S, M, C, S, v->at<float>(w.bv), a.p + (size_t)b * S * C, C, 0);
+  if (!ex.dry && !ex.rc) {
+    AttnWideArgs aa{};
+    aa.q = qkv.p; aa.k = qkv.p + C; aa.v = qkv.p + 2 * C; aa.ldq = aa.ldk = aa.ldv = 3 * C; aa.kv_rows = S;
+    aa.o = a.p; aa.ldo = C; aa.B = x.B; aa.Sq = S; aa.Skv = S; aa.D = C; aa.scale = 1.0f / sqrtf((float)C);
+    char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=1 Sq=%d Skv=%d d=%d", x.B, S, S, C);
+    ProfScope ps(PROF_ATTN, ex.stream, 4.0 * x.B * (double)S * S * C, 2.0 * C * x.B * (4.0 * S), tag);
+    ex.rc = dmx_attention_wide_launch(aa, ex.stream);
   }
-  ex.drop(sc); ex.drop(pr); ex.drop(q); ex.drop(k); ex.drop(vt);
+  ex.drop(qkv);
   Tn y = ex.linear(a, v->at<bf16>(w.wo), C, v->at<float>(w.bo), &x, false);
   ex.drop(a);
   return y;
@@ -155,6 +157,9 @@ extern "C" dmx_vae* dmx_vae_create(const dmx_vae_config* cfg) {
   if (!cfg) { dmx_set_error("vae_create: null config"); return nullptr; }
   for (int i = 0; i < 4; ++i)
     if (cfg->block_out_channels[i] % 64 != 0) { dmx_set_error("vae_create: block_out_channels must be multiples of 64"); return nullptr; }
+  if (!dmx_attention_wide_supported(cfg->block_out_channels[3])) {
+    dmx_set_error("vae_create: the mid-block attention width block_out_channels[3]=%d must be 128, 256 or 512", cfg->block_out_channels[3]); return nullptr;
+  }
   auto v = std::make_unique<dmx_vae>();
   v->cfg = *cfg;
   ParamTable& pt = v->pt;

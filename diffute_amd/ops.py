@@ -322,6 +322,14 @@ def attention_v(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
     return o
 
 
+def attention_wide(q, k, v, B, Sq, Skv, D, scale, kv_rows=None):
+    """single head of width D (128 / 256 / 512): q [B*Sq, >=D], k / v [B*kv_rows, >=D] row-major 2-D views -> [B*Sq, D]"""
+    o = torch.empty(B * Sq, D, dtype=torch.bfloat16, device=q.device)
+    check(lib().dmx_attention_wide(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), Skv if kv_rows is None else kv_rows,
+                                   ptr(o), D, B, Sq, Skv, D, float(scale), current_stream()), "attention_wide")
+    return o
+
+
 def attention_train(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
     """forward with row-major V that also returns lse [B,H,Sq] (log2 domain)"""
     o = torch.empty(B * Sq, H * 64, dtype=torch.bfloat16, device=q.device)

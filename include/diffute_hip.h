@@ -159,6 +159,12 @@ int dmx_attention_fwd(const void* q, int ldq, const void* k, int ldk, int kv_row
 
 /* Same attention with V given row-major (row b*kv_rows+s, head h at column 64h - e.g. a slice of a fused
  * q|k|v projection): the P.V operand is fetched with gfx950 LDS transpose reads, no V^T tensor is needed. */
+/* K6b: single-head attention with a wide head, d = 128 / 256 / 512 (AutoencoderKL mid block: diffusers `Attention` inside
+ * the VAE's UNetMidBlock2D, reached from vae.encode / vae.decode, app.ipynb:793,819; train_diffute_v1.py:875,886).
+ * q / k / v / o: bf16 row-major, row (b*Sq + s) resp. (b*kv_rows + s), d contiguous (column slices of one fused q|k|v buffer
+ * are fine: pass the row stride).  Fused flash-style: no S x S buffer, no workspace. */
+int dmx_attention_wide(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                       void* o, int ldo, int B, int Sq, int Skv, int D, float scale, dmx_stream_t stream);
 int dmx_attention_fwd_v(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
                         void* o, int ldo, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream);
 

@@ -339,3 +339,24 @@ def test_lin_kernel_geglu(cuda):
         mean = x.mean(1, keepdim=True); rstd = torch.rsqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
         gs = rstd * (F.linear(x, wp) - mean * c1) + c2; a3, gate3 = gs.chunk(2, dim=-1)
         assert_close(out2, bf(a3 * F.gelu(gate3)), TOL, f"lin geglu + folded LayerNorm vs the folded formula M={M} C={C}")
+
+
+WIDE_CASES = [("d512_S4096", 1, 512, 4096), ("d512_S1024_B2", 2, 512, 1024), ("d128_S64", 2, 128, 64), ("d128_S96_tail", 3, 128, 96),
+              ("d256_S200_tails", 1, 256, 200), ("d512_S70_tails", 1, 512, 70)]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_attention_wide(cuda, case):
+    """K6b: fused single-head attention, d = C (VAE mid block), against fp32 softmax(Q K^T / sqrt(d)) V on the same bf16 inputs;
+    q / k / v are column slices of one fused buffer as in the VAE graph; one key row is spiked so the deferred-max rescale
+    branch (in-place accumulator rescale) runs; S not a multiple of 32 / 128 exercises the key mask and the query clamp."""
+    from diffute_amd import ops
+    name, B, D, S = case
+    q = bf(seeded((B, S, D), 1)); k = bf(seeded((B, S, D), 2)); v = bf(seeded((B, S, D), 3))
+    k[0, min(37, S - 1)] *= 5.0
+    ref = torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v
+    ref = bf(ref.reshape(B * S, D))
+    qkv = torch.cat([q, k, v], dim=-1).reshape(B * S, 3 * D).to(cuda).to(torch.bfloat16)
+    out = ops.attention_wide(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, S, D, D ** -0.5)
+    assert_close(out, ref, 4e-3, name)
+    assert torch.equal(ops.attention_wide(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, S, D, D ** -0.5), out)
