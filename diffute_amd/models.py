@@ -378,11 +378,25 @@ class UNet2DConditionModel(_HipModel):
             tb["wt_sig"] = sig
         return tb
 
-    def set_gradient_sync(self, dist=None, group=None):
+    def set_gradient_sync(self, dist=None, group=None, mode="rs_ag"):
         """Average gradients over the ranks of `dist` (torch.distributed; RCCL on GPUs) INSIDE the backward: each of the
-        11 gradient buckets is all-reduced on a side stream as soon as the backward has finished it.
+        11 gradient buckets is exchanged on a side stream as soon as the backward has finished it - as an
+        in-place reduce-scatter + all-gather of the arena slices (mode "rs_ag") or one all-reduce per slice ("all_reduce").
         dist=None switches the exchange off (single GPU, or a wrapping torch DDP does it)."""
-        self._sync = None if dist is None else dict(dist=dist, group=group, world=dist.get_world_size(group), stream=None)
+        if mode not in ("rs_ag", "all_reduce"):
+            raise ValueError(f"set_gradient_sync: unknown mode {mode!r}")
+        self._sync = None if dist is None else dict(dist=dist, group=group, world=dist.get_world_size(group), stream=None, mode=mode,
+                                                    exposed=None)
+
+    def exposed_exchange_ms(self):
+        """how long the last backward's main stream sat waiting for the gradient exchange after its own kernels were done
+        (the NON-overlapped part of D1); None before the first synchronised backward"""
+        sync = getattr(self, "_sync", None)
+        if not sync or not sync.get("exposed"):
+            return None
+        a, b = sync["exposed"]
+        b.synchronize()
+        return a.elapsed_time(b)
 
     def _sync_plan(self, tb):
         if tb["plan"] is None:
@@ -450,8 +464,12 @@ class UNet2DConditionModel(_HipModel):
             side = sync["stream"]
             with torch.cuda.stream(side):
                 reduce_buckets(tb["grads"], self._sync_plan(tb), sync["dist"], group=sync["group"],
-                               wait_bucket=lambda i: side.wait_event(tb["events"][i]))
+                               wait_bucket=lambda i: side.wait_event(tb["events"][i]), mode=sync["mode"])
+            if sync["exposed"] is None:
+                sync["exposed"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            sync["exposed"][0].record(tb["fwd_stream"])                 # the backward's own kernels end here ...
             tb["fwd_stream"].wait_stream(side)
+            sync["exposed"][1].record(tb["fwd_stream"])                 # ... and here the exchange has caught up
         if fused is not None:                              # the fused optimizer reads the gradient arena directly
             with torch.cuda.stream(tb["fwd_stream"]):
                 fused.after_backward(tb["grads"])

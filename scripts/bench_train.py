@@ -3,7 +3,9 @@
     python scripts/bench_train.py [--batch 8] [--steps 3] [--warmup 1] [--no-vae]
     python -m torch.distributed.run --nproc-per-node N scripts/bench_train.py ...     (one rank per GPU, RCCL)
 
-Prints one JSON line: images/s over all ranks for forward + backward + gradient exchange + clip + AdamW."""
+Prints one JSON line: images/s over all ranks for forward + backward + gradient exchange + clip + AdamW, plus (N > 1) the
+EXPOSED gradient-exchange time per step: how long the backward's stream waited for the side-stream exchange after its own
+kernels had finished ("exposed (non-overlapped) all-reduce time")."""
 import argparse
 import json
 import os
@@ -25,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet / VAE (plumbing check)")
+    ap.add_argument("--exchange", choices=("rs_ag", "all_reduce"), default="rs_ag", help="gradient exchange schedule (SURVEY.md D1)")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW on exported gradients instead of the fused HIP optimizer")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -38,7 +41,7 @@ def main():
     sched = D.DDPMScheduler()
     if dist is not None:
         DD.broadcast_parameters(list(unet.parameters()), dist)                      # D3
-        unet.set_gradient_sync(dist)                                               # D1
+        unet.set_gradient_sync(dist, mode=a.exchange)                              # D1
     if a.torch_adamw:
         opt = torch.optim.AdamW(unet.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)   # train_diffute_v1.py:190-194
     else:
@@ -52,6 +55,7 @@ def main():
                  ocr_embeddings=torch.randn(B, 577, ctx_dim, device=dev, generator=g))
     stream = torch.cuda.Stream(device=dev)
     losses = []
+    exposed = []
     with torch.cuda.stream(stream):
         for _ in range(a.warmup):
             train_step(unet, vae, sched, opt, batch, generator=g)
@@ -60,6 +64,9 @@ def main():
         for _ in range(a.steps):
             out = train_step(unet, vae, sched, opt, batch, generator=g)
             losses.append(out["loss"])
+            e = unet.exposed_exchange_ms()                 # time the backward's stream waited for the exchange after its own kernels
+            if e is not None:
+                exposed.append(e)
         DD.barrier_sync(dist, dev)
         dt = time.perf_counter() - t0
     t, thr = DD.whole_job_throughput(dist, dt, B * a.steps, dev)
@@ -67,6 +74,8 @@ def main():
         print(json.dumps({"metric": "DDP training images/sec (forward + backward + exchange + AdamW)", "value": round(thr, 3), "unit": "images/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 2),
                           "optimizer": "torch.optim.AdamW" if a.torch_adamw else "FusedAdamW (HIP)", "per_gpu_batch": B, "px": px, "dtype": "bf16", "data": "synthetic", "loss_last": float(losses[-1]),
+                          "gradient_exchange": (a.exchange if dist is not None else None),
+                          "exposed_exchange_ms_per_step": (round(sum(exposed) / len(exposed), 3) if exposed else None),
                           "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}))
 
 

@@ -60,20 +60,20 @@ def test_bucket_planning():
     assert plan_buckets(params, [[(0, 1024)]], itemsize=4, gap=64) == [[(0, 50), (128, 150)]]
 
 
-def _train_sync_worker(rank, world, port, q):
+def _train_sync_worker(rank, world, port, q, mode="rs_ag"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from diffute_amd import dist as D
     dist = D.init_from_env("gloo")
     # a fake gradient arena: trainable ranges get rank-dependent values, the holes a sentinel that must survive
     n = 4096
     flat = torch.full((n,), -7.0)
-    params = [(0, 1000 * 4), (1500 * 4, 3000 * 4), (3500 * 4, 4096 * 4)]
+    params = [(0, 1000 * 4), (1500 * 4, 3000 * 4), (3501 * 4, 4096 * 4)]
     for b, e in params:
         flat[b // 4:e // 4] = torch.arange(b // 4, e // 4, dtype=torch.float32) * (rank + 1)
     buckets = [[(2048 * 4, 4096 * 4)], [(0, 2048 * 4)]]                 # completion order: back half first
     plan = D.plan_buckets(params, buckets, gap=0)
     order = []
-    D.reduce_buckets(flat, plan, dist, wait_bucket=order.append, average_by=world)
+    D.reduce_buckets(flat, plan, dist, wait_bucket=order.append, average_by=world, mode=mode)
     w = [torch.ones(3) * (rank + 5)]
     D.broadcast_parameters(w, dist, src=0)
     mean_loss = D.gather_scalar(float(rank + 1), dist, world)
@@ -82,20 +82,26 @@ def _train_sync_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bucketed_gradient_all_reduce_gloo_world2():
-    """D1/D2/D3 with gloo, world_size 2: bucket by bucket in completion order, only the trainable ranges are touched,
-    the result is the mean over ranks and identical on every rank; parameters broadcast from rank 0; scalar loss mean."""
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["rs_ag", "all_reduce"])
+def test_bucketed_gradient_exchange_gloo_world2(mode):
+    """D1/D2/D3 with gloo, world_size 2, for both exchange schedules (in-place reduce-scatter + all-gather per arena slice -
+    slices here have odd lengths, so the < world leftover path runs too - and one all-reduce per slice): bucket by bucket in
+    completion order, only the trainable ranges are touched, the result is the mean over ranks and identical on every rank;
+    parameters broadcast from rank 0; scalar loss mean."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_train_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_train_sync_worker, args=(r, world, port, q, mode)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
     [p.join(timeout=60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     idx = torch.arange(4096, dtype=torch.float32)
     want = torch.full((4096,), -7.0)
-    for b, e in [(0, 1000), (1500, 3000), (3500, 4096)]:
+    for b, e in [(0, 1000), (1500, 3000), (3501, 4096)]:
         want[b:e] = idx[b:e] * (1 + 2) / 2.0                             # mean of rank-scaled values
     for rank, flat, order, w, mean_loss in res:
         assert torch.equal(torch.from_numpy(flat), want), f"rank {rank}: reduced arena differs"
