@@ -113,6 +113,11 @@ _PROTOS = {
     "dmx_unet_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dmx_unet_set_context": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_size_t, _P, c_size_t, _P]),
     "dmx_unet_forward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_unet_forward_taps": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t,
+                                      _P, c_size_t, _P, _P, _P]),
+    "dmx_unet_workspace_bytes_f32": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
+    "dmx_unet_forward_f32": (c_int, [_P, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t,
+                                     _P, c_size_t, _P, _P, _P]),
     "dmx_unet_forward_graph": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "dmx_unet_train_workspace_bytes": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
     "dmx_unet_train_wt_bytes": (c_size_t, [_P]),

@@ -78,8 +78,16 @@ struct Tn {                 // NHWC bf16 activation [B*H*W][C] with row stride l
   int rows() const { return B * H * W; }
 };
 
+// Debug taps: block outputs of a forward pass copied out as NCHW fp32 (tests compare them with the oracle's per-block tensors)
+struct TapSink {
+  float* buf = nullptr; size_t cap = 0, used = 0;     // floats
+  int n = 0; int shape[16][4];                         // (B, C, H, W) of tap i, written back to back in `buf`
+};
+
 struct ConvOpts {
   int ksize = 3, stride = 1, pad = 1, ups = 0;
+  const float* bias2 = nullptr;   // fp32 validation mode only: a second bias vector (the raw conv_shortcut bias; the product path folds it)
+  int ldw = 0;                    // weight row stride when it is not K (fp32 validation mode: the K-padded conv_in matrix)
   int ups2 = 0;             // with ups: `w` holds the [4][Cout][4*Cin] phase weights (GemmArgs.ups2), not the 3x3 taps
   const float* bias = nullptr;
   const float* rowbias = nullptr; int ldrb = 0;
@@ -94,10 +102,18 @@ class Exec {
   bool dry = false;
   int rc = 0;
   Workspace ws;
+  // fp32 VALIDATION mode (ref_f32.hip): activations are floats (Tn::p points to float data), weights come from the fp32
+  // master arena (callers pass float pointers typed as bf16*), every op runs the plain fp32 kernel.  Tests only.
+  bool f32 = false;
+  TapSink* taps = nullptr;
+  size_t esz() const { return f32 ? 4 : 2; }
+  // column offset inside an activation row, in the active element type
+  bf16* col(const Tn& t, int c) const { return (bf16*)((char*)t.p + (size_t)c * esz()); }
+  void tap(const Tn& t);           // copy a block output to the tap sink (no-op without one)
 
   Tn make(int B, int H, int W, int C) {
     Tn t; t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
-    t.p = (bf16*)ws.alloc((size_t)B * H * W * C * 2);
+    t.p = (bf16*)ws.alloc((size_t)B * H * W * C * esz());
     if (ws.failed() && !rc) { dmx_set_error("workspace too small"); rc = DMX_ERR_WORKSPACE; }
     return t;
   }
@@ -142,5 +158,6 @@ struct ResW {
 // as extra K columns of conv2 and its bias is folded into conv2's by resnet_finalize.
 void resnet_build(ParamTable& pt, ResW& r, const std::string& p, int cin, int cout);
 int resnet_finalize(const ResW& r, char* arena, hipStream_t stream);
+// wmul: 1 = `arena` is the packed bf16 weights arena; 2 = fp32 validation mode, `arena` is the fp32 master arena (byte offsets double)
 Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn* x1, int groups, float eps,
-              const float* tproj, int tproj_total);
+              const float* tproj, int tproj_total, int wmul = 1);

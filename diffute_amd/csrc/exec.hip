@@ -133,6 +133,12 @@ void Exec::run_gemm(GemmArgs& a) {
 Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, bool silu) {
   const int C = x0.C + (x1 ? x1->C : 0);
   Tn y = make(x0.B, x0.H, x0.W, C);
+  if (f32) {
+    if (!dry && !rc)
+      rc = dmx_groupnorm_f32_launch((const float*)x0.p, x0.ld, x0.C, x1 ? (const float*)x1->p : nullptr, x1 ? x1->ld : 0, C, groups, x0.B, x0.H * x0.W,
+                                    gamma, beta, eps, silu ? 1 : 0, (float*)y.p, y.ld, stream);
+    return y;
+  }
   const size_t pb = dmx_gn_workspace_bytes(x0.B, x0.H * x0.W, groups);
   void* part = raw(pb);
   if (!dry && !rc) {
@@ -158,6 +164,28 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   if (o.stride == 2) { OH /= 2; OW /= 2; }
   Tn y; y.B = x0.B; y.H = OH; y.W = OW; y.C = Cout; y.ld = Cout;
   if (!o.out_f32) y = make(x0.B, OH, OW, Cout);
+  if (f32) {
+    GemmF32Args a{};
+    a.x0 = (const float*)x0.p; a.ldx0 = x0.ld; a.cx0 = x0.C;
+    a.x1 = x1 ? (const float*)x1->p : (const float*)x0.p; a.ldx1 = x1 ? x1->ld : x0.ld;
+    a.Cin = x0.C + (x1 ? x1->C : 0);
+    a.ksize = o.ksize; a.stride = o.stride; a.pad = o.pad; a.ups = o.ups;
+    a.direct = (o.ksize == 1 && o.stride == 1 && !o.ups) ? 1 : 0;
+    a.IH = x0.H; a.IW = x0.W; a.OH = OH; a.OW = OW;
+    a.Ktaps = o.ksize * o.ksize * a.Cin; a.K = a.Ktaps;
+    if (o.sc0) {
+      a.s0 = (const float*)o.sc0->p; a.lds0 = o.sc0->ld; a.cs0 = o.sc0->C;
+      a.s1 = o.sc1 ? (const float*)o.sc1->p : a.s0; a.lds1 = o.sc1 ? o.sc1->ld : o.sc0->ld;
+      a.K += o.sc0->C + (o.sc1 ? o.sc1->C : 0);
+    }
+    a.w = (const float*)w; a.ldw = o.ldw ? o.ldw : a.K;
+    a.M = x0.B * OH * OW; a.N = Cout;
+    a.bias = o.bias; a.bias2 = o.bias2; a.rowbias = o.rowbias; a.rows_per_group = OH * OW; a.ldrb = o.ldrb;
+    if (o.res) { a.res = (const float*)o.res->p; a.ldres = o.res->ld; }
+    a.out = o.out_f32 ? (float*)f32_out : (float*)y.p; a.ldo = Cout;
+    if (!dry && !rc) rc = dmx_gemm_f32_launch(a, stream);
+    return y;
+  }
   GemmArgs a{};
   a.x0 = x0.p; a.ldx0 = x0.ld; a.cx0 = x0.C;
   a.x1 = x1 ? x1->p : x0.p; a.ldx1 = x1 ? x1->ld : x0.ld;
@@ -190,6 +218,15 @@ Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* 
                 RowStats* rowstats, const LnIn* ln) {
   const int Nout = geglu ? N / 2 : N;
   Tn y = make(x.B, x.H, x.W, Nout);
+  if (f32) {                                           // (the folded-LayerNorm / row-statistics protocol is a bf16-path fusion: callers normalise explicitly)
+    GemmF32Args a{};
+    a.x0 = (const float*)x.p; a.x1 = a.x0; a.ldx0 = a.ldx1 = x.ld; a.cx0 = a.Cin = x.C; a.direct = 1; a.ksize = 1; a.stride = 1;
+    a.Ktaps = a.K = x.C; a.w = (const float*)w; a.ldw = x.C; a.M = x.rows(); a.N = N; a.bias = bias; a.rows_per_group = 1;
+    if (res) { a.res = (const float*)res->p; a.ldres = res->ld; }
+    a.out = (float*)y.p; a.ldo = Nout; a.geglu = geglu ? 1 : 0;
+    if (!dry && !rc) rc = dmx_gemm_f32_launch(a, stream);
+    return y;
+  }
   GemmArgs a{};
   a.x0 = x.p; a.x1 = x.p; a.ldx0 = x.ld; a.ldx1 = x.ld; a.cx0 = x.C; a.Cin = x.C;
   a.direct = 1; a.ksize = 1; a.stride = 1; a.IH = a.OH = x.H; a.IW = a.OW = x.W;
@@ -234,6 +271,10 @@ Tn Exec::linear_gelu(const Tn& x, const bf16* w, int N, const float* bias) {
 
 Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps) {
   Tn y = make(x.B, x.H, x.W, x.C);
+  if (f32) {
+    if (!dry && !rc) rc = dmx_layernorm_f32_launch((const float*)x.p, x.ld, (float*)y.p, y.ld, gamma, beta, x.rows(), x.C, eps, stream);
+    return y;
+  }
   if (!dry && !rc) {
     char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d", x.rows(), x.C);
     ProfScope ps(PROF_LNORM, stream, 0.0, 4.0 * (double)x.rows() * x.C, tag);
@@ -245,12 +286,28 @@ Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps
 void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                      bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale) {
   if (dry || rc) return;
+  if (f32) {
+    rc = dmx_attention_f32_launch((const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, kv_rows, (float*)o, ldo, B, H, Sq, Skv, scale, stream);
+    return;
+  }
   AttnArgs a{};
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.v = v; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
   char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
   ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv), tag);
   rc = dmx_attention_launch(a, stream);
+}
+
+void Exec::tap(const Tn& t) {
+  if (!taps || dry || rc) return;
+  const size_t n = (size_t)t.rows() * t.C;
+  if (taps->n >= 16) return;                           // (only reachable with the DMX_TAPS_FINE debugging switch)
+  if (taps->used + n > taps->cap) { dmx_set_error("tap buffer too small"); rc = DMX_ERR_WORKSPACE; return; }
+  float* dst = taps->buf + taps->used;
+  rc = f32 ? dmx_nhwc_to_nchw_f32_launch((const float*)t.p, t.ld, dst, t.B, t.C, t.H * t.W, stream)
+           : dmx_nhwc_bf16_to_nchw_f32_launch(t.p, t.ld, dst, t.B, t.C, t.H * t.W, stream);
+  int* sh = taps->shape[taps->n++]; sh[0] = t.B; sh[1] = t.C; sh[2] = t.H; sh[3] = t.W;
+  taps->used += n;
 }
 
 // --------------------------------------------------------------------------- ResnetBlock2D
@@ -286,9 +343,9 @@ int resnet_finalize(const ResW& r, char* arena, hipStream_t stream) {
 }
 
 Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn* x1, int groups, float eps,
-              const float* tproj, int tproj_total) {
-  auto F = [&](size_t off) { return (const float*)(arena + off); };
-  auto H = [&](size_t off) { return (const bf16*)(arena + off); };
+              const float* tproj, int tproj_total, int wmul) {
+  auto F = [&](size_t off) { return (const float*)(arena + off * (size_t)wmul); };
+  auto H = [&](size_t off) { return (const bf16*)(arena + off * (size_t)wmul); };
   Tn t1 = ex.groupnorm(x0, x1, F(r.n1g), F(r.n1b), groups, eps, true);
   ConvOpts o1; o1.bias = F(r.b1);
   if (r.temb_off >= 0 && tproj) { o1.rowbias = tproj + r.temb_off; o1.ldrb = tproj_total; }
@@ -297,6 +354,7 @@ Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn
   Tn t3 = ex.groupnorm(t2, nullptr, F(r.n2g), F(r.n2b), groups, eps, true);
   ex.drop(t2);
   ConvOpts o2; o2.bias = F(r.b2);
+  if (ex.f32 && r.shortcut) { o2.bias = F(r.b2raw); o2.bias2 = F(r.bscraw); }     // the folded bias is derived data: not in the master arena
   if (r.shortcut) { o2.sc0 = &x0; o2.sc1 = x1; } else { o2.res = &x0; }
   Tn y = ex.conv(t3, nullptr, H(r.w2), r.cout, o2);
   ex.drop(t3);

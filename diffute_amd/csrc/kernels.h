@@ -166,6 +166,25 @@ struct AttnBwdArgs {
 size_t dmx_attn_bwd_ws_bytes(int B, int H, int Sq);
 int dmx_attention_bwd_launch(const AttnBwdArgs& a, hipStream_t stream);
 
+// ------------------------------------------------------------------ ref_f32.hip (fp32 validation instantiation; tests only)
+struct GemmF32Args {             // same gather semantics as GemmArgs, float operands, 3x3 taps never phase-decomposed
+  const float* x0; const float* x1; int ldx0, ldx1, cx0, direct;
+  int IH, IW, OH, OW, stride, pad, ups, ksize, Cin, Ktaps;
+  const float* s0; const float* s1; int lds0, lds1, cs0;
+  const float* w; int ldw; int M, N, K;
+  const float* bias; const float* bias2; const float* rowbias; int rows_per_group, ldrb;
+  const float* res; int ldres;
+  float* out; int ldo; int geglu, act;
+};
+int dmx_gemm_f32_launch(const GemmF32Args& a, hipStream_t stream);
+int dmx_groupnorm_f32_launch(const float* x0, int ldx0, int c0, const float* x1, int ldx1, int C, int groups, int B, int HW,
+                             const float* gamma, const float* beta, float eps, int silu, float* y, int ldy, hipStream_t stream);
+int dmx_layernorm_f32_launch(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t stream);
+int dmx_attention_f32_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int kv_rows, float* o, int ldo,
+                             int B, int H, int Sq, int Skv, float scale, hipStream_t stream);
+int dmx_silu_f32_launch(float* x, size_t n, hipStream_t stream);
+int dmx_concat_nchw_to_nhwc_f32_launch(const float* f0, int c0, const float* f1, int c1, const float* f2, int c2, float* out, int B, int HW, hipStream_t stream);
+
 // ------------------------------------------------------------------ elementwise.hip
 struct Im2colArgs {
   // sources: up to 3 NCHW fp32 tensors concatenated on channels, or one NHWC bf16 tensor

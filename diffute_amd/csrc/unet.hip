@@ -250,13 +250,45 @@ namespace {
 
 struct Fwd {
   dmx_unet* u; Exec& ex; int B; const float* tproj; int tp_ld; const void* cache; int ctx_len;
+  const char* wbase; int wmul;      // weights: the packed bf16 arena (x1) or, in fp32 validation mode, the fp32 master arena (byte offsets x2)
+  template <typename T> const T* W(size_t off) const { return (const T*)(wbase + off * (size_t)wmul); }
 
   Tn resnet(const ResW& r, const Tn& x0, const Tn* x1) {
-    return resnet_run(ex, u->arena, r, x0, x1, u->cfg.norm_num_groups, 1e-5f, tproj, tp_ld);
+    return resnet_run(ex, wbase, r, x0, x1, u->cfg.norm_num_groups, 1e-5f, tproj, tp_ld, wmul);
+  }
+
+  // fp32 validation mode: the same block with explicit LayerNorms on the RAW weights (the folded copies are derived data of
+  // the bf16 path) and the context K / V projected in place (`cache` is the fp32 context [B*ctx_len][cross_attention_dim])
+  Tn xformer_f32(const XfW& w, const Tn& x) {
+    const int G = u->cfg.norm_num_groups, C = w.C, S = x.H * x.W, D = u->cfg.cross_attention_dim;
+    auto F = [&](size_t off) { return W<float>(off); };
+    auto H = [&](size_t off) { return W<bf16>(off); };
+    Tn t = ex.groupnorm(x, nullptr, F(w.ng), F(w.nb), G, 1e-6f, false);
+    Tn h = ex.linear(t, H(w.wpi), C, F(w.bpi), nullptr, false); ex.drop(t);
+    Tn n = ex.layernorm(h, F(w.l1g), F(w.l1b), 1e-5f);
+    Tn qkv = ex.linear(n, H(w.wqkv_raw), 3 * C, nullptr, nullptr, false); ex.drop(n);
+    Tn a = ex.make(x.B, x.H, x.W, C);
+    ex.attention(qkv.p, 3 * C, ex.col(qkv, C), 3 * C, ex.col(qkv, 2 * C), 3 * C, S, a.p, C, x.B, w.heads, S, S, 0.125f);
+    ex.drop(qkv);
+    Tn h2 = ex.linear(a, H(w.wo1), C, F(w.bo1), &h, false); ex.drop(a); ex.drop(h);
+    n = ex.layernorm(h2, F(w.l2g), F(w.l2b), 1e-5f);
+    Tn q = ex.linear(n, H(w.wq2_raw), C, nullptr, nullptr, false); ex.drop(n);
+    Tn cx; cx.p = (bf16*)cache; cx.B = x.B; cx.H = 1; cx.W = ctx_len; cx.C = D; cx.ld = D;
+    Tn kv = ex.linear(cx, H(w.wkv2), 2 * C, nullptr, nullptr, false);
+    a = ex.make(x.B, x.H, x.W, C);
+    ex.attention(q.p, C, kv.p, 2 * C, ex.col(kv, C), 2 * C, ctx_len, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
+    ex.drop(q); ex.drop(kv);
+    Tn h3 = ex.linear(a, H(w.wo2), C, F(w.bo2), &h2, false); ex.drop(a); ex.drop(h2);
+    n = ex.layernorm(h3, F(w.l3g), F(w.l3b), 1e-5f);
+    Tn g = ex.linear(n, H(w.wf1_raw), 8 * C, F(w.bf1), nullptr, true); ex.drop(n);
+    Tn h4 = ex.linear(g, H(w.wf2), C, F(w.bf2), &h3, false); ex.drop(g); ex.drop(h3);
+    Tn y = ex.linear(h4, H(w.wpo), C, F(w.bpo), &x, false); ex.drop(h4);
+    return y;
   }
 
   Tn xformer(const XfW& w, const Tn& x) {
-    const int G = u->cfg.norm_num_groups, C = w.C, S = x.H * x.W, M = x.rows();
+    if (ex.f32) return xformer_f32(w, x);
+    const int G = u->cfg.norm_num_groups, C = w.C, S = x.H * x.W;
     Tn t = ex.groupnorm(x, nullptr, u->at<float>(w.ng), u->at<float>(w.nb), G, 1e-6f, false);
     // LayerNorms are folded: each residual-stream producer also emits per-row (sum, sumsq) partials and the
     // consuming GEMM multiplies the raw rows by W*gamma and normalises in its epilogue - no LN kernels, no LN tensors.
@@ -307,39 +339,91 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
   float* e1 = (float*)ex.raw((size_t)B * temb * 4);
   float* emb = (float*)ex.raw((size_t)B * temb * 4);
   float* tproj = (float*)ex.raw((size_t)B * u->tproj_total * 4);
-  if (!ex.dry && !ex.rc) {
-    ex.rc = dmx_timestep_embedding_launch(timesteps, t_count, u->at<float>(u->freq), Bt, boc[0], sinus, ex.stream);
-    if (!ex.rc) ex.rc = dmx_linear_small_launch(sinus, boc[0], u->at<bf16>(u->te_w1), boc[0], u->at<float>(u->te_b1), e1, temb, Bt, temb, boc[0], 0, ex.stream);
-    if (!ex.rc) ex.rc = dmx_linear_small_launch(e1, temb, u->at<bf16>(u->te_w2), temb, u->at<float>(u->te_b2), emb, temb, Bt, temb, temb, 1, ex.stream);
-    if (!ex.rc) ex.rc = dmx_linear_small_launch(emb, temb, u->at<bf16>(u->tp_w), temb, u->at<float>(u->tp_b), tproj, u->tproj_total, Bt, u->tproj_total, temb, 1, ex.stream);
+  const char* wbase = ex.f32 ? (const char*)u->masters_f32 : u->arena;
+  const int wmul = ex.f32 ? 2 : 1;
+  Fwd f{u, ex, B, tproj, tp_ld, cache, ctx_len, wbase, wmul};
+  Tn h;
+  if (ex.f32) {
+    // fp32 validation mode: same layers on the fp32 masters through the generic fp32 GEMM (SiLU as its own tiny pass)
+    auto small = [&](float* x, int K, size_t w, size_t b, int N, float* y) {
+      Tn xi; xi.p = (bf16*)x; xi.B = Bt; xi.H = xi.W = 1; xi.C = K; xi.ld = K;
+      if (ex.dry || ex.rc) return;
+      GemmF32Args a{}; a.x0 = a.x1 = x; a.ldx0 = a.ldx1 = K; a.cx0 = a.Cin = K; a.direct = 1; a.ksize = 1; a.stride = 1; a.Ktaps = a.K = K;
+      a.w = f.W<float>(w); a.ldw = K; a.M = Bt; a.N = N; a.bias = f.W<float>(b); a.rows_per_group = 1; a.out = y; a.ldo = N;
+      ex.rc = dmx_gemm_f32_launch(a, ex.stream);
+    };
+    if (!ex.dry && !ex.rc) ex.rc = dmx_timestep_embedding_launch(timesteps, t_count, (const float*)(u->arena + u->freq), Bt, boc[0], sinus, ex.stream);
+    small(sinus, boc[0], u->te_w1, u->te_b1, temb, e1);
+    if (!ex.dry && !ex.rc) ex.rc = dmx_silu_f32_launch(e1, (size_t)Bt * temb, ex.stream);
+    small(e1, temb, u->te_w2, u->te_b2, temb, emb);
+    if (!ex.dry && !ex.rc) ex.rc = dmx_silu_f32_launch(emb, (size_t)Bt * temb, ex.stream);
+    // the 22 time_emb_proj biases are separate fp32 entries: in the master arena entry k sits at byte 2*dst_k, so (unlike the
+    // stacked bf16 weight rows) they are not one contiguous vector there - gather them into one
+    float* tpb = (float*)ex.raw((size_t)u->tproj_total * 4);
+    if (!ex.dry && !ex.rc) {
+      auto put = [&](const ResW& r) {
+        if (r.temb_off >= 0 && !ex.rc &&
+            hipMemcpyAsync(tpb + r.temb_off, f.W<float>(u->tp_b + (size_t)r.temb_off * 4), (size_t)r.cout * 4, hipMemcpyDeviceToDevice, ex.stream) != hipSuccess) {
+          dmx_set_error("unet_forward_f32: bias gather failed"); ex.rc = DMX_ERR_HIP;
+        }
+      };
+      for (int i = 0; i < 4; ++i) { for (auto& r : u->down_res[i]) put(r); for (auto& r : u->up_res[i]) put(r); }
+      put(u->mid_res[0]); put(u->mid_res[1]);
+    }
+    {
+      Tn xi; (void)xi;
+      if (!ex.dry && !ex.rc) {
+        GemmF32Args a{}; a.x0 = a.x1 = emb; a.ldx0 = a.ldx1 = temb; a.cx0 = a.Cin = temb; a.direct = 1; a.ksize = 1; a.stride = 1; a.Ktaps = a.K = temb;
+        a.w = f.W<float>(u->tp_w); a.ldw = temb; a.M = Bt; a.N = u->tproj_total; a.bias = tpb; a.rows_per_group = 1; a.out = tproj; a.ldo = u->tproj_total;
+        ex.rc = dmx_gemm_f32_launch(a, ex.stream);
+      }
+    }
+    ex.drop(tpb);
+    ex.drop(sinus); ex.drop(e1); ex.drop(emb);
+    Tn x9 = ex.make(B, H, W, cfg.in_channels);
+    if (!ex.dry && !ex.rc) ex.rc = dmx_concat_nchw_to_nhwc_f32_launch(f0, c0, f1, c1, f2, c2, (float*)x9.p, B, H * W, ex.stream);
+    ConvOpts oi; oi.bias = f.W<float>(u->ci_b); oi.ldw = u->ci_kpad;
+    h = ex.conv(x9, nullptr, f.W<bf16>(u->ci_w), boc[0], oi);
+    ex.drop(x9);
+  } else {
+    if (!ex.dry && !ex.rc) {
+      ex.rc = dmx_timestep_embedding_launch(timesteps, t_count, u->at<float>(u->freq), Bt, boc[0], sinus, ex.stream);
+      if (!ex.rc) ex.rc = dmx_linear_small_launch(sinus, boc[0], u->at<bf16>(u->te_w1), boc[0], u->at<float>(u->te_b1), e1, temb, Bt, temb, boc[0], 0, ex.stream);
+      if (!ex.rc) ex.rc = dmx_linear_small_launch(e1, temb, u->at<bf16>(u->te_w2), temb, u->at<float>(u->te_b2), emb, temb, Bt, temb, temb, 1, ex.stream);
+      if (!ex.rc) ex.rc = dmx_linear_small_launch(emb, temb, u->at<bf16>(u->tp_w), temb, u->at<float>(u->tp_b), tproj, u->tproj_total, Bt, u->tproj_total, temb, 1, ex.stream);
+    }
+    ex.drop(sinus); ex.drop(e1); ex.drop(emb);
+    // ---- conv_in: cat + layout + im2col, then GEMM
+    Tn col = ex.make(B, H, W, u->ci_kpad);
+    if (!ex.dry && !ex.rc) {
+      Im2colArgs a{}; a.f0 = f0; a.c0 = c0; a.f1 = f1; a.c1 = c1; a.f2 = f2; a.c2 = c2; a.C = cfg.in_channels;
+      a.B = B; a.IH = a.OH = H; a.IW = a.OW = W; a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = u->ci_kpad;
+      ex.rc = dmx_im2col_small_launch(a, ex.stream);
+    }
+    h = ex.linear(col, u->at<bf16>(u->ci_w), boc[0], u->at<float>(u->ci_b), nullptr, false);
+    ex.drop(col);
   }
-  ex.drop(sinus); ex.drop(e1); ex.drop(emb);
-  // ---- conv_in: cat + layout + im2col, then GEMM
-  Tn col = ex.make(B, H, W, u->ci_kpad);
-  if (!ex.dry && !ex.rc) {
-    Im2colArgs a{}; a.f0 = f0; a.c0 = c0; a.f1 = f1; a.c1 = c1; a.f2 = f2; a.c2 = c2; a.C = cfg.in_channels;
-    a.B = B; a.IH = a.OH = H; a.IW = a.OW = W; a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = u->ci_kpad;
-    ex.rc = dmx_im2col_small_launch(a, ex.stream);
-  }
-  Tn h = ex.linear(col, u->at<bf16>(u->ci_w), boc[0], u->at<float>(u->ci_b), nullptr, false);
-  ex.drop(col);
-  Fwd f{u, ex, B, tproj, tp_ld, cache, ctx_len};
+  ex.tap(h);                                           // "conv_in"
   std::vector<Tn> skips; skips.push_back(h);
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L; ++j) {
+      static const bool fine = getenv("DMX_TAPS_FINE") != nullptr;      // debugging aid: also tap every resnet / transformer output of the down path
       Tn y = f.resnet(u->down_res[i][j], h, nullptr);
-      if (cfg.down_has_attn[i]) { Tn z = f.xformer(u->down_xf[i][j], y); ex.drop(y); y = z; }
+      if (fine) ex.tap(y);
+      if (cfg.down_has_attn[i]) { Tn z = f.xformer(u->down_xf[i][j], y); ex.drop(y); y = z; if (fine) ex.tap(y); }
       h = y; skips.push_back(h);                      // previous h stays alive as a skip
     }
     if (i < 3) {
-      ConvOpts o; o.stride = 2; o.pad = 1; o.bias = u->at<float>(u->down_ds[i].b);
-      h = ex.conv(h, nullptr, u->at<bf16>(u->down_ds[i].w), boc[i], o);
+      ConvOpts o; o.stride = 2; o.pad = 1; o.bias = f.W<float>(u->down_ds[i].b);
+      h = ex.conv(h, nullptr, f.W<bf16>(u->down_ds[i].w), boc[i], o);
       skips.push_back(h);
     }
+    ex.tap(h);                                         // "down{i}"
   }
   { Tn y = f.resnet(u->mid_res[0], h, nullptr);          // h is also skips.back(): keep it
     Tn z = f.xformer(u->mid_xf, y); ex.drop(y);
     h = f.resnet(u->mid_res[1], z, nullptr); ex.drop(z); }
+  ex.tap(h);                                           // "mid"
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L + 1; ++j) {
       Tn s = skips.back(); skips.pop_back();
@@ -350,17 +434,19 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
     }
     if (i < 3) {
       // nearest x2 + conv3x3 as four 2x2 phase convolutions on the source grid (pre-summed taps): 4/9 of the multiply-adds
-      static const bool direct = getenv("DMX_UPS_DIRECT") != nullptr;      // measurement aid: gather over the virtual upsampled grid
-      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = u->at<float>(u->up_us[i].b);
-      Tn y = ex.conv(h, nullptr, u->at<bf16>(direct ? u->up_us[i].w : u->up_us[i].wp), boc[3 - i], o);
+      static const bool env_direct = getenv("DMX_UPS_DIRECT") != nullptr;  // measurement aid: gather over the virtual upsampled grid
+      const bool direct = env_direct || ex.f32;                            // (the phase weights are derived data of the bf16 path)
+      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = f.W<float>(u->up_us[i].b);
+      Tn y = ex.conv(h, nullptr, direct ? f.W<bf16>(u->up_us[i].w) : u->at<bf16>(u->up_us[i].wp), boc[3 - i], o);
       ex.drop(h); h = y;
     }
+    ex.tap(h);                                         // "up{i}"
   }
-  Tn t = ex.groupnorm(h, nullptr, u->at<float>(u->cno_g), u->at<float>(u->cno_b), cfg.norm_num_groups, 1e-5f, true);
+  Tn t = ex.groupnorm(h, nullptr, f.W<float>(u->cno_g), f.W<float>(u->cno_b), cfg.norm_num_groups, 1e-5f, true);
   ex.drop(h);
   float* eps_nhwc = (float*)ex.raw((size_t)B * H * W * cfg.out_channels * 4);
-  ConvOpts oo; oo.bias = u->at<float>(u->co_b); oo.out_f32 = 1;
-  ex.conv(t, nullptr, u->at<bf16>(u->co_w), cfg.out_channels, oo, eps_nhwc);
+  ConvOpts oo; oo.bias = f.W<float>(u->co_b); oo.out_f32 = 1;
+  ex.conv(t, nullptr, f.W<bf16>(u->co_w), cfg.out_channels, oo, eps_nhwc);
   ex.drop(t);
   if (!ex.dry && !ex.rc) ex.rc = dmx_nhwc_to_nchw_f32_launch(eps_nhwc, cfg.out_channels, out, B, cfg.out_channels, H * W, ex.stream);
   ex.drop(eps_nhwc); ex.drop(tproj);
@@ -393,6 +479,48 @@ extern "C" int dmx_unet_forward(dmx_unet* u, const float* f0, int c0, const floa
   DMX_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "unet_forward: H=%d W=%d must be positive multiples of 8", H, W);
   Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
   return unet_run(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
+}
+
+// dmx_unet_forward + debug taps: the block outputs conv_in, down0..3, mid, up0..3 (the oracle's tap points) are copied out as
+// NCHW fp32, back to back, into `taps`; shapes (B, C, H, W) land in tap_shapes[i*4..], the count in *n_taps.
+extern "C" int dmx_unet_forward_taps(dmx_unet* u, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                                     const int64_t* timesteps, int t_count, const void* cache, int ctx_len, float* out, int B, int H, int W,
+                                     void* workspace, size_t workspace_bytes, float* taps, size_t tap_floats, int* tap_shapes, int* n_taps, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->finalized, "unet_forward_taps: weights not finalized");
+  DMX_REQUIRE(f0 && out && timesteps && cache && workspace && taps && tap_shapes && n_taps, "unet_forward_taps: null argument");
+  DMX_REQUIRE(c0 + c1 + c2 == u->cfg.in_channels && B > 0 && H % 8 == 0 && W % 8 == 0, "unet_forward_taps: bad shapes");
+  TapSink sink; sink.buf = taps; sink.cap = tap_floats;
+  Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false); ex.taps = &sink;
+  const int rc = unet_run(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
+  *n_taps = sink.n;
+  for (int i = 0; i < sink.n; ++i) for (int k = 0; k < 4; ++k) tap_shapes[4 * i + k] = sink.shape[i][k];
+  return rc;
+}
+
+// fp32 VALIDATION forward (tests): the same graph walker on fp32 activations, the fp32 master copy of the parameters
+// (`masters`: dmx_unet_grad_bytes(u) bytes filled by dmx_unet_master_import for every parameter) and the plain fp32 kernels of
+// ref_f32.hip.  `context` is the raw glyph context [B][ctx_len][cross_attention_dim] fp32 (its K / V are projected in the call).
+// taps / tap_shapes / n_taps may be NULL.  Never used by the product path.
+extern "C" size_t dmx_unet_workspace_bytes_f32(dmx_unet* u, int B, int H, int W, int ctx_len) {
+  if (!u) return 0;
+  Exec ex; ex.dry = true; ex.f32 = true; ex.ws.reset(nullptr, 0, true);
+  unet_run(u, ex, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, B, nullptr, ctx_len, nullptr, B, H, W);
+  return ex.ws.peak() + 4096;
+}
+extern "C" int dmx_unet_forward_f32(dmx_unet* u, const void* masters, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                                    const int64_t* timesteps, int t_count, const float* context, int ctx_len, float* out, int B, int H, int W,
+                                    void* workspace, size_t workspace_bytes, float* taps, size_t tap_floats, int* tap_shapes, int* n_taps, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->finalized && masters, "unet_forward_f32: weights not finalized / no master arena");
+  DMX_REQUIRE(f0 && out && timesteps && context && workspace, "unet_forward_f32: null argument");
+  DMX_REQUIRE(c0 + c1 + c2 == u->cfg.in_channels && B > 0 && H % 8 == 0 && W % 8 == 0, "unet_forward_f32: bad shapes");
+  TapSink sink; sink.buf = taps; sink.cap = tap_floats;
+  Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false); ex.f32 = true;
+  if (taps) ex.taps = &sink;
+  u->masters_f32 = masters;
+  const int rc = unet_run(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, context, ctx_len, out, B, H, W);
+  u->masters_f32 = nullptr;
+  if (n_taps) { *n_taps = sink.n; for (int i = 0; i < sink.n; ++i) for (int k = 0; k < 4; ++k) tap_shapes[4 * i + k] = sink.shape[i][k]; }
+  return rc;
 }
 
 // Same contract as dmx_unet_forward, but the launch sequence (~600 kernels) is captured into a hipGraph the second

@@ -21,6 +21,7 @@ struct dmx_unet {
   dmx_unet_config cfg;
   ParamTable pt;
   char* arena = nullptr;
+  const void* masters_f32 = nullptr;   // fp32 validation forward only (dmx_unet_forward_f32): the caller's fp32 master arena for the duration of the call
   int temb_dim = 0, tproj_total = 0;
   size_t te_w1, te_b1, te_w2, te_b2, tp_w, tp_b, freq;
   size_t ci_w, ci_b; int ci_kpad = 0;

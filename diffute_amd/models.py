@@ -363,6 +363,74 @@ class UNet2DConditionModel(_HipModel):
                         _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_forward")
         return out
 
+    # ---- validation / debugging (tests only): per-block taps of the product path, and the fp32 instantiation of the graph
+    TAP_NAMES = ("conv_in", "down0", "down1", "down2", "down3", "mid", "up0", "up1", "up2", "up3")
+
+    def _tap_buffers(self, B, H, W):
+        boc = self.config.block_out_channels
+        n = B * H * W * boc[0] * 4 + 16 * B * H * W * max(boc)           # generous: every tap is <= B*H*W*max(C) floats
+        return (torch.empty(n, dtype=torch.float32, device=self.device), (ctypes.c_int * 64)(), ctypes.c_int(0))
+
+    @staticmethod
+    def _split_taps(buf, shapes, n):
+        out, off = OrderedDict(), 0
+        for i in range(n.value):
+            b, c, h, w = (int(shapes[4 * i + k]) for k in range(4))
+            out[UNet2DConditionModel.TAP_NAMES[i]] = buf[off:off + b * c * h * w].reshape(b, c, h, w).clone()
+            off += b * c * h * w
+        return out
+
+    @torch.no_grad()
+    def forward_taps(self, sample, timestep, encoder_hidden_states):
+        """the product (bf16) forward plus the block outputs conv_in, down0..3, mid, up0..3 as NCHW fp32 tensors"""
+        lib = _cabi.lib()
+        self._ensure_packed()
+        self.set_context(encoder_hidden_states)
+        sl = self._slot(0)
+        x = sample.to(torch.float32).contiguous()
+        B, _, H, W = x.shape
+        t = torch.as_tensor(timestep).reshape(-1).to(device=x.device, dtype=torch.int64)
+        out = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=x.device)
+        ws = self._slot_workspace(sl, lib.dmx_unet_workspace_bytes(self._h, B, H, W, sl["ctx_shape"][1]))
+        buf, shapes, n = self._tap_buffers(B, H, W)
+        _cabi.check(lib.dmx_unet_forward_taps(self._h, _cabi.ptr(x), x.shape[1], None, 0, None, 0, _cabi.ptr(t), t.numel(),
+                                              _cabi.ptr(sl["ctx_cache"]), sl["ctx_shape"][1], _cabi.ptr(out), B, H, W, _cabi.ptr(ws), ws.numel(),
+                                              _cabi.ptr(buf), buf.numel(), shapes, ctypes.byref(n), _cabi.current_stream()), "unet_forward_taps")
+        return out, self._split_taps(buf, shapes, n)
+
+    @torch.no_grad()
+    def forward_fp32(self, parts, timestep, encoder_hidden_states, taps=False):
+        """VALIDATION ONLY: the same graph on fp32 activations, fp32 master weights and plain fp32 kernels (ref_f32.hip) -
+        north_star's "within 1e-3 rel fp32" check against the fp32 reference path.  parts: one NCHW tensor or the list
+        [latents, mask, masked_latents]; returns eps (and the block taps when taps=True).  Slow; never on the product path."""
+        lib = _cabi.lib()
+        self._ensure_packed()
+        if torch.is_tensor(parts):
+            parts = [parts]
+        parts = [p.to(torch.float32).contiguous() for p in parts]
+        B, _, H, W = parts[0].shape
+        dev = parts[0].device
+        m = getattr(self, "_masters32", None)
+        if m is None or m[0] != self._packed_sig:
+            arena = torch.zeros(lib.dmx_unet_grad_bytes(self._h) // 4, dtype=torch.float32, device=dev)
+            st = _cabi.current_stream()
+            for k, p in zip(self._keys, self._param_list()):
+                src = p.detach().to(torch.float32).contiguous()
+                _cabi.check(lib.dmx_unet_master_import(self._h, _cabi.ptr(arena), k.encode(), _cabi.ptr(src), st), f"master_import({k})")
+            m = self._masters32 = (self._packed_sig, arena)
+        ctx = encoder_hidden_states.to(torch.float32).contiguous()
+        S = ctx.shape[1]
+        t = torch.as_tensor(timestep).reshape(-1).to(device=dev, dtype=torch.int64)
+        out = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.dmx_unet_workspace_bytes_f32(self._h, B, H, W, S), dtype=torch.uint8, device=dev)
+        ps = [(p, p.shape[1]) for p in parts] + [(None, 0)] * (3 - len(parts))
+        buf, shapes, n = self._tap_buffers(B, H, W) if taps else (None, None, None)
+        _cabi.check(lib.dmx_unet_forward_f32(self._h, _cabi.ptr(m[1]), _cabi.ptr(ps[0][0]), ps[0][1], _cabi.ptr(ps[1][0]), ps[1][1],
+                                             _cabi.ptr(ps[2][0]), ps[2][1], _cabi.ptr(t), t.numel(), _cabi.ptr(ctx), S, _cabi.ptr(out), B, H, W,
+                                             _cabi.ptr(ws), ws.numel(), _cabi.ptr(buf) if taps else None, buf.numel() if taps else 0,
+                                             shapes if taps else None, ctypes.byref(n) if taps else None, _cabi.current_stream()), "unet_forward_f32")
+        return (out, self._split_taps(buf, shapes, n)) if taps else out
+
     # ---- training (train_diffute_v1.py:913-925): forward that keeps activations + hand-written HIP backward
     def _train_buffers(self):
         """transposed-weights arena (data-gradient operands, refreshed when the weights change) and the fp32 gradient arena"""

@@ -277,6 +277,21 @@ int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, const float* f1
                            const int64_t* timesteps, int t_count, const void* context_cache, int ctx_len,
                            float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* Validation / debugging entry points (tests only; the product path never calls them).
+ *   dmx_unet_forward_taps   dmx_unet_forward that also copies out the block outputs conv_in, down0..3, mid, up0..3 (the points the
+ *                           oracle taps, oracle/unet.py) as NCHW fp32, back to back, into `taps`; tap_shapes[4*i..] = (B, C, H, W).
+ *   dmx_unet_forward_f32    the same graph walker on fp32 activations, the fp32 master copy of the parameters (`masters`:
+ *                           dmx_unet_grad_bytes(u) bytes filled by dmx_unet_master_import for every parameter) and plain fp32
+ *                           kernels: north_star's "within 1e-3 rel fp32" against the fp32 reference path (app.ipynb:560 runs
+ *                           inference in fp32).  `context` = raw glyph context [B][ctx_len][cross_attention_dim] fp32; taps optional. */
+int dmx_unet_forward_taps(dmx_unet* u, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                          const int64_t* timesteps, int t_count, const void* context_cache, int ctx_len, float* out, int B, int H, int W,
+                          void* workspace, size_t workspace_bytes, float* taps, size_t tap_floats, int* tap_shapes, int* n_taps, dmx_stream_t stream);
+size_t dmx_unet_workspace_bytes_f32(dmx_unet* u, int B, int H, int W, int ctx_len);
+int dmx_unet_forward_f32(dmx_unet* u, const void* masters, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                         const int64_t* timesteps, int t_count, const float* context, int ctx_len, float* out, int B, int H, int W,
+                         void* workspace, size_t workspace_bytes, float* taps, size_t tap_floats, int* tap_shapes, int* n_taps, dmx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Training of the denoiser: train_diffute_v1.py:913-925.
  *   dmx_unet_train_prepare   W^T copies of every GEMM weight (data-gradient operands) into `wt`; after each weight update

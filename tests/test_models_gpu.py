@@ -673,3 +673,72 @@ def test_edit_latents_end_to_end(cuda, tiny_unet, tiny_vae):
     init = OP.initial_latents((1, 4, 16, 16)).to(cuda)
     out2 = D.edit_latents(tiny_unet, tiny_vae, D.DDIMScheduler(), img, masked, mask, ctx, 3, enc_noise=en, init_latents=init)
     assert torch.equal(out, out2)
+
+
+# ------------------------------------------------------------------------------------------------ per-block taps and the fp32 validation path
+def _load_taps():
+    g = np.load(os.path.join(GOLD, "tiny_unet_taps.npz"))
+    f32 = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("fp32_")}
+    b16 = {k[8:]: (torch.from_numpy(g[k].astype(np.int32)) << 16).view(torch.float32) for k in g.files if k.startswith("bf16emu_")}
+    return f32, b16
+
+
+TAP_TOL = dict(conv_in=2e-3, down0=1e-2, down1=2e-2, down2=2e-2, down3=2e-2, mid=2e-2, up0=2e-2, up1=2e-2, up2=2e-2, up3=2e-2)
+
+
+def test_tiny_unet_block_taps(cuda, tiny_unet):
+    """every block output of the product (bf16) forward - conv_in, down0..3, mid, up0..3 - against the committed per-block
+    tensors of the bf16-emulating oracle (tests/golden/tiny_unet_taps.npz): a wrong-but-small term inside one block cannot hide
+    behind the end-to-end tolerance.  Bounds per block grow along the chain like the bf16 decorrelation does (TAP_TOL)."""
+    from diffute_amd.synthetic import synth_inputs
+    _, b16 = _load_taps()
+    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1)
+    y, taps = tiny_unet.forward_taps(x, torch.tensor(981), ctx)
+    assert list(taps) == list(tiny_unet.TAP_NAMES) and set(taps) == set(b16)
+    errs = {k: assert_close(taps[k], b16[k], TAP_TOL[k], f"block tap {k} vs bf16-emulating oracle") for k in taps}
+    print("block taps rel-L2:", " ".join(f"{k} {e:.1e}" for k, e in errs.items()))
+    with torch.no_grad():
+        assert torch.equal(y, tiny_unet(x, torch.tensor(981), ctx).sample)      # taps do not change the result
+
+
+def test_tiny_unet_fp32_validation_path(cuda, tiny_unet):
+    """north_star: "within 1e-3 rel fp32".  The fp32 instantiation of the SAME graph walker (fp32 activations, fp32 master
+    weights, plain fp32 kernels) against the fp32 oracle: eps and every block output <= 1e-3 (measured ~1e-6: only the
+    summation order differs), scalar and per-sample timesteps, fused 3-part input."""
+    from diffute_amd.synthetic import synth_inputs
+    g = np.load(os.path.join(GOLD, "tiny_unet.npz"))
+    f32, _ = _load_taps()
+    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, 128, device=cuda)
+    y, taps = tiny_unet.forward_fp32([lat, mask, mlat], torch.tensor(981), ctx, taps=True)
+    e = assert_close(y, torch.from_numpy(g["eps_fp32"]), 1e-3, "fp32 validation path: eps vs fp32 oracle")
+    errs = {k: assert_close(taps[k], f32[k], 1e-3, f"fp32 validation path: block {k}") for k in taps}
+    print(f"fp32 validation path rel-L2: eps {e:.1e}; blocks " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    # and the bf16 product path sits at its bf16 distance from the same fp32 truth, block by block
+    _, tb = tiny_unet.forward_taps(torch.cat([lat, mask, mlat], 1), torch.tensor(981), ctx)
+    for k in tb:
+        assert rel_l2(tb[k], taps[k]) < 2e-2, k
+
+
+def test_cfg1_fp32_validation_path(cuda):
+    """BASELINE config 1 (full SD2-inpaint UNet, B=1, 256 px, 10 DDIM steps) on the fp32 validation path: first-step eps and
+    the final latents within 1e-3 rel-L2 of the fp32 oracle's (tests/golden/cfg1_full.npz eps0_fp32 / final_fp32)."""
+    import diffute_amd as D
+    from diffute_amd.synthetic import synth_inputs
+    path = os.path.join(GOLD, "cfg1_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("cfg1_full.npz not generated")
+    g = np.load(path)
+    unet = D.UNet2DConditionModel(device=cuda).requires_grad_(False)
+    lat, mask, mlat, ctx = synth_inputs(1, 32, 32, 577, 1024, device=cuda)
+    sch = D.DDIMScheduler(); sch.set_timesteps(10)
+    x = lat * sch.init_noise_sigma
+    eps0 = None
+    for t in sch.timesteps:
+        eps = unet.forward_fp32([sch.scale_model_input(x, t), mask, mlat], t, ctx)
+        if eps0 is None:
+            eps0 = eps.clone()
+        x = sch.step(eps, t, x).prev_sample
+    e0 = assert_close(eps0, torch.from_numpy(g["eps0_fp32"]), 1e-3, "cfg1 fp32 path: first-step eps")
+    e1 = assert_close(x, torch.from_numpy(g["final_fp32"]), 1e-3, "cfg1 fp32 path: final latents after 10 DDIM steps")
+    print(f"cfg1 on the fp32 validation path: eps0 rel-L2 {e0:.2e}, final latents {e1:.2e}")
