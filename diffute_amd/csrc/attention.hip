@@ -113,6 +113,15 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   const int ntiles = (p.Skv + 63) / 64;
   load_tile(0);
   write_tile(0);
+  // The Q fragments come from plain global loads issued before the loop.  hipcc's waitcnt pass cannot prove them complete
+  // at the loop header (the back edge merges with the entry state), so it re-waits for them INSIDE the loop with
+  // vmcnt(3), (2), (1), (0) in front of the QK MFMAs - and since vmcnt retires in order, that also waits for the K/V tile
+  // prefetch issued at the top of the very same iteration: the prefetch was effectively synchronous (47 % of all wave cycles
+  // sat in s_waitcnt).  Passing the fragments through an empty asm makes them fresh values that carry no pending load.
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(qf[j][kk]));
   __syncthreads();
   for (int it = 0; it < ntiles; ++it) {
     const int kv0 = it * 64;

@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256, 1) void dmx_attn_wide_kernel(const AttnWideArg
   for (int j = 0; j < 4; ++j) vslot[j] = ((j ^ ((p16 >> 2) & 3)) << 6) + vcol;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the Q fragments must not look like pending loads inside the loop: hipcc would re-wait for them there (vmcnt retires in
+  // order, so that wait would also drain the K/V tile DMA issued at the top of each iteration) - see attention.hip
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(qf[kk]));
   __syncthreads();
   for (int it = 0; it < ntiles; ++it) {
     const int kv0 = it * 32;
