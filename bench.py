@@ -24,22 +24,28 @@ if ROOT not in sys.path:
 
 # profile classes of the library (diffute_amd/csrc/kernels.h ProfClass); classes 10.. = one per GEMM tile config, named
 # after the rocprofv3 kernel name of that template instance dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP>
+# hipEvent bracketing costs about this much per launch in the profiled pass (measured: sum of bracketed launch times minus the
+# un-profiled pass time, divided by the launch count; round 1: (387 - 365) ms / 16 k launches); subtracted when ranking kernels
+EVENT_OVERHEAD_US = 1.4
 GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2>"), ("gemm_128x64x32", "<2, 1, 32, 4, 2, 0, 2>"), ("gemm_256x128x64", "<4, 2, 64, 3, 2, 0, 2>"),
              ("gemm_128x64x64_deep", "<2, 1, 64, 6, 2, 0, 2>"), ("gemm_128x128x64_deep", "<2, 2, 64, 4, 2, 0, 2>"), ("gemm_256x256x32", "<4, 4, 32, 4, 2, 0, 2>"),
              ("gemm_256x128x64_ws", "<2, 2, 64, 3, 4, 4, 2>"), ("gemm_128x64x64_8w", "<4, 1, 64, 3, 1, 0, 2>"), ("gemm_128x128x32_8w", "<4, 2, 32, 4, 1, 0, 2>"),
              ("gemm_128x128x64_8w", "<4, 2, 64, 3, 1, 0, 2>"), ("gemm_128x160x64", "<4, 5, 64, 2, 1, 0, 1>"), ("gemm_128x320x64", "<4, 5, 64, 2, 1, 0, 2>")]
+LIN_CFGS = [("lin_128x160x64", "<1, 5, 64, 3, 2, false>"), ("lin_128x64x64", "<1, 2, 64, 4, 2, false>"), ("lin_128x256x32", "<2, 4, 32, 4, 1, false>")]
 KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % t for n, t in GEMM_CFGS}
-KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true>(AttnArgs)"
+KERNEL_NAMES.update({n: "void dmx_lin_kernel%s(GemmArgs, int, int, int)" % t for n, t in LIN_CFGS})
+KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true, 1, 4>(AttnArgs)"
 PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
-                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS]
+                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS] + [n for n, _ in LIN_CFGS]
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
 def pmc_traffic(kernel_name):
     """bytes per launch of `kernel_name` from the committed PMC summary (scripts/rocprof_to_profiles.py), or None"""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.csv")
-    if not os.path.exists(path):
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((os.path.join(here, f) for f in ("r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if os.path.exists(os.path.join(here, f))), None)
+    if path is None:
         return None
     for r in csv.DictReader(open(path)):
         if r["kernel"] == kernel_name:
@@ -155,16 +161,24 @@ def main():
                 classes[name] = {"launches": int(n), "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / n, 2),
                                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if fl > 0 and ms > 0 else None,
                                  "gbps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-        # dominant kernel = the MFMA kernel (a GEMM template instance or the attention kernel) with the most time in the pass
-        dom = max((k for k in classes if k.startswith("gemm") or k == "attention_d64"), key=lambda k: classes[k]["total_ms"])
+        # dominant kernel = the MFMA kernel (a GEMM template instance or the attention kernel) with the most time in the pass,
+        # ranked and rated on event-overhead-corrected times (each bracketed launch carries ~EVENT_OVERHEAD_US of hipEvent cost,
+        # which would otherwise penalise the classes with many short launches)
+        def corrected_ms(k):
+            return max(classes[k]["total_ms"] - classes[k]["launches"] * EVENT_OVERHEAD_US * 1e-3, 1e-6)
+        dom = max((k for k in classes if k.startswith("gemm") or k.startswith("lin_") or k == "attention_d64"), key=corrected_ms)
         n, ms, fl, by = buf[4 * PROF_CLASSES.index(dom):4 * PROF_CLASSES.index(dom) + 4]
+        ms = corrected_ms(dom)
         ach = fl / (ms * 1e-3) / 1e12
+        profiled_total = sum(c["total_ms"] for c in classes.values())
+        result["profile_overhead_ms"] = round(profiled_total - ms_per_step, 3)      # > 0: hipEvent bracketing of ~17 k launches (the classes sum to more than the timed pass)
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom]),
                               "kernel": KERNEL_NAMES[dom],
                               "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
-                              "note": "hipEvent-bracketed launches over one 50-step pass; traffic = HBM bytes per launch of this kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed in profiles/r01_pmc_traffic.csv (FETCH x2 per the gfx950 note), null if absent"}
+                              "whole_loop_frac": result["loop_mfma_frac"],
+                              "note": "hipEvent-bracketed launches over one 50-step pass, minus %.1f us of event overhead per launch; whole_loop_frac = algorithmic FLOPs of the whole 50-step loop / timed pass / peak; traffic = HBM bytes per launch of this kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ (FETCH x2 per the gfx950 note), null if absent" % EVENT_OVERHEAD_US}
         result["kernel_classes"] = classes
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -185,6 +199,7 @@ def main():
                                      torch.tensor([981], device=dev))
         rel = float((eps_gpu.cpu() - eps_cpu).norm() / eps_cpu.norm())
         result["cpu_baseline"] = {"value": round(1.0 / (T * t_fwd), 5), "unit": "images/s", "cores": nthreads, "kind": "port",
+                                  "host_cores_total": os.cpu_count(),
                                   "sample": f"1 UNet forward (B=1, {hw * 8} px, fp32 torch-CPU oracle, {nthreads} threads) = "
                                             f"{t_fwd:.2f} s, x{T} steps extrapolated linearly",
                                   "gpu_vs_cpu_eps_rel_l2": round(rel, 5)}
