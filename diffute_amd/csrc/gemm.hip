@@ -453,9 +453,17 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
       static_assert(WM % EP == 0, "160-column epilogue: whole waves per pass");
       float* tile = (float*)smem;
       const bool geglu = NWN == 2 && p.geglu != 0;
-      const int OCI = geglu ? BN / 16 : BN / 8;          // output octets per tile row
-      const int items = RPP * OCI;
       const float* bsrc = p.ln_stats ? p.ln_c2 : p.bias;
+      // the tile's column vectors (bias | c2, c1, time-embedding row bias) go to LDS once: fetched per item from global memory
+      // (three dependent L2 round trips inside the item loop) they made this epilogue 4-5 us per tile
+      float* colv = lnst + 2 * BM;                       // [3][BN]
+      const bool rb_one = p.rowbias && (m0 / p.rows_per_group == (min(m0 + BM, Mlim) - 1) / p.rows_per_group);   // whole tile inside one row-bias group
+      for (int c = t; c < BN; c += NT) {
+        const int n = min(n0 + c, p.N - 1);
+        colv[c] = bsrc ? bsrc[n] : 0.f;
+        colv[BN + c] = p.ln_stats ? p.ln_c1[n] : 0.f;
+        colv[2 * BN + c] = rb_one ? p.rowbias[(size_t)(m0 / p.rows_per_group) * p.ldrb + n] : 0.f;
+      }
 #pragma unroll
       for (int ep = 0; ep < EP; ++ep) {
         __builtin_amdgcn_s_barrier();
@@ -474,57 +482,86 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        for (int q = t; q < items; q += NT) {
-          const int r = q / OCI, o = q - r * OCI;
-          const int m = m0 + ep * RPP + r;
-          if (m >= Mlim) continue;
-          float mean = 0.f, rstd = 1.f;
-          if (p.ln_stats) { mean = lnst[2 * (ep * RPP + r)]; rstd = lnst[2 * (ep * RPP + r) + 1]; }
-          auto column = [&](int tc, int n, float* v) {   // tile column tc, global (packed) column n: acc -> affine
-            const f32x4 v0 = *(const f32x4*)(tile + r * LDT + tc), v1 = *(const f32x4*)(tile + r * LDT + tc + 4);
-            float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (bsrc) {
-              const f32x4 b0 = *(const f32x4*)(bsrc + n), b1 = *(const f32x4*)(bsrc + n + 4);
+        // Items (row, output octet) are processed U at a time: all LDS reads (and residual loads) of a group are issued before
+        // the first one is consumed - one item at a time the loop paid the LDS round trip (and a non-constant division) per item.
+        auto affine = [&](const f32x4& v0, const f32x4& v1, int tc, float mean, float rstd, float* v) {
+          const f32x4 b0 = *(const f32x4*)(colv + tc), b1 = *(const f32x4*)(colv + tc + 4);
+          if (p.ln_stats) {
+            const f32x4 c0 = *(const f32x4*)(colv + BN + tc), c1 = *(const f32x4*)(colv + BN + tc + 4);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
+            for (int e = 0; e < 4; ++e) { v[e] = rstd * (v0[e] - mean * c0[e]) + b0[e]; v[4 + e] = rstd * (v1[e] - mean * c1[e]) + b1[e]; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+          }
+        };
+        if (geglu) {
+          constexpr int OCG = BN / 16;                   // output octets per tile row (GEGLU halves the columns)
+          constexpr int NIT = (RPP * OCG + NT - 1) / NT;
+#pragma unroll
+          for (int k0 = 0; k0 < NIT; k0 += 3) {
+            f32x4 a0[3], a1[3], g0[3], g1[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int q = min(t + NT * (k0 + u), RPP * OCG - 1);
+              const int r = q / OCG, o = q - r * OCG, tc = 64 * (o >> 2) + (o & 3) * 8;
+              a0[u] = *(const f32x4*)(tile + r * LDT + tc); a1[u] = *(const f32x4*)(tile + r * LDT + tc + 4);
+              g0[u] = *(const f32x4*)(tile + r * LDT + tc + 32); g1[u] = *(const f32x4*)(tile + r * LDT + tc + 36);
             }
-            if (p.ln_stats) {
-              const f32x4 c0 = *(const f32x4*)(p.ln_c1 + n), c1 = *(const f32x4*)(p.ln_c1 + n + 4);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] = rstd * (v0[e] - mean * c0[e]) + bs[e]; v[4 + e] = rstd * (v1[e] - mean * c1[e]) + bs[4 + e]; }
-            } else {
+            for (int u = 0; u < 3; ++u) {
+              const int q = t + NT * (k0 + u);
+              if (k0 + u >= NIT || q >= RPP * OCG) continue;
+              const int r = q / OCG, o = q - r * OCG, Gg = o >> 2, jj = (o & 3) * 8;
+              const int m = m0 + ep * RPP + r, na = n0 + 64 * Gg + jj;
+              if (m >= Mlim || na >= p.N) continue;
+              float mean = 0.f, rstd = 1.f;
+              if (p.ln_stats) { mean = lnst[2 * (ep * RPP + r)]; rstd = lnst[2 * (ep * RPP + r) + 1]; }
+              float v[8], gt[8];
+              affine(a0[u], a1[u], 64 * Gg + jj, mean, rstd, v);
+              affine(g0[u], g1[u], 64 * Gg + 32 + jj, mean, rstd, gt);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bs[e]; v[4 + e] = v1[e] + bs[4 + e]; }
+              for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(gt[e]);
+              *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + (n0 >> 1) + 32 * Gg + jj) = pack_bf8(v);
             }
-          };
-          float v[8];
-          if (geglu) {
-            const int Gg = o >> 2, jj = (o & 3) * 8;     // packed 64-column group: 32 'a' columns then 32 gate columns
-            const int na = n0 + 64 * Gg + jj;
-            if (na >= p.N) continue;
-            float gt[8];
-            column(64 * Gg + jj, na, v);
-            column(64 * Gg + 32 + jj, na + 32, gt);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(gt[e]);
-            *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + (n0 >> 1) + 32 * Gg + jj) = pack_bf8(v);
-            continue;
           }
-          const int n = n0 + o * 8;
-          if (n >= p.N) continue;
-          column(o * 8, n, v);
-          if (p.rowbias) {
-            const float* rb = p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb + n;
-            const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
+        } else {
+          constexpr int OCP = BN / 8;
+          constexpr int NIT = RPP * OCP / NT;            // 5 for both instances (64 rows x 20 | 40 octets over 256 | 512 threads)
+          static_assert(RPP * OCP % NT == 0, "160-column epilogue: items divide over the block");
+          f32x4 x0[NIT], x1[NIT]; u32x4 rr[NIT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          for (int u = 0; u < NIT; ++u) {
+            const int q = t + NT * u, r = q / OCP, o = q - r * OCP;
+            x0[u] = *(const f32x4*)(tile + r * LDT + o * 8); x1[u] = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
+            if (p.res) {
+              int m = m0 + ep * RPP + r; if (m >= Mlim) m = Mlim - 1;
+              const int n = min(n0 + o * 8, p.N - 8);
+              rr[u] = *(const u32x4*)(p.res + (size_t)m * p.ldres + n);
+            }
           }
-          if (p.res) {
-            float rf[8]; unpack_bf8(*(const u32x4*)(p.res + (size_t)m * p.ldres + n), rf);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          for (int u = 0; u < NIT; ++u) {
+            const int q = t + NT * u, r = q / OCP, o = q - r * OCP;
+            const int m = m0 + ep * RPP + r, n = n0 + o * 8;
+            if (m >= Mlim || n >= p.N) continue;
+            float mean = 0.f, rstd = 1.f;
+            if (p.ln_stats) { mean = lnst[2 * (ep * RPP + r)]; rstd = lnst[2 * (ep * RPP + r) + 1]; }
+            float v[8];
+            affine(x0[u], x1[u], o * 8, mean, rstd, v);
+            if (p.rowbias) {
+              const float* rb = rb_one ? colv + 2 * BN + o * 8 : p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb + n;
+              const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            }
+            if (p.res) {
+              float rf[8]; unpack_bf8(rr[u], rf);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += rf[e];
+            }
+            *(u32x4*)((bf16*)p.out + out_row(m) * p.ldo + n) = pack_bf8(v);
           }
-          *(u32x4*)((bf16*)p.out + out_row(m) * p.ldo + n) = pack_bf8(v);
         }
       }
     }
@@ -935,9 +972,10 @@ static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
   if (TN == 5) lds_epi /= 2;                                           // the 160 / 320-column tiles stage half their rows per pass
   else if (lds_epi > 152 * 1024) lds_epi /= WM;                            // (only the experimental 256x256 tile)                            // staged one 64-row slab at a time
   if (lds_epi > lds) lds = lds_epi;
-  if (a.ln_stats) lds += (size_t)BM * 2 * sizeof(float);               // (mean, rstd) per row of the folded LayerNorm
+  if (a.ln_stats || TN == 5) lds += (size_t)BM * 2 * sizeof(float);    // (mean, rstd) per row of the folded LayerNorm
+  if (TN == 5) lds += (size_t)3 * BN * sizeof(float);                  // the tile's column vectors (160 / 320-column epilogue)
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float))); attr = true; }
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr = true; }
   hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN>), grid, dim3(64 * (NWN * WM + NP)), lds, stream, a);
 }
 
