@@ -7,7 +7,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diffute_amd as D  # noqa: E402
 from diffute_amd.flops import unet_flops  # noqa: E402
 from diffute_amd.synthetic import synth_inputs, text_crop_images  # noqa: E402

@@ -1,15 +1,25 @@
-# Regenerates profiles/r01_*: rocprofv3 kernel stats of one bench pass + separate PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy).
+# Regenerates profiles/r02_*: rocprofv3 kernel stats of one bench pass + separate PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy),
+# plus kernel-stat summaries of the secondary configurations (cfg3 VAE 32 x 512 px, cfg5 768 px loop, cfg4 per-GPU training step).
 # Run on the GPU box from the repo root: bash scripts/profile_round.sh ; outputs land in gpurun_out/ (copy the CSVs to profiles/).
+# Counter passes are separate runs with --pmc only (never combined with trace domains).
 R=$PWD
+P=${1:-r02}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write /tmp/rp_mfma
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o r01 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/rp_stats.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -o r01 -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -o r01 -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_write.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/rp_mfma -o r01 -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_mfma.log 2>&1
+rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write /tmp/rp_mfma /tmp/rp_extra /tmp/rp_train
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o $P -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/rp_stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/rp_mfma -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_mfma.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_extra -o $P -- python3 $R/scripts/bench_extra.py --skip-vit > $R/gpurun_out/${P}_cfg3_cfg5.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_train -o $P -- python3 $R/scripts/bench_train.py --steps 2 --warmup 1 > $R/gpurun_out/${P}_train.log 2>&1
 cd $R
-python3 scripts/rocprof_to_profiles.py /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write gpurun_out/r01 /tmp/rp_mfma
-head -8 gpurun_out/r01_kernel_stats.csv | cut -c1-160
-head -6 gpurun_out/r01_pmc_traffic.csv
-head -8 gpurun_out/r01_pmc_mfma.csv
+python3 scripts/rocprof_to_profiles.py /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write gpurun_out/$P /tmp/rp_mfma
+cp $(find /tmp/rp_extra -name "*kernel_stats.csv" | head -1) gpurun_out/${P}_cfg3_cfg5_kernel_stats.csv
+cp $(find /tmp/rp_train -name "*kernel_stats.csv" | head -1) gpurun_out/${P}_train_kernel_stats.csv
+tail -1 gpurun_out/rp_stats.log > gpurun_out/${P}_bench_line_profiled.json
+grep -h '^{' gpurun_out/${P}_cfg3_cfg5.log gpurun_out/${P}_train.log > gpurun_out/${P}_secondary_configs.jsonl
+head -8 gpurun_out/${P}_kernel_stats.csv | cut -c1-160
+head -6 gpurun_out/${P}_pmc_traffic.csv
+head -8 gpurun_out/${P}_pmc_mfma.csv
+cat gpurun_out/${P}_secondary_configs.jsonl
