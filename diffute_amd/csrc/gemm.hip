@@ -1040,14 +1040,19 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;
-  if (sk > 1) {
-    const size_t total4 = (size_t)a.M * a.N / 4;
-    const int blocks = (int)((total4 + 255) / 256);
-    ProfScope ps(PROF_SPLITK, stream, 0.0, 4.0 * sk * (double)a.M * a.N, tag);
-    hipLaunchKernelGGL(dmx_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
-    rc = dmx_check_launch("dmx_splitk_reduce_kernel");
-  }
+  if (sk > 1 && !a.defer_reduce) rc = dmx_splitk_reduce_launch(a, stream);
   return rc;
+}
+
+// the reduce pass of a split-K GEMM on its own (a: the arguments dmx_gemm_launch ran with, partial / splitk filled in)
+int dmx_splitk_reduce_launch(const GemmArgs& a, hipStream_t stream) {
+  const size_t total4 = (size_t)a.M * a.N / 4;
+  const int blocks = (int)((total4 + 255) / 256);
+  char tag[96];
+  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=%d st=%d ups=%d tn=0 sk=%d", a.M, a.N, a.K, a.direct ? 1 : a.ksize, a.stride, a.ups2 ? 2 : a.ups, a.splitk);
+  ProfScope ps(PROF_SPLITK, stream, 0.0, 4.0 * a.splitk * (double)a.M * a.N, tag);
+  hipLaunchKernelGGL(dmx_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return dmx_check_launch("dmx_splitk_reduce_kernel");
 }
 
 // ------------------------------------------------------------------------- folded-LayerNorm weight preparation
