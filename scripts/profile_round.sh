@@ -17,7 +17,7 @@ cd $R
 python3 scripts/rocprof_to_profiles.py /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write gpurun_out/$P /tmp/rp_mfma
 cp $(find /tmp/rp_extra -name "*kernel_stats.csv" | head -1) gpurun_out/${P}_cfg3_cfg5_kernel_stats.csv
 cp $(find /tmp/rp_train -name "*kernel_stats.csv" | head -1) gpurun_out/${P}_train_kernel_stats.csv
-tail -1 gpurun_out/rp_stats.log > gpurun_out/${P}_bench_line_profiled.json
+grep -h '^{"metric"' gpurun_out/rp_stats.log > gpurun_out/${P}_bench_line_profiled.json
 grep -h '^{' gpurun_out/${P}_cfg3_cfg5.log gpurun_out/${P}_train.log > gpurun_out/${P}_secondary_configs.jsonl
 head -8 gpurun_out/${P}_kernel_stats.csv | cut -c1-160
 head -6 gpurun_out/${P}_pmc_traffic.csv
