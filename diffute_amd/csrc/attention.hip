@@ -3,9 +3,16 @@
 //   O[b, q, h, :] = softmax(Q K^T * scale) V        (no mask; Skv = 577 tail handled)
 //
 // grid (ceil(Sq/128), H, B), 256 threads = 4 waves; each wave owns 32 query rows, the
-// block streams 64-key K / V^T tiles through LDS (register-staged, double buffered: the
-// next tile's global loads are issued before the current tile is multiplied and written
-// to LDS after it).  Scores are computed TRANSPOSED (S^T = K Q^T, K rows as the MFMA A
+// block streams 64-key K / V tiles through LDS, double buffered.  Row-major V (the UNet path): both tiles go L2 -> LDS by
+// LDS-DMA (global_load_lds, 16 B per lane, no staging registers and no address VALU in the loop: a wave-uniform tile
+// base plus two per-lane constant offsets), unpadded 128-byte rows made conflict-free by XOR swizzles applied on the DMA
+// SOURCE address (K: 16-byte chunk ^ (key & 7) for the ds_read_b128 fragment reads; V: 64-byte half ^ (key & 1) for
+// the transpose reads).  4 % faster than staging through registers (147.7 -> 141.4 us at S = 4096, B*H = 20) and 16
+// VGPRs / 11 KB of LDS lighter.  scripts/attn_pieces.py (probe build) prices the pieces of the loop: exp 19 %, QK MFMAs
+// 17 %, PV MFMAs 10 %, row sum 9 %, row max 5 %, and 34 % for the skeleton (24 LDS fragment reads = 16 KB per wave per
+// tile, the scale fma, bf16 packing) - the costs add up almost exactly, i.e. the three waves of a SIMD hide little of each
+// other: VALU issue, LDS reads and the matrix pipe are each 30-47 % busy and effectively serialised.
+// V^T input (cached cross-attention operands of other callers): register-staged tiles as before.  Scores are computed TRANSPOSED (S^T = K Q^T, K rows as the MFMA A
 // operand) so that every lane holds 32 scores of ONE query: the row max / row sum are
 // in-register plus one lane^32 exchange, and the bf16 P fragment that feeds P·V is
 // exactly 8 consecutive accumulator registers - no LDS round trip for P.  V arrives
@@ -36,17 +43,24 @@
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 // R = 32-row query sub-blocks per wave (1 or 2), NW = waves per block: a block covers 32*R*NW query rows and streams the K/V
 // tiles ONCE for all of them.  R = 2 halves the K/V traffic out of L2 per query row (the S = 4096 self-attention of the
 // 64x64 level is bound by exactly that: every 128-row block re-streams the head's whole K/V), halves the LDS fragment
 // reads per MFMA (a K / V fragment feeds both sub-blocks) and gives the scheduler two independent softmax / MFMA chains
 // to interleave inside one wave.
-template <bool VROWMAJOR, int R, int NW>
+// PROBE (builds with -DDMX_ATTN_PROBE only; results invalid): bit 0 no exp, 1 no row sum, 2 no row max, 3 no QK MFMAs,
+// 4 no PV MFMAs, 5 no K/V staging after tile 0, 6 no per-tile barrier - the marginal cost of each piece of the loop.
+template <bool VROWMAJOR, int R, int NW, int PROBE = 0>
 __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_attn_d64_kernel(const AttnArgs p) {
   constexpr int NT = 64 * NW, SL = 512 / NT;          // staging loads per thread per operand per tile (64 rows x 8 pieces)
-  __shared__ __attribute__((aligned(16))) char smem[2 * (KT_BYTES + VT_BYTES)];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr bool DMA = VROWMAJOR;
+  constexpr int KTB = DMA ? 64 * 128 : KT_BYTES, VTB = DMA ? 64 * 128 : VT_BYTES;     // DMA tiles: unpadded, swizzled
+  constexpr int NBUF = 2;                             // (a third slot with tiles requested two iterations ahead measured the same: 141.3 vs 141.4 us)
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * (KTB + VTB)];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (32 * R * NW) + wave * (32 * R);
@@ -101,6 +115,38 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
     }
   };
 
+  // ---- LDS-DMA staging (row-major V): instruction i of this wave fills rows 8*(wave + NW*i) .. +8 of a tile; lane =
+  // (row drow, physical 16-byte chunk dchk) of that 1-KB slab and fetches the source chunk the swizzle assigns to it
+  const int drow = lane >> 3, dchk = lane & 7;
+  const unsigned ldkb = (unsigned)p.ldk * 2u, ldvb = (unsigned)p.ldv * 2u;
+  const unsigned kcb = (unsigned)((dchk ^ drow) << 4);                                             // K: chunk ^ (row & 7)
+  const unsigned vcb = (unsigned)((((((dchk >> 2) ^ (drow & 1)) << 2) | (dchk & 3))) << 4);        // V: 64-byte half ^ (row & 1)
+  const unsigned koff = (unsigned)drow * ldkb + kcb, voff = (unsigned)drow * ldvb + vcb;
+  const char* kdma = (const char*)(p.k + (size_t)b * p.kv_rows * p.ldk + h * 64);
+  const char* vdma = DMA ? (const char*)(p.v + (size_t)b * p.kv_rows * p.ldv + h * 64) : nullptr;
+  auto stage = [&](int buf, int kv0) {
+    char* ksd = smem + buf * (KTB + VTB);
+    char* vsd = ksd + KTB;
+    if (kv0 + 64 <= p.Skv) {
+#pragma unroll
+      for (int i = 0; i < 8 / NW; ++i) {
+        const int r0 = 8 * (wave + NW * i);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kdma + (size_t)(kv0 + r0) * ldkb + koff), (lptr_t)(ksd + r0 * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vdma + (size_t)(kv0 + r0) * ldvb + voff), (lptr_t)(vsd + r0 * 128), 16, 0, 0);
+      }
+    } else {                                           // last, ragged tile: keys past Skv re-read the last valid row (their P is 0)
+      const int last = p.Skv - 1 - kv0;
+#pragma unroll
+      for (int i = 0; i < 8 / NW; ++i) {
+        const int r0 = 8 * (wave + NW * i);
+        const unsigned rc = (unsigned)min(r0 + drow, last);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kdma + (size_t)kv0 * ldkb + (rc * ldkb + kcb)), (lptr_t)(ksd + r0 * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vdma + (size_t)kv0 * ldvb + (rc * ldvb + vcb)), (lptr_t)(vsd + r0 * 128), 16, 0, 0);
+      }
+    }
+  };
+  const int ksw = (lh ^ (lr & 7)) << 4;               // K fragment: row lr (mod 8), chunk (2kk + lh) ^ (lr & 7) == (2kk << 4) ^ ksw
+
   f32x16 o[R][2];
   float m_run[R], l_run[R];
 #pragma unroll
@@ -111,8 +157,8 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   }
 
   const int ntiles = (p.Skv + 63) / 64;
-  load_tile(0);
-  write_tile(0);
+  if (DMA) { stage(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  else { load_tile(0); write_tile(0); }
   // The Q fragments come from plain global loads issued before the loop.  hipcc's waitcnt pass cannot prove them complete
   // at the loop header (the back edge merges with the entry state), so it re-waits for them INSIDE the loop with
   // vmcnt(3), (2), (1), (0) in front of the QK MFMAs - and since vmcnt retires in order, that also waits for the K/V tile
@@ -125,9 +171,9 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   __syncthreads();
   for (int it = 0; it < ntiles; ++it) {
     const int kv0 = it * 64;
-    if (it + 1 < ntiles) load_tile(kv0 + 64);
-    const char* ks = smem + (it & 1) * (KT_BYTES + VT_BYTES);
-    const char* vs = ks + KT_BYTES;
+    if (it + 1 < ntiles && !(PROBE & 32)) { if (DMA) stage((it + 1) & 1, kv0 + 64); else load_tile(kv0 + 64); }
+    const char* ks = smem + ((PROBE & 32) ? 0 : (it & 1)) * (KTB + VTB);
+    const char* vs = ks + KTB;
 
     // ---- S^T = K Q^T : s[j][kt][r] = score(query 32j + lr, key kv0 + 32kt + (r&3) + 8(r>>2) + 4lh); a K fragment feeds all sub-blocks
     f32x16 s[R][2];
@@ -137,14 +183,19 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) kf[kt][kk] = *(const bf16x8*)(ks + (32 * kt + lr) * (KROW * 2) + (2 * kk + lh) * 16);
+        for (int kt = 0; kt < 2; ++kt)
+          kf[kt][kk] = DMA ? *(const bf16x8*)(ks + (32 * kt + lr) * 128 + (((2 * kk) << 4) ^ ksw))
+                           : *(const bf16x8*)(ks + (32 * kt + lr) * (KROW * 2) + (2 * kk + lh) * 16);
       // kk outer, key-half inner: consecutive MFMAs go to DIFFERENT accumulators (a dependent 32x32x16 chain issues every 64 cycles, independent ones every 32)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int j = 0; j < R; ++j) s[j][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][kk], qf[j][kk], kk == 0 ? zero : s[j][kt], 0, 0, 0);
+          for (int j = 0; j < R; ++j) {
+            if (PROBE & 8) { if (kk == 0) { s[j][kt] = zero; s[j][kt][0] = __builtin_bit_cast(float, (int)kf[kt][0][0] + (int)kf[kt][1][1] + (int)kf[kt][2][2] + (int)kf[kt][3][3]) * 1e-30f; } }
+            else s[j][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][kk], qf[j][kk], kk == 0 ? zero : s[j][kt], 0, 0, 0);
+          }
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // all eight fragment reads first ...
       __builtin_amdgcn_sched_group_barrier(0x008, 8 * R, 0);         // ... then the MFMAs in the order written
     }
@@ -167,7 +218,8 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][kt][r]);
+        for (int r = 0; r < 16; ++r) if (!(PROBE & 4)) mx = fmaxf(mx, s[j][kt][r]);
+      if (PROBE & 4) mx = 0.f; else
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       if (!__all(mx <= m_run[j] + thr)) {                // wave-uniform: some query row needs a higher reference max
         const float m_new = fmaxf(m_run[j], mx);
@@ -186,9 +238,10 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
           unsigned int w[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kt][8 * u + 2 * e], sl2, mc));
-            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kt][8 * u + 2 * e + 1], sl2, mc));
-            psum += p0 + p1;
+            const float a0 = __builtin_fmaf(s[j][kt][8 * u + 2 * e], sl2, mc), a1 = __builtin_fmaf(s[j][kt][8 * u + 2 * e + 1], sl2, mc);
+            const float p0 = (PROBE & 1) ? a0 : __builtin_amdgcn_exp2f(a0);
+            const float p1 = (PROBE & 1) ? a1 : __builtin_amdgcn_exp2f(a1);
+            if (!(PROBE & 2)) psum += p0 + p1;
             w[e] = pack_bf2(p0, p1);
           }
           u32x4 wv = {w[0], w[1], w[2], w[3]};
@@ -201,17 +254,22 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
     if (VROWMAJOR) {
       // V tile is [key][d]; the MFMA A operand (rows d, k-slots = keys) comes from LDS transpose reads:
       // group g = lane>>4 covers d = 32dt + 16(g&1) + 0..15 and key-half lh = g>>1; two reads per operand.
+      // (all of a lane's rows have row & 1 == (p16 >> 2) & 1: the swizzled half of d-tile dt is a per-lane constant)
       const int p16 = lane & 15, g = lane >> 4;
-      const char* va = vs + (4 * (g >> 1) + (p16 >> 2)) * VRS + (16 * (g & 1) + 4 * (p16 & 3)) * 2;
+      const char* va = vs + (4 * (g >> 1) + (p16 >> 2)) * 128 + (16 * (g & 1) + 4 * (p16 & 3)) * 2;
+      const int vsw = (p16 >> 2) & 1;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(va + 64 * dt + (2 * s4) * 8 * VRS));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(va + 64 * dt + (2 * s4 + 1) * 8 * VRS));
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(va + 64 * (dt ^ vsw) + (2 * s4) * 8 * 128));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(va + 64 * (dt ^ vsw) + (2 * s4 + 1) * 8 * 128));
           const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-          for (int j = 0; j < R; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j][s4], o[j][dt], 0, 0, 0);
+          for (int j = 0; j < R; ++j) {
+            if (PROBE & 16) { o[j][dt][s4] += __builtin_bit_cast(float, (int)vv[0] + (int)vv[5]) * 1e-30f + __builtin_bit_cast(float, (int)pf[j][s4][0] + (int)pf[j][s4][7]) * 1e-30f; }
+            else o[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j][s4], o[j][dt], 0, 0, 0);
+          }
         }
     } else {
 #pragma unroll
@@ -227,8 +285,9 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
         }
     }
 
-    if (it + 1 < ntiles) write_tile((it + 1) & 1);
-    __syncthreads();
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile it+1 has landed (requested a whole iteration ago)
+    else if (it + 1 < ntiles && !(PROBE & 32)) write_tile((it + 1) & 1);
+    if (!(PROBE & 64)) __syncthreads();
   }
 
   // ---- normalise and store: lane holds query 32j + lr, d = 32dt + 8g + 4lh + e
@@ -274,7 +333,14 @@ int dmx_attention_launch(const AttnArgs& a, hipStream_t stream) {
     static const int r2 = getenv("DMX_ATTN_R2") ? 1 : 0;       // measurement aid: 4 waves x 64 rows instead of 8 waves x 32 rows
     if (rows == 256 && r2) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 2, 4>), grid, dim3(256), 0, stream, a);
     else if (rows == 256) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 8>), grid, dim3(512), 0, stream, a);
+#ifdef DMX_ATTN_PROBE
+#define PB(N) else if (pb == N) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4, N>), grid, dim3(256), 0, stream, a);
+    else if (const int pb = getenv("DMX_ATTN_PROBE_BITS") ? atoi(getenv("DMX_ATTN_PROBE_BITS")) : 0; pb == 0) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4>), grid, dim3(256), 0, stream, a);
+    PB(1) PB(2) PB(4) PB(8) PB(16) PB(32) PB(96) PB(3) PB(7) PB(24) PB(31) PB(127) PB(120)
+#undef PB
+#else
     else hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4>), grid, dim3(256), 0, stream, a);
+#endif
   } else {
     grid = dim3(cdiv(a.Sq, 128), a.H, a.B);
     DMX_REQUIRE(a.vt && a.ldvt % 8 == 0 && a.skv_stride % 8 == 0, "attention: V^T strides must be multiples of 8 (ldvt=%d skv_stride=%d)", a.ldvt, a.skv_stride);
