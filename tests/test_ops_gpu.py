@@ -341,6 +341,37 @@ def test_lin_kernel_geglu(cuda):
         assert_close(out2, bf(a3 * F.gelu(gate3)), TOL, f"lin geglu + folded LayerNorm vs the folded formula M={M} C={C}")
 
 
+@pytest.mark.parametrize("shape", ["rising", "falling", "huge", "ragged_rising"])
+def test_attention_reference_max_stress(cuda, shape):
+    """The d=64 kernel exponentiates each 64-key tile against the running reference max BEFORE looking at the tile's own max and
+    falls back (max, rescale, exponentiate again) only when a lane's exponentials overflow a bound.  Score profiles that
+    move the max by hundreds of exp2 units between tiles in either direction, with magnitudes that overflow fp32 exp2 when
+    unshifted, and with the ragged 577-key tail."""
+    from diffute_amd import ops
+    B, H, Sq = 1, 2, 128
+    Skv = 577 if shape == "ragged_rising" else 512
+    q = bf(seeded((B, Sq, H * 64), 11)); k = bf(seeded((B, Skv, H * 64), 12)); v = bf(seeded((B, Skv, H * 64), 13))
+    ramp = torch.linspace(0.2, 12.0, Skv).view(1, Skv, 1)
+    if shape in ("rising", "ragged_rising"):
+        k = bf(k * ramp)
+    elif shape == "falling":
+        k = bf(k * ramp.flip(1))
+    else:
+        k = bf(k * 40.0)                                             # |scores * scale * log2e| up to ~1e3
+    qh = q.view(B, Sq, H, 64).transpose(1, 2); kh = k.view(B, Skv, H, 64).transpose(1, 2); vh = v.view(B, Skv, H, 64).transpose(1, 2)
+    ref = torch.softmax((qh.double() @ kh.double().transpose(-1, -2)) * 0.125, -1) @ vh.double()
+    ref = bf(ref.float().transpose(1, 2).reshape(B * Sq, H * 64))
+    pad = (Skv + 63) // 64 * 64
+    kp = torch.zeros(B, pad, H * 64); kp[:, :Skv] = k
+    vp = torch.zeros(B, pad, H * 64); vp[:, :Skv] = v
+    kv = torch.cat([kp, vp], dim=-1).reshape(B * pad, 2 * H * 64).to(cuda).to(torch.bfloat16)
+    C = H * 64
+    out = ops.attention_v(q.reshape(B * Sq, -1).to(cuda).to(torch.bfloat16), kv[:, :C], kv[:, C:], B, H, Sq, Skv, 0.125, kv_rows=pad)
+    assert torch.isfinite(out.float()).all()
+    # near-one-hot softmax rows: the output is one (bf16) V row, the error is the bf16 rounding of P and O
+    assert_close(out, ref, 6e-3, f"attention, {shape} scores")
+
+
 WIDE_CASES = [("d512_S4096", 1, 512, 4096), ("d512_S1024_B2", 2, 512, 1024), ("d128_S64", 2, 128, 64), ("d128_S96_tail", 3, 128, 96),
               ("d256_S200_tails", 1, 256, 200), ("d512_S70_tails", 1, 512, 70)]
 
