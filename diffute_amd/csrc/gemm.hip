@@ -936,6 +936,10 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     if (c >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (c == 10 && a.geglu))) continue;   // what their epilogue covers
     if (!a.force_tn && c != 1 && c != 3 && a.N <= 64) continue;
     if (!a.force_tn && (c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
+    // 3x3 convolutions over <= 128 input channels (the 512^2 / 256^2 levels of the autoencoder, K = 1152): the weight operand is
+    // as large as the activation operand per tile, so the 256-row tile's reuse buys nothing and its longer prologue / epilogue
+    // shows - measured at batch 32 (scripts/vae_conv_probe.py): 128->128 3.54 vs 3.79 ms, 128->256 1.61 vs 1.76 ms
+    if (!a.force_tn && c == 2 && a.ksize == 3 && !a.direct && a.Cin <= 128 && a.Ktaps == a.K && !getenv("DMX_NO_THIN_RULE")) continue;
     const int nkt = a.K / T.bk;
     const int max_sk = (a.geglu || a.act || (a.N % 4) != 0 || a.rowstats_out || a.ln_stats) ? 1 : 16;   // those epilogues live in the GEMM kernel
     for (int sk = 1; sk <= max_sk; ++sk) {
