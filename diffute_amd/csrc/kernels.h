@@ -1,5 +1,6 @@
 // Internal (C++) launch interfaces shared by the C-ABI wrappers and the model executors.
 #pragma once
+#include <vector>
 #include "common.h"
 
 // ------------------------------------------------------------------ profiler (exec.hip)
@@ -220,6 +221,16 @@ int dmx_cast_pad_rows_launch(const void* in, int in_is_bf16, bf16* out, int B, i
 
 // ------------------------------------------------------------------ train_small.hip (training)
 int dmx_transpose_bf16_launch(const bf16* in, int ldin, bf16* out, int ldout, int R, int C, hipStream_t stream);
+// Batched transposes (the W^T pass after every optimizer step is ~600 small transposes: one launch instead of 600).
+// While a TrBatch is recording on this thread, dmx_transpose_bf16_launch only appends a job; run() uploads the job table to
+// `table_dev` when it differs from `cache` (the previous call's table: steady state uploads nothing) and launches once.
+struct TrJob { const unsigned short* in; unsigned short* out; int ldin, ldout, R, C, tiles_x, first; };
+struct TrBatch {
+  std::vector<TrJob> jobs; int tiles = 0;
+  TrBatch(); ~TrBatch();
+  int run(void* table_dev, size_t table_bytes, std::vector<TrJob>& cache, hipStream_t stream);
+};
+constexpr size_t DMX_TR_TABLE_BYTES = 2048 * sizeof(TrJob);
 int dmx_add_bf16_launch(const bf16* a, int lda, const bf16* b, int ldb, bf16* o, int ldo, int rows, int C, hipStream_t stream);
 size_t dmx_mse_workspace_bytes();
 int dmx_mse_loss_launch(const float* pred, const float* target, size_t n, float* loss, float* dpred, float grad_scale,

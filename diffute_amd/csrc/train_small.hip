@@ -3,6 +3,7 @@
 // fp32 time-embedding linears (M = batch).  Everything deterministic.
 #include "common.h"
 #include "kernels.h"
+#include <string.h>
 
 namespace {
 // out[c][r] = in[r][c], 32x32 tiles through LDS (both sides coalesced)
@@ -78,19 +79,20 @@ __global__ __launch_bounds__(256) void dmx_linear_small_bwd_w_kernel(const float
   }
 }
 // dx[b][k] = act'(x[b][k]) * sum_n dy[b][n] W[n][k].  N is the long axis here (time_emb_proj of all 22 resnets stacked:
-// N ~ 20k rows of K = 1280), so a block owns 32 columns k and up to 8 samples and splits N over 32 lanes of threads: W
-// is read once (64-byte row segments), the dy values are block-uniform, the 32 partial sums are folded in lane order.
+// N ~ 20k rows of K = 1280), so a block owns only 8 columns k (and up to 8 samples) and splits N over 128 lanes of
+// threads: 160 blocks at K = 1280 (32 columns per block left 40 blocks streaming the 52 MB of W: 717 us per call); W is
+// read once in 16-byte row segments, the dy values are block-uniform, the 128 partial sums are folded in lane order.
 __global__ __launch_bounds__(1024) void dmx_linear_small_bwd_x_kernel(const float* dy, int lddy, const bf16* w, int ldw, const float* x, int ldx,
                                                                       float* dx, int lddx, int B, int N, int K, int silu_in) {
-  __shared__ float red[32][8][33];
-  const int kk = threadIdx.x & 31, nl = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + kk, b0 = blockIdx.y * 8;
+  __shared__ float red[128][8][9];
+  const int kk = threadIdx.x & 7, nl = threadIdx.x >> 3;
+  const int k = blockIdx.x * 8 + kk, b0 = blockIdx.y * 8;
   const int nb = min(8, B - b0);
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   if (k < K)
-    for (int n = nl; n < N; n += 32) {
+    for (int n = nl; n < N; n += 128) {
       const float wv = (float)w[(size_t)n * ldw + k];
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (j < nb) acc[j] += dy[(size_t)(b0 + j) * lddy + n] * wv;
@@ -98,11 +100,11 @@ __global__ __launch_bounds__(1024) void dmx_linear_small_bwd_x_kernel(const floa
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[nl][j][kk] = acc[j];
   __syncthreads();
-  if (threadIdx.x < 256) {
-    const int j = threadIdx.x >> 5;
+  if (threadIdx.x < 64) {
+    const int j = threadIdx.x >> 3;
     if (j < nb && k < K) {
       float s = 0.f;
-      for (int l = 0; l < 32; ++l) s += red[l][j][kk];
+      for (int l = 0; l < 128; ++l) s += red[l][j][kk];
       if (silu_in) s *= dsilu1(x[(size_t)(b0 + j) * ldx + k]);
       dx[(size_t)(b0 + j) * lddx + k] = s;
     }
@@ -202,7 +204,51 @@ int dmx_softmax_bwd_rows_launch(const bf16* P, int ldp, const float* dP, int ldd
   return dmx_check_launch("dmx_softmax_bwd_rows_kernel");
 }
 
+// one block per 32x32 tile of one job; the job of a block is found by bisection over the jobs' first-tile indices
+__global__ __launch_bounds__(256) void dmx_transpose_batch_kernel(const TrJob* jobs, int njobs) {
+  __shared__ unsigned short tile[32][34];
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].first <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const TrJob j = jobs[lo];
+  const int tix = (int)blockIdx.x - j.first;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = (tix / j.tiles_x) * 32, c0 = (tix % j.tiles_x) * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = r0 + ty + 8 * q, c = c0 + tx;
+    tile[ty + 8 * q][tx] = (r < j.R && c < j.C) ? j.in[(size_t)r * j.ldin + c] : (unsigned short)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = c0 + ty + 8 * q, r = r0 + tx;
+    if (c < j.C && r < j.R) j.out[(size_t)c * j.ldout + r] = tile[tx][ty + 8 * q];
+  }
+}
+static thread_local TrBatch* g_tr_batch = nullptr;
+TrBatch::TrBatch() { g_tr_batch = this; }
+TrBatch::~TrBatch() { if (g_tr_batch == this) g_tr_batch = nullptr; }
+int TrBatch::run(void* table_dev, size_t table_bytes, std::vector<TrJob>& cache, hipStream_t stream) {
+  g_tr_batch = nullptr;
+  if (jobs.empty()) return DMX_OK;
+  DMX_REQUIRE(table_dev && jobs.size() * sizeof(TrJob) <= table_bytes, "transpose batch: %zu jobs do not fit the table", jobs.size());
+  if (cache.size() != jobs.size() || memcmp(cache.data(), jobs.data(), jobs.size() * sizeof(TrJob)) != 0) {
+    DMX_HIP(hipStreamSynchronize(stream));           // (a previous batch may still be reading the old table; pointers change ~never)
+    DMX_HIP(hipMemcpy(table_dev, jobs.data(), jobs.size() * sizeof(TrJob), hipMemcpyHostToDevice));
+    cache = jobs;
+  }
+  hipLaunchKernelGGL(dmx_transpose_batch_kernel, dim3(tiles), dim3(256), 0, stream, (const TrJob*)table_dev, (int)jobs.size());
+  return dmx_check_launch("dmx_transpose_batch_kernel");
+}
+
 int dmx_transpose_bf16_launch(const bf16* in, int ldin, bf16* out, int ldout, int R, int C, hipStream_t stream) {
+  if (g_tr_batch) {
+    TrJob j; j.in = (const unsigned short*)in; j.out = (unsigned short*)out; j.ldin = ldin; j.ldout = ldout; j.R = R; j.C = C;
+    j.tiles_x = cdiv(C, 32); j.first = g_tr_batch->tiles;
+    g_tr_batch->tiles += j.tiles_x * cdiv(R, 32);
+    g_tr_batch->jobs.push_back(j);
+    return DMX_OK;
+  }
   hipLaunchKernelGGL(dmx_transpose_bf16_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, stream,
                      (const unsigned short*)in, ldin, (unsigned short*)out, ldout, R, C);
   return dmx_check_launch("dmx_transpose_bf16_kernel");
@@ -235,7 +281,7 @@ int dmx_linear_small_bwd_launch(const float* x, int ldx, const float* dy, int ld
     if (rc) return rc;
   }
   if (dx) {
-    hipLaunchKernelGGL(dmx_linear_small_bwd_x_kernel, dim3(cdiv(K, 32), cdiv(B, 8)), dim3(1024), 0, stream, dy, lddy, w, ldw, x, ldx, dx, lddx, B, N, K, silu_in);
+    hipLaunchKernelGGL(dmx_linear_small_bwd_x_kernel, dim3(cdiv(K, 8), cdiv(B, 8)), dim3(1024), 0, stream, dy, lddy, w, ldw, x, ldx, dx, lddx, B, N, K, silu_in);
     return dmx_check_launch("dmx_linear_small_bwd_x_kernel");
   }
   return DMX_OK;

@@ -30,6 +30,7 @@ struct dmx_unet {
   ConvW down_ds[4], up_us[4];
   ResW mid_res[2]; XfW mid_xf;
   std::vector<XfW*> xf_all;          // cross-attention layers in graph order (context cache slots)
+  std::vector<TrJob> tr_cache;       // the transpose job table dmx_unet_train_prepare uploaded last (kernels.h TrBatch)
   bool finalized = false;
   std::shared_ptr<void> train_state;   // live training pass (unet_train.hip)
   // hipGraph cache: one captured UNet step per distinct argument tuple (pointers are baked into the nodes)

@@ -115,6 +115,7 @@ struct Train : TrainOps {
 };
 
 static size_t co_wt_off(const dmx_unet* u) { return align_up(u->pt.total(), 256); }
+static size_t tr_table_off(const dmx_unet* u) { return align_up(co_wt_off(u) + (size_t)u->cfg.block_out_channels[0] * 64 * 2, 256); }   // transpose job table
 
 struct TrainState {
   std::vector<ResSave> down_res[4], up_res[4]; std::vector<XfSave> down_xf[4], up_xf[4];
@@ -418,7 +419,7 @@ extern "C" size_t dmx_unet_train_workspace_bytes(dmx_unet* u, int B, int H, int 
 // W^T of every GEMM weight into `wt` (same offsets as the weights arena, + the padded conv_out filter behind it);
 // call after the weights change.
 extern "C" size_t dmx_unet_train_wt_bytes(const dmx_unet* u) {
-  return u ? co_wt_off(u) + (size_t)u->cfg.block_out_channels[0] * 64 * 2 : 0;
+  return u ? tr_table_off(u) + DMX_TR_TABLE_BYTES : 0;
 }
 extern "C" int dmx_unet_train_prepare(dmx_unet* u, void* wt_arena, size_t wt_bytes, dmx_stream_t stream) {
   DMX_REQUIRE(u && u->finalized, "unet_train_prepare: weights not finalized");
@@ -426,6 +427,7 @@ extern "C" int dmx_unet_train_prepare(dmx_unet* u, void* wt_arena, size_t wt_byt
   hipStream_t s = (hipStream_t)stream; char* wt = (char*)wt_arena;
   const int* boc = u->cfg.block_out_channels;
   int rc = 0;
+  TrBatch batch;                                       // the ~600 transposes below are recorded and run as one launch
   for (int i = 0; i < 4 && !rc; ++i) {
     for (auto& r : u->down_res[i]) if (!rc) rc = transpose_resnet(u, wt, r, s);
     for (auto& r : u->up_res[i]) if (!rc) rc = transpose_resnet(u, wt, r, s);
@@ -446,6 +448,7 @@ extern "C" int dmx_unet_train_prepare(dmx_unet* u, void* wt_arena, size_t wt_byt
       rc = dmx_transpose_bf16_launch((const bf16*)(u->arena + u->co_w) + (size_t)tap * boc[0], 9 * boc[0],
                                      (bf16*)(wt + co_wt_off(u)) + (size_t)(8 - tap) * OC, 64, OC, boc[0], s);
   }
+  if (!rc) rc = batch.run(wt + tr_table_off(u), DMX_TR_TABLE_BYTES, u->tr_cache, s);
   return rc;
 }
 
