@@ -47,6 +47,10 @@ __device__ __forceinline__ unsigned short f2bf_bits(float f) {
 __device__ __forceinline__ float bf_bits2f(unsigned short b) {
   return __uint_as_float(((unsigned int)b) << 16);
 }
+// value of the lane N positions below within the 16-lane DPP row (0 for the first N lanes of a row)
+template <int N> __device__ __forceinline__ float dpp_row_shr(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
 __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
   const bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(unsigned int, v);

@@ -726,9 +726,19 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
 #pragma unroll
               for (int e = 0; e < 8; ++e) { sa += f[e]; sq += f[e] * f[e]; }
             }
+            // the OC lanes of a row are adjacent; OC | 16: an inclusive scan with DPP row shifts (no LDS round trips: the
+            // bpermute butterfly was three dependent LDS exchanges per item); the row's last lane holds the total
+            constexpr bool DPP = OC <= 16 && (OC & (OC - 1)) == 0;
+            if constexpr (DPP) {
+              if (OC > 1) { sa += dpp_row_shr<1>(sa); sq += dpp_row_shr<1>(sq); }
+              if (OC > 2) { sa += dpp_row_shr<2>(sa); sq += dpp_row_shr<2>(sq); }
+              if (OC > 4) { sa += dpp_row_shr<4>(sa); sq += dpp_row_shr<4>(sq); }
+              if (OC > 8) { sa += dpp_row_shr<8>(sa); sq += dpp_row_shr<8>(sq); }
+            } else {
 #pragma unroll
-            for (int d = 1; d < OC; d <<= 1) { sa += __shfl_xor(sa, d); sq += __shfl_xor(sq, d); }
-            if (o == 0 && m < p.M) {
+              for (int d = 1; d < OC; d <<= 1) { sa += __shfl_xor(sa, d); sq += __shfl_xor(sq, d); }
+            }
+            if (o == (DPP ? OC - 1 : 0) && m < p.M) {
               float* q = p.rowstats_out + ((size_t)tile_n * p.M + m) * 2;
               q[0] = sa; q[1] = sq;
             }

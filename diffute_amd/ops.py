@@ -160,7 +160,7 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
         d.ln_stats = st.data_ptr(); d.ln_tiles = st.shape[0]; d.ln_c1 = c1.data_ptr(); d.ln_c2 = c2.data_ptr(); d.ln_C = K; d.ln_eps = eps
     stats = None
     if rowstats:
-        stats = torch.zeros(lib().dmx_conv_gemm_rowstats_tiles(ctypes.byref(d)), d.M, 2, dtype=torch.float32, device=x0.device)
+        stats = torch.empty(lib().dmx_conv_gemm_rowstats_tiles(ctypes.byref(d)), d.M, 2, dtype=torch.float32, device=x0.device)   # (every entry is written)
         d.rowstats_out = stats.data_ptr()
     wsb = lib().dmx_conv_gemm_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x0.device)
