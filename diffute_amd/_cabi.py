@@ -142,6 +142,10 @@ _PROTOS = {
     "dmx_unet_optim_elements": (c_size_t, [_P]),
     "dmx_unet_optim_table": (c_int, [_P, _P, c_size_t, _P]),
     "dmx_unet_master_import": (c_int, [_P, _P, c_char_p, _P, _P]),
+    "dmx_vae_master_import": (c_int, [_P, _P, c_char_p, _P, _P]),
+    "dmx_vae_workspace_bytes_f32": (c_size_t, [_P, c_int, c_int, c_int, c_int]),
+    "dmx_vae_encode_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "dmx_vae_decode_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "dmx_unet_adamw_step": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P, c_size_t, _P, c_float, _P]),
     "dmx_unet_refresh_derived": (c_int, [_P, _P]),
     "dmx_mask_rasterize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -191,7 +191,7 @@ int dmx_groupnorm_f32_launch(const float* x0, int ldx0, int c0, const float* x1,
                              const float* gamma, const float* beta, float eps, int silu, float* y, int ldy, hipStream_t stream);
 int dmx_layernorm_f32_launch(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t stream);
 int dmx_attention_f32_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int kv_rows, float* o, int ldo,
-                             int B, int H, int Sq, int Skv, float scale, hipStream_t stream);
+                             int B, int H, int Sq, int Skv, float scale, hipStream_t stream, int head_dim = 64);
 int dmx_silu_f32_launch(float* x, size_t n, hipStream_t stream);
 int dmx_concat_nchw_to_nhwc_f32_launch(const float* f0, int c0, const float* f1, int c1, const float* f2, int c2, float* out, int B, int HW, hipStream_t stream);
 

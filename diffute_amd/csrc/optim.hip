@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <vector>
 #include "unet_model.h"
+#include "vae_model.h"
 
 namespace {
 struct OptChunk { unsigned long long index; unsigned int count; unsigned int is_bf16; unsigned long long arena_off; };
@@ -138,10 +139,9 @@ extern "C" int dmx_unet_optim_table(const dmx_unet* u, void* table_dev, size_t b
 }
 
 // master[name] <- src (fp32, torch layout)
-extern "C" int dmx_unet_master_import(const dmx_unet* u, void* masters, const char* name, const float* src, dmx_stream_t stream) {
-  DMX_REQUIRE(u && masters && name && src, "unet_master_import: null argument");
-  const ParamEntry* e = u->pt.find(name);
-  DMX_REQUIRE(e != nullptr, "unet_master_import: unknown parameter %s", name);
+static int master_import(const ParamTable& pt, void* masters, const char* name, const float* src, hipStream_t stream, const char* who) {
+  const ParamEntry* e = pt.find(name);
+  DMX_REQUIRE(e != nullptr, "%s: unknown parameter %s", who, name);
   const PackRule& r = e->rule;
   float* g = (float*)((char*)masters + 2 * r.dst);
   int kind = 0, rows = r.rows, cols = r.cols;
@@ -154,8 +154,18 @@ extern "C" int dmx_unet_master_import(const dmx_unet* u, void* masters, const ch
   }
   const size_t total = (kind == 1) ? (size_t)rows * cols * r.ks * r.ks : (size_t)rows * (cols > 0 ? cols : 1);
   int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(dmx_master_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, g, kind, rows, cols, r.ks, r.ld, r.koff);
+  hipLaunchKernelGGL(dmx_master_pack_kernel, dim3(blocks), dim3(256), 0, stream, src, g, kind, rows, cols, r.ks, r.ld, r.koff);
   return dmx_check_launch("dmx_master_pack_kernel");
+}
+extern "C" int dmx_unet_master_import(const dmx_unet* u, void* masters, const char* name, const float* src, dmx_stream_t stream) {
+  DMX_REQUIRE(u && masters && name && src, "unet_master_import: null argument");
+  return master_import(u->pt, masters, name, src, (hipStream_t)stream, "unet_master_import");
+}
+// the autoencoder's fp32 master copy (same layout rule: weights-arena byte o <-> master byte 2*o); used by the fp32
+// validation path dmx_vae_encode_f32 / dmx_vae_decode_f32
+extern "C" int dmx_vae_master_import(const dmx_vae* v, void* masters, const char* name, const float* src, dmx_stream_t stream) {
+  DMX_REQUIRE(v && masters && name && src, "vae_master_import: null argument");
+  return master_import(v->pt, masters, name, src, (hipStream_t)stream, "vae_master_import");
 }
 
 // scalars: device float[2] = (gradient norm before clipping, clip coefficient); workspace: nchunks floats.

@@ -157,23 +157,25 @@ int dmx_layernorm_f32_launch(const float* x, int ldx, float* y, int ldy, const f
   return dmx_check_launch("dmx_layernorm_f32_kernel");
 }
 
-// ------------------------------------------------------------------ attention, head dim 64, fp32, exact two-pass softmax: block = 16 queries of one (b, h)
+// ------------------------------------------------------------------ attention, head dim D (64 in the UNet, 128 / 256 / 512 = the
+// single head of the autoencoder's mid block), fp32, exact two-pass softmax: block = 16 queries of one (b, h)
+template <int D>
 __global__ __launch_bounds__(256) void dmx_attention_f32_kernel(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int kv_rows,
                                                                 float* o, int ldo, int H, int Sq, int Skv, float scale) {
-  extern __shared__ float sm[];                       // [16][64] q | [16][Skv] scores
-  float* qs = sm; float* sc = sm + 16 * 64;
+  extern __shared__ float sm[];                       // [16][D] q | [16][Skv] scores
+  float* qs = sm; float* sc = sm + 16 * D;
   const int t = threadIdx.x, b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 16;
-  for (int e = t; e < 16 * 64; e += 256) {
-    const int r = e >> 6, d = e & 63; int qr = q0 + r; if (qr >= Sq) qr = Sq - 1;
-    qs[e] = q[((size_t)b * Sq + qr) * ldq + h * 64 + d];
+  for (int e = t; e < 16 * D; e += 256) {
+    const int r = e / D, d = e % D; int qr = q0 + r; if (qr >= Sq) qr = Sq - 1;
+    qs[e] = q[((size_t)b * Sq + qr) * ldq + h * D + d];
   }
   __syncthreads();
   const int qi = t >> 4, sub = t & 15;
   for (int kj = sub; kj < Skv; kj += 16) {
-    const float* kr = k + ((size_t)b * kv_rows + kj) * ldk + h * 64;
+    const float* kr = k + ((size_t)b * kv_rows + kj) * ldk + h * D;
     float s = 0.f;
 #pragma unroll 8
-    for (int d = 0; d < 64; ++d) s = fmaf(qs[qi * 64 + d], kr[d], s);
+    for (int d = 0; d < D; ++d) s = fmaf(qs[qi * D + d], kr[d], s);
     sc[qi * Skv + kj] = s * scale;
   }
   __syncthreads();
@@ -187,27 +189,42 @@ __global__ __launch_bounds__(256) void dmx_attention_f32_kernel(const float* q, 
   for (int d = 8; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
   __syncthreads();
   const float inv = 1.0f / sum;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int PT = D / 16;                          // output channels per thread
+  float acc[PT];
+#pragma unroll
+  for (int e = 0; e < PT; ++e) acc[e] = 0.f;
   for (int kj = 0; kj < Skv; ++kj) {
     const float pr = sc[qi * Skv + kj];
-    const float* vr = v + ((size_t)b * kv_rows + kj) * ldv + h * 64 + sub * 4;
+    const float* vr = v + ((size_t)b * kv_rows + kj) * ldv + h * D + sub * PT;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = fmaf(pr, vr[e], acc[e]);
+    for (int e = 0; e < PT; ++e) acc[e] = fmaf(pr, vr[e], acc[e]);
   }
   if (q0 + qi < Sq) {
-    float* orow = o + ((size_t)b * Sq + q0 + qi) * ldo + h * 64 + sub * 4;
+    float* orow = o + ((size_t)b * Sq + q0 + qi) * ldo + h * D + sub * PT;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) orow[e] = acc[e] * inv;
+    for (int e = 0; e < PT; ++e) orow[e] = acc[e] * inv;
   }
 }
-int dmx_attention_f32_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int kv_rows, float* o, int ldo,
-                             int B, int H, int Sq, int Skv, float scale, hipStream_t stream) {
-  const size_t lds = (size_t)(16 * 64 + 16 * Skv) * sizeof(float);
+template <int D>
+static int attention_f32_launch_d(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int kv_rows, float* o, int ldo,
+                                  int B, int H, int Sq, int Skv, float scale, hipStream_t stream) {
+  const size_t lds = (size_t)(16 * D + 16 * Skv) * sizeof(float);
   DMX_REQUIRE(lds <= 150 * 1024, "attention_f32: Skv=%d too long for the validation kernel (scores of 16 queries live in LDS)", Skv);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attention_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-  hipLaunchKernelGGL(dmx_attention_f32_kernel, dim3(cdiv(Sq, 16), H, B), dim3(256), lds, stream, q, ldq, k, ldk, v, ldv, kv_rows, o, ldo, H, Sq, Skv, scale);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attention_f32_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+  hipLaunchKernelGGL((dmx_attention_f32_kernel<D>), dim3(cdiv(Sq, 16), H, B), dim3(256), lds, stream, q, ldq, k, ldk, v, ldv, kv_rows, o, ldo, H, Sq, Skv, scale);
   return dmx_check_launch("dmx_attention_f32_kernel");
+}
+int dmx_attention_f32_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int kv_rows, float* o, int ldo,
+                             int B, int H, int Sq, int Skv, float scale, hipStream_t stream, int head_dim) {
+  switch (head_dim) {
+    case 64: return attention_f32_launch_d<64>(q, ldq, k, ldk, v, ldv, kv_rows, o, ldo, B, H, Sq, Skv, scale, stream);
+    case 128: return attention_f32_launch_d<128>(q, ldq, k, ldk, v, ldv, kv_rows, o, ldo, B, H, Sq, Skv, scale, stream);
+    case 256: return attention_f32_launch_d<256>(q, ldq, k, ldk, v, ldv, kv_rows, o, ldo, B, H, Sq, Skv, scale, stream);
+    case 512: return attention_f32_launch_d<512>(q, ldq, k, ldk, v, ldv, kv_rows, o, ldo, B, H, Sq, Skv, scale, stream);
+  }
+  dmx_set_error("attention_f32: head dim %d not built (64, 128, 256, 512)", head_dim);
+  return DMX_ERR_ARG;
 }
 
 // ------------------------------------------------------------------ small elementwise helpers

@@ -40,11 +40,30 @@ void attn_build(ParamTable& pt, AttnW& a, const std::string& p, int C) {
 // (attention_wide.hip: nothing of size S x S is materialised) -> to_out + residual
 Tn attn_run(Exec& ex, const dmx_vae* v, const AttnW& w, const Tn& x, int G) {
   const int C = w.C, S = x.H * x.W;
-  Tn n = ex.groupnorm(x, nullptr, v->at<float>(w.gg), v->at<float>(w.gb), G, 1e-6f, false);
-  Tn qkv = ex.linear(n, v->at<bf16>(w.wq), 3 * C, v->at<float>(w.bq), nullptr, false);
+  Tn n = ex.groupnorm(x, nullptr, v->W<float>(w.gg), v->W<float>(w.gb), G, 1e-6f, false);
+  const float* bqkv = v->W<float>(w.bq);
+  float* btmp = nullptr;
+  if (ex.f32) {                                        // the three bias vectors are not adjacent in the fp32 master arena
+    btmp = (float*)ex.raw((size_t)3 * C * 4);
+    if (!ex.dry && !ex.rc) {
+      const size_t offs[3] = {w.bq, w.bk, w.bv};
+      for (int i = 0; i < 3 && !ex.rc; ++i)
+        if (hipMemcpyAsync(btmp + (size_t)i * C, v->W<float>(offs[i]), (size_t)C * 4, hipMemcpyDeviceToDevice, ex.stream) != hipSuccess) {
+          dmx_set_error("hipMemcpyAsync failed (attention biases)"); ex.rc = DMX_ERR_HIP;
+        }
+    }
+    bqkv = btmp;
+  }
+  Tn qkv = ex.linear(n, v->W<bf16>(w.wq), 3 * C, bqkv, nullptr, false);
   ex.drop(n);
+  if (btmp) ex.drop(btmp);
   Tn a = ex.make(x.B, x.H, x.W, C);
-  if (!ex.dry && !ex.rc) {
+  if (ex.f32) {
+    if (!ex.dry && !ex.rc) {
+      const float* qp = (const float*)qkv.p;
+      ex.rc = dmx_attention_f32_launch(qp, 3 * C, qp + C, 3 * C, qp + 2 * C, 3 * C, S, (float*)a.p, C, x.B, 1, S, S, 1.0f / sqrtf((float)C), ex.stream, C);
+    }
+  } else if (!ex.dry && !ex.rc) {
     AttnWideArgs aa{};
     aa.q = qkv.p; aa.k = qkv.p + C; aa.v = qkv.p + 2 * C; aa.ldq = aa.ldk = aa.ldv = 3 * C; aa.kv_rows = S;
     aa.o = a.p; aa.ldo = C; aa.B = x.B; aa.Sq = S; aa.Skv = S; aa.D = C; aa.scale = 1.0f / sqrtf((float)C);
@@ -53,40 +72,56 @@ Tn attn_run(Exec& ex, const dmx_vae* v, const AttnW& w, const Tn& x, int G) {
     ex.rc = dmx_attention_wide_launch(aa, ex.stream);
   }
   ex.drop(qkv);
-  Tn y = ex.linear(a, v->at<bf16>(w.wo), C, v->at<float>(w.bo), &x, false);
+  Tn y = ex.linear(a, v->W<bf16>(w.wo), C, v->W<float>(w.bo), &x, false);
   ex.drop(a);
   return y;
 }
 
 int vae_encode_run(dmx_vae* v, Exec& ex, const float* x, float* moments, int B, int H, int W) {
   const dmx_vae_config& c = v->cfg; const int G = c.norm_num_groups; const int L = c.layers_per_block;
-  Tn col = ex.make(B, H, W, v->e_in.kpad);
-  if (!ex.dry && !ex.rc) {
-    Im2colArgs a{}; a.f0 = x; a.c0 = c.in_channels; a.C = c.in_channels; a.B = B; a.IH = a.OH = H; a.IW = a.OW = W;
-    a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = v->e_in.kpad;
-    ex.rc = dmx_im2col_small_launch(a, ex.stream);
+  Tn h;
+  if (ex.f32) {                                        // NCHW -> NHWC, then the generic conv on the K-padded filter matrix
+    Tn xn = ex.make(B, H, W, c.in_channels);
+    if (!ex.dry && !ex.rc) ex.rc = dmx_concat_nchw_to_nhwc_f32_launch(x, c.in_channels, nullptr, 0, nullptr, 0, (float*)xn.p, B, H * W, ex.stream);
+    ConvOpts oi; oi.bias = v->W<float>(v->e_in.b); oi.ldw = v->e_in.kpad;
+    h = ex.conv(xn, nullptr, v->W<bf16>(v->e_in.w), c.block_out_channels[0], oi);
+    ex.drop(xn);
+  } else {
+    Tn col = ex.make(B, H, W, v->e_in.kpad);
+    if (!ex.dry && !ex.rc) {
+      Im2colArgs a{}; a.f0 = x; a.c0 = c.in_channels; a.C = c.in_channels; a.B = B; a.IH = a.OH = H; a.IW = a.OW = W;
+      a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = v->e_in.kpad;
+      ex.rc = dmx_im2col_small_launch(a, ex.stream);
+    }
+    h = ex.linear(col, v->W<bf16>(v->e_in.w), c.block_out_channels[0], v->W<float>(v->e_in.b), nullptr, false);
+    ex.drop(col);
   }
-  Tn h = ex.linear(col, v->at<bf16>(v->e_in.w), c.block_out_channels[0], v->at<float>(v->e_in.b), nullptr, false);
-  ex.drop(col);
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L; ++j) {
-      Tn y = resnet_run(ex, v->arena, v->e_res[i][j], h, nullptr, G, 1e-6f, nullptr, 0);
+      Tn y = resnet_run(ex, v->wbase(), v->e_res[i][j], h, nullptr, G, 1e-6f, nullptr, 0, v->wmul());
       ex.drop(h); h = y;
     }
     if (i < 3) {                       // F.pad(h,(0,1,0,1)) + conv s2 p0: the gather's range check is the pad
-      ConvOpts o; o.stride = 2; o.pad = 0; o.bias = v->at<float>(v->e_ds[i].b);
-      Tn y = ex.conv(h, nullptr, v->at<bf16>(v->e_ds[i].w), c.block_out_channels[i], o);
+      ConvOpts o; o.stride = 2; o.pad = 0; o.bias = v->W<float>(v->e_ds[i].b);
+      Tn y = ex.conv(h, nullptr, v->W<bf16>(v->e_ds[i].w), c.block_out_channels[i], o);
       ex.drop(h); h = y;
     }
   }
-  { Tn y = resnet_run(ex, v->arena, v->e_mid[0], h, nullptr, G, 1e-6f, nullptr, 0); ex.drop(h);
+  { Tn y = resnet_run(ex, v->wbase(), v->e_mid[0], h, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(h);
     Tn z = attn_run(ex, v, v->e_attn, y, G); ex.drop(y);
-    h = resnet_run(ex, v->arena, v->e_mid[1], z, nullptr, G, 1e-6f, nullptr, 0); ex.drop(z); }
-  Tn t = ex.groupnorm(h, nullptr, v->at<float>(v->e_ng), v->at<float>(v->e_nb), G, 1e-6f, true);
+    h = resnet_run(ex, v->wbase(), v->e_mid[1], z, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(z); }
+  Tn t = ex.groupnorm(h, nullptr, v->W<float>(v->e_ng), v->W<float>(v->e_nb), G, 1e-6f, true);
   ex.drop(h);
-  ConvOpts oo; oo.bias = v->at<float>(v->e_out.b);
-  Tn m8 = ex.conv(t, nullptr, v->at<bf16>(v->e_out.w), 2 * c.latent_channels, oo);   // [M][8] bf16
+  ConvOpts oo; oo.bias = v->W<float>(v->e_out.b);
+  Tn m8 = ex.conv(t, nullptr, v->W<bf16>(v->e_out.w), 2 * c.latent_channels, oo);   // [M][8] bf16
   ex.drop(t);
+  if (ex.f32) {
+    ConvOpts oq; oq.ksize = 1; oq.pad = 0; oq.bias = v->W<float>(v->quant.b); oq.ldw = v->quant.kpad;
+    Tn mo = ex.conv(m8, nullptr, v->W<bf16>(v->quant.w), 2 * c.latent_channels, oq);
+    if (!ex.dry && !ex.rc) ex.rc = dmx_nhwc_to_nchw_f32_launch((const float*)mo.p, mo.ld, moments, B, mo.C, m8.H * m8.W, ex.stream);
+    ex.drop(m8); ex.drop(mo);
+    return ex.rc;
+  }
   // quant_conv 1x1 (8 -> 8): pad K to 64 and reuse the GEMM; fp32 out, then NCHW
   Tn qc = ex.make(B, m8.H, m8.W, v->quant.kpad);
   if (!ex.dry && !ex.rc) {
@@ -96,7 +131,7 @@ int vae_encode_run(dmx_vae* v, Exec& ex, const float* x, float* moments, int B, 
   }
   const int Mo = B * m8.H * m8.W, C2 = 2 * c.latent_channels;
   float* mo = (float*)ex.raw((size_t)Mo * C2 * 4);
-  ex.gemm_raw(qc.p, qc.ld, Mo, v->at<bf16>(v->quant.w), v->quant.kpad, C2, v->quant.kpad, v->at<float>(v->quant.b), mo, C2, 1);
+  ex.gemm_raw(qc.p, qc.ld, Mo, v->W<bf16>(v->quant.w), v->quant.kpad, C2, v->quant.kpad, v->W<float>(v->quant.b), mo, C2, 1);
   if (!ex.dry && !ex.rc) ex.rc = dmx_nhwc_to_nchw_f32_launch(mo, C2, moments, B, C2, m8.H * m8.W, ex.stream);
   ex.drop(qc); ex.drop(m8); ex.drop(mo);
   return ex.rc;
@@ -105,6 +140,17 @@ int vae_encode_run(dmx_vae* v, Exec& ex, const float* x, float* moments, int B, 
 int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, int h0, int w0) {
   const dmx_vae_config& c = v->cfg; const int G = c.norm_num_groups; const int L = c.layers_per_block;
   const int lc = c.latent_channels;
+  Tn h;
+  if (ex.f32) {
+    Tn zn = ex.make(B, h0, w0, lc);
+    if (!ex.dry && !ex.rc) ex.rc = dmx_concat_nchw_to_nhwc_f32_launch(z, lc, nullptr, 0, nullptr, 0, (float*)zn.p, B, h0 * w0, ex.stream);
+    ConvOpts op; op.ksize = 1; op.pad = 0; op.bias = v->W<float>(v->pquant.b); op.ldw = v->pquant.kpad;
+    Tn z2 = ex.conv(zn, nullptr, v->W<bf16>(v->pquant.w), lc, op);
+    ex.drop(zn);
+    ConvOpts oi; oi.bias = v->W<float>(v->d_in.b); oi.ldw = v->d_in.kpad;
+    h = ex.conv(z2, nullptr, v->W<bf16>(v->d_in.w), c.block_out_channels[3], oi);
+    ex.drop(z2);
+  } else {
   // post_quant_conv 1x1 on the NCHW fp32 latents
   Tn pc = ex.make(B, h0, w0, v->pquant.kpad);
   if (!ex.dry && !ex.rc) {
@@ -113,7 +159,7 @@ int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, in
     ex.rc = dmx_im2col_small_launch(a, ex.stream);
   }
   Tn z2 = ex.make(B, h0, w0, lc);
-  ex.gemm_raw(pc.p, pc.ld, B * h0 * w0, v->at<bf16>(v->pquant.w), v->pquant.kpad, lc, v->pquant.kpad, v->at<float>(v->pquant.b), z2.p, lc, 0);
+  ex.gemm_raw(pc.p, pc.ld, B * h0 * w0, v->W<bf16>(v->pquant.w), v->pquant.kpad, lc, v->pquant.kpad, v->W<float>(v->pquant.b), z2.p, lc, 0);
   ex.drop(pc);
   Tn col = ex.make(B, h0, w0, v->d_in.kpad);
   if (!ex.dry && !ex.rc) {
@@ -122,30 +168,32 @@ int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, in
     ex.rc = dmx_im2col_small_launch(a, ex.stream);
   }
   ex.drop(z2);
-  Tn h = ex.linear(col, v->at<bf16>(v->d_in.w), c.block_out_channels[3], v->at<float>(v->d_in.b), nullptr, false);
+  h = ex.linear(col, v->W<bf16>(v->d_in.w), c.block_out_channels[3], v->W<float>(v->d_in.b), nullptr, false);
   ex.drop(col);
-  { Tn y = resnet_run(ex, v->arena, v->d_mid[0], h, nullptr, G, 1e-6f, nullptr, 0); ex.drop(h);
+  }
+  { Tn y = resnet_run(ex, v->wbase(), v->d_mid[0], h, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(h);
     Tn zz = attn_run(ex, v, v->d_attn, y, G); ex.drop(y);
-    h = resnet_run(ex, v->arena, v->d_mid[1], zz, nullptr, G, 1e-6f, nullptr, 0); ex.drop(zz); }
+    h = resnet_run(ex, v->wbase(), v->d_mid[1], zz, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(zz); }
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L + 1; ++j) {
-      Tn y = resnet_run(ex, v->arena, v->d_res[i][j], h, nullptr, G, 1e-6f, nullptr, 0);
+      Tn y = resnet_run(ex, v->wbase(), v->d_res[i][j], h, nullptr, G, 1e-6f, nullptr, 0, v->wmul());
       ex.drop(h); h = y;
     }
     if (i < 3) {
       // nearest x2 + conv3x3 as four 2x2 phase convolutions on the source grid (GemmArgs.ups2)
-      static const bool direct = getenv("DMX_UPS_DIRECT") != nullptr;      // measurement aid
-      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = v->at<float>(v->d_us[i].b);
-      Tn y = ex.conv(h, nullptr, v->at<bf16>(direct ? v->d_us[i].w : v->d_us[i].wp), c.block_out_channels[3 - i], o);
+      static const bool env_direct = getenv("DMX_UPS_DIRECT") != nullptr;  // measurement aid
+      const bool direct = env_direct || ex.f32;                            // (the phase weights are derived data of the bf16 path)
+      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = v->W<float>(v->d_us[i].b);
+      Tn y = ex.conv(h, nullptr, v->W<bf16>(direct ? v->d_us[i].w : v->d_us[i].wp), c.block_out_channels[3 - i], o);
       ex.drop(h); h = y;
     }
   }
-  Tn t = ex.groupnorm(h, nullptr, v->at<float>(v->d_ng), v->at<float>(v->d_nb), G, 1e-6f, true);
+  Tn t = ex.groupnorm(h, nullptr, v->W<float>(v->d_ng), v->W<float>(v->d_nb), G, 1e-6f, true);
   ex.drop(h);
   const int Mo = B * t.H * t.W;
   float* im = (float*)ex.raw((size_t)Mo * c.out_channels * 4);
-  ConvOpts oo; oo.bias = v->at<float>(v->d_out.b); oo.out_f32 = 1;
-  ex.conv(t, nullptr, v->at<bf16>(v->d_out.w), c.out_channels, oo, im);
+  ConvOpts oo; oo.bias = v->W<float>(v->d_out.b); oo.out_f32 = 1;
+  ex.conv(t, nullptr, v->W<bf16>(v->d_out.w), c.out_channels, oo, im);
   if (!ex.dry && !ex.rc) ex.rc = dmx_nhwc_to_nchw_f32_launch(im, c.out_channels, image, B, c.out_channels, t.H * t.W, ex.stream);
   ex.drop(t); ex.drop(im);
   return ex.rc;
@@ -253,6 +301,36 @@ extern "C" int dmx_vae_encode(dmx_vae* v, const float* x, float* moments, int B,
   DMX_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0 && H > 0 && W > 0, "vae_encode: H=%d W=%d must be positive multiples of 8", H, W);
   Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
   return vae_encode_run(v, ex, x, moments, B, H, W);
+}
+// ---- fp32 VALIDATION instantiation (tests only): the same walkers on fp32 activations, the caller's fp32 master copy of the
+// parameters and the plain fp32 kernels of ref_f32.hip
+extern "C" size_t dmx_vae_workspace_bytes_f32(dmx_vae* v, int B, int H, int W, int decode) {
+  if (!v) return 0;
+  Exec ex; ex.dry = true; ex.f32 = true; ex.ws.reset(nullptr, 0, true);
+  v->masters_f32 = (const char*)4096;                  // dry run: pointers are never dereferenced
+  if (decode) vae_decode_run(v, ex, nullptr, nullptr, B, H, W); else vae_encode_run(v, ex, nullptr, nullptr, B, H, W);
+  v->masters_f32 = nullptr;
+  return ex.ws.peak() + 4096;
+}
+extern "C" int dmx_vae_encode_f32(dmx_vae* v, const void* masters, const float* x, float* moments, int B, int H, int W,
+                                  void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(v && masters && x && moments && workspace, "vae_encode_f32: null argument");
+  DMX_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0 && H > 0 && W > 0, "vae_encode_f32: H=%d W=%d must be positive multiples of 8", H, W);
+  Exec ex; ex.stream = (hipStream_t)stream; ex.f32 = true; ex.ws.reset(workspace, workspace_bytes, false);
+  v->masters_f32 = (const char*)masters;
+  const int rc = vae_encode_run(v, ex, x, moments, B, H, W);
+  v->masters_f32 = nullptr;
+  return rc;
+}
+extern "C" int dmx_vae_decode_f32(dmx_vae* v, const void* masters, const float* z, float* image, int B, int h, int w,
+                                  void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(v && masters && z && image && workspace, "vae_decode_f32: null argument");
+  DMX_REQUIRE(B > 0 && h > 0 && w > 0, "vae_decode_f32: empty problem");
+  Exec ex; ex.stream = (hipStream_t)stream; ex.f32 = true; ex.ws.reset(workspace, workspace_bytes, false);
+  v->masters_f32 = (const char*)masters;
+  const int rc = vae_decode_run(v, ex, z, image, B, h, w);
+  v->masters_f32 = nullptr;
+  return rc;
 }
 extern "C" int dmx_vae_decode(dmx_vae* v, const float* z, float* image, int B, int h, int w,
                               void* workspace, size_t workspace_bytes, dmx_stream_t stream) {

@@ -19,5 +19,11 @@ struct dmx_vae {
   CW pquant, d_in, d_out; ResW d_mid[2]; AttnW d_attn; std::vector<ResW> d_res[4]; CW d_us[4]; size_t d_ng, d_nb;
   std::shared_ptr<void> train_state;   // live training pass (vae_train.hip)
   template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
+  // fp32 VALIDATION mode (dmx_vae_encode_f32 / dmx_vae_decode_f32, tests only): for the duration of the call the parameters
+  // come from the caller's fp32 master arena, where weights-arena byte o lives at byte 2*o (as in the UNet's)
+  const char* masters_f32 = nullptr;
+  template <typename T> const T* W(size_t off) const { return masters_f32 ? (const T*)(masters_f32 + 2 * off) : (const T*)(arena + off); }
+  const char* wbase() const { return masters_f32 ? masters_f32 : arena; }
+  int wmul() const { return masters_f32 ? 2 : 1; }
 };
 

@@ -718,6 +718,49 @@ class AutoencoderKL(_HipModel):
                                        _cabi.current_stream()), "vae_decode")
         return DecoderOutput(sample=img) if return_dict else (img,)
 
+    # ---- fp32 VALIDATION path (tests only): the same graphs on fp32 activations, fp32 master weights, plain fp32 kernels
+    def _masters_fp32(self):
+        lib = _cabi.lib()
+        self._ensure_packed()
+        m = getattr(self, "_masters32", None)
+        if m is None or m[0] != self._packed_sig:
+            arena = torch.zeros(lib.dmx_vae_grad_bytes(self._h) // 4, dtype=torch.float32, device=self.device)
+            st = _cabi.current_stream()
+            for k, p in zip(self._keys, self._param_list()):
+                src = p.detach().to(torch.float32).contiguous()
+                _cabi.check(lib.dmx_vae_master_import(self._h, _cabi.ptr(arena), k.encode(), _cabi.ptr(src), st), f"vae_master_import({k})")
+            m = self._masters32 = (self._packed_sig, arena)
+        return m[1]
+
+    @torch.no_grad()
+    def encode_fp32(self, x):
+        """VALIDATION ONLY: `encode(x).latent_dist.parameters` (the moments) through the fp32 instantiation of the graph -
+        north_star's "within 1e-3 rel fp32" check at model level.  Slow; images up to ~384 px."""
+        lib = _cabi.lib()
+        m = self._masters_fp32()
+        x = x.to(torch.float32).contiguous()
+        B, C, H, W = x.shape
+        f = 2 ** (len(self.config.block_out_channels) - 1)
+        moments = torch.empty(B, 2 * self.config.latent_channels, H // f, W // f, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.dmx_vae_workspace_bytes_f32(self._h, B, H, W, 0), dtype=torch.uint8, device=x.device)
+        _cabi.check(lib.dmx_vae_encode_f32(self._h, _cabi.ptr(m), _cabi.ptr(x), _cabi.ptr(moments), B, H, W, _cabi.ptr(ws), ws.numel(),
+                                           _cabi.current_stream()), "vae_encode_f32")
+        return moments
+
+    @torch.no_grad()
+    def decode_fp32(self, z):
+        """VALIDATION ONLY: `decode(z).sample` through the fp32 instantiation of the graph."""
+        lib = _cabi.lib()
+        m = self._masters_fp32()
+        z = z.to(torch.float32).contiguous()
+        B, C, h, w = z.shape
+        f = 2 ** (len(self.config.block_out_channels) - 1)
+        img = torch.empty(B, self.config.out_channels, h * f, w * f, dtype=torch.float32, device=z.device)
+        ws = torch.empty(lib.dmx_vae_workspace_bytes_f32(self._h, B, h, w, 1), dtype=torch.uint8, device=z.device)
+        _cabi.check(lib.dmx_vae_decode_f32(self._h, _cabi.ptr(m), _cabi.ptr(z), _cabi.ptr(img), B, h, w, _cabi.ptr(ws), ws.numel(),
+                                           _cabi.current_stream()), "vae_decode_f32")
+        return img
+
     # ---- training (train_vae.py:716-736): recon = decode(encode(x).mode()) with a HIP backward
     def _train_buffers(self):
         lib = _cabi.lib()

@@ -413,6 +413,16 @@ size_t dmx_vae_workspace_bytes(dmx_vae* v, int B, int H, int W, int decode);
 int dmx_vae_encode(dmx_vae* v, const float* x, float* moments, int B, int H, int W,
                    void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 /* vae.decode(z).sample: z NCHW fp32 [B][latent][h][w] -> image [B][3][8h][8w]  (app.ipynb:819) */
+/* fp32 VALIDATION instantiation of the two graphs above (tests only; north_star's "within 1e-3 rel fp32" at model level for
+ * app.ipynb:793,819): fp32 activations, the fp32 master copy of the parameters (`masters`: dmx_vae_grad_bytes(v) bytes,
+ * filled by dmx_vae_master_import for every parameter) and the plain fp32 kernels.  The mid-block attention keeps the
+ * scores of 16 queries in LDS: images up to ~384 px. */
+int dmx_vae_master_import(const dmx_vae* v, void* masters, const char* name, const float* src, dmx_stream_t stream);
+size_t dmx_vae_workspace_bytes_f32(dmx_vae* v, int B, int H, int W, int decode);
+int dmx_vae_encode_f32(dmx_vae* v, const void* masters, const float* x, float* moments, int B, int H, int W,
+                       void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+int dmx_vae_decode_f32(dmx_vae* v, const void* masters, const float* z, float* image, int B, int h, int w,
+                       void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 int dmx_vae_decode(dmx_vae* v, const float* z, float* image, int B, int h, int w,
                    void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 

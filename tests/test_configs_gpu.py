@@ -48,6 +48,10 @@ def test_cfg3_sd_vae_256px_vs_oracle(cuda, sd_vae):
     e3 = assert_close(dec, OV.vae_decode(P, OV.SD_VAE, z.cpu(), emulate_bf16=True), E2E_EMU, "SD-VAE decode 256 px vs bf16emu")
     e4 = assert_close(dec, OV.vae_decode(P, OV.SD_VAE, z.cpu()), 5e-2, "SD-VAE decode 256 px vs fp32")
     print(f"cfg3 SD-VAE 256 px rel-L2: encode {e1:.2e} (bf16emu) {e2:.2e} (fp32); decode {e3:.2e} (bf16emu) {e4:.2e} (fp32)")
+    # the fp32 validation instantiation of the same graphs (north_star: within 1e-3 rel of the fp32 reference path)
+    f1 = assert_close(sd_vae.encode_fp32(img), OV.vae_encode_moments(P, OV.SD_VAE, img.cpu()), 1e-3, "SD-VAE encode 256 px, fp32 path vs fp32 oracle")
+    f2 = assert_close(sd_vae.decode_fp32(z), OV.vae_decode(P, OV.SD_VAE, z.cpu()), 1e-3, "SD-VAE decode 256 px, fp32 path vs fp32 oracle")
+    print(f"cfg3 SD-VAE 256 px fp32 validation path rel-L2: encode {f1:.2e}, decode {f2:.2e}")
 
 
 def test_cfg3_sd_vae_batch32_512px_properties(cuda, sd_vae):

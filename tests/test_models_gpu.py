@@ -787,3 +787,17 @@ def test_deferred_splitk_reduce_is_bit_identical(cuda, tiny_unet, tiny_vae, monk
           f"tiny vae encoder: {nv1[SPLITK]} vs {nv2[SPLITK]}")
     assert nu1[GNORM] == nu2[GNORM] and nu1[SPLITK] < nu2[SPLITK]
     assert nv1[SPLITK] <= nv2[SPLITK]
+
+
+def test_tiny_vae_fp32_validation_path(cuda, tiny_vae):
+    """north_star's "within 1e-3 rel fp32" at model level for the autoencoder: the fp32 instantiation of the encode / decode
+    graphs (fp32 activations, fp32 master weights, plain FMA kernels; AutoencoderKL.encode_fp32 / decode_fp32) against
+    the fp32 oracle's golden tensors."""
+    from diffute_amd.synthetic import synth_images
+    from diffute_amd.init import normal
+    g = np.load(os.path.join(GOLD, "tiny_vae.npz"))
+    img = synth_images(2, 64, 64, device=cuda)
+    z = normal(5, 22, 2 * 4 * 8 * 8, cuda).reshape(2, 4, 8, 8)
+    e1 = assert_close(tiny_vae.encode_fp32(img), torch.from_numpy(g["moments_fp32"]), 1e-3, "tiny vae fp32 path, moments")
+    e2 = assert_close(tiny_vae.decode_fp32(z), torch.from_numpy(g["image_fp32"]), 1e-3, "tiny vae fp32 path, image")
+    print(f"tiny vae fp32 validation path rel-L2: moments {e1:.2e}, image {e2:.2e}")
