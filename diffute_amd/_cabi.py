@@ -101,6 +101,10 @@ _PROTOS = {
     "dmx_vit_finalize": (c_int, [_P, _P]),
     "dmx_vit_workspace_bytes": (c_size_t, [_P, c_int]),
     "dmx_vit_forward": (c_int, [_P, _P, _P, c_int, _P, c_size_t, _P]),
+    "dmx_vit_master_bytes": (c_size_t, [_P]),
+    "dmx_vit_master_import": (c_int, [_P, _P, c_char_p, _P, _P]),
+    "dmx_vit_workspace_bytes_f32": (c_size_t, [_P, c_int]),
+    "dmx_vit_forward_f32": (c_int, [_P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "dmx_unet_create": (_P, [POINTER(UNetConfig)]),
     "dmx_unet_destroy": (None, [_P]),
     "dmx_unet_param_count": (c_int, [_P]),

@@ -73,6 +73,10 @@ class Workspace {
   size_t used_ = 0, peak_ = 0; bool failed_ = false;
 };
 
+// optim.hip: one parameter (torch layout, fp32) into an fp32 master arena laid out like the packed weights arena
+// (weights-arena byte o <-> master byte 2*o); shared by the UNet / autoencoder / ViT handles
+int dmx_master_import(const ParamTable& pt, void* masters, const char* name, const float* src, hipStream_t stream, const char* who);
+
 struct Tn {                 // NHWC bf16 activation [B*H*W][C] with row stride ld
   bf16* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0;
   int def = -1;             // >= 0: index of the Exec::Deferred record of the split-K GEMM that produced it (see Exec::conv)

@@ -204,7 +204,7 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
 Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpts& o, void* f32_out) {
   int OH = x0.H, OW = x0.W;
   if (o.ups) { OH *= 2; OW *= 2; }
-  if (o.stride == 2) { OH /= 2; OW /= 2; }
+  if (o.stride > 1) { OH /= o.stride; OW /= o.stride; }          // (2 in the UNet / autoencoder; the ViT patch conv of the fp32 path: patch size)
   ensure(x0); ensure(x1); ensure(o.res); ensure(o.sc0); ensure(o.sc1);
   Tn y; y.B = x0.B; y.H = OH; y.W = OW; y.C = Cout; y.ld = Cout;
   if (!o.out_f32) y = make(x0.B, OH, OW, Cout);
@@ -304,6 +304,14 @@ void Exec::gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N
 Tn Exec::linear_gelu(const Tn& x, const bf16* w, int N, const float* bias) {
   ensure(x);
   Tn y = make(x.B, x.H, x.W, N);
+  if (f32) {
+    GemmF32Args a{};
+    a.x0 = (const float*)x.p; a.x1 = a.x0; a.ldx0 = a.ldx1 = x.ld; a.cx0 = a.Cin = x.C; a.direct = 1; a.ksize = 1; a.stride = 1;
+    a.Ktaps = a.K = x.C; a.w = (const float*)w; a.ldw = x.C; a.M = x.rows(); a.N = N; a.bias = bias; a.rows_per_group = 1;
+    a.out = (float*)y.p; a.ldo = N; a.act = 1;
+    if (!dry && !rc) rc = dmx_gemm_f32_launch(a, stream);
+    return y;
+  }
   GemmArgs a{};
   a.x0 = x.p; a.x1 = x.p; a.ldx0 = x.ld; a.ldx1 = x.ld; a.cx0 = x.C; a.Cin = x.C;
   a.direct = 1; a.ksize = 1; a.stride = 1; a.IH = a.OH = x.H; a.IW = a.OW = x.W;

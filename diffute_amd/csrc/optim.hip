@@ -139,7 +139,7 @@ extern "C" int dmx_unet_optim_table(const dmx_unet* u, void* table_dev, size_t b
 }
 
 // master[name] <- src (fp32, torch layout)
-static int master_import(const ParamTable& pt, void* masters, const char* name, const float* src, hipStream_t stream, const char* who) {
+int dmx_master_import(const ParamTable& pt, void* masters, const char* name, const float* src, hipStream_t stream, const char* who) {
   const ParamEntry* e = pt.find(name);
   DMX_REQUIRE(e != nullptr, "%s: unknown parameter %s", who, name);
   const PackRule& r = e->rule;
@@ -159,13 +159,13 @@ static int master_import(const ParamTable& pt, void* masters, const char* name, 
 }
 extern "C" int dmx_unet_master_import(const dmx_unet* u, void* masters, const char* name, const float* src, dmx_stream_t stream) {
   DMX_REQUIRE(u && masters && name && src, "unet_master_import: null argument");
-  return master_import(u->pt, masters, name, src, (hipStream_t)stream, "unet_master_import");
+  return dmx_master_import(u->pt, masters, name, src, (hipStream_t)stream, "unet_master_import");
 }
 // the autoencoder's fp32 master copy (same layout rule: weights-arena byte o <-> master byte 2*o); used by the fp32
 // validation path dmx_vae_encode_f32 / dmx_vae_decode_f32
 extern "C" int dmx_vae_master_import(const dmx_vae* v, void* masters, const char* name, const float* src, dmx_stream_t stream) {
   DMX_REQUIRE(v && masters && name && src, "vae_master_import: null argument");
-  return master_import(v->pt, masters, name, src, (hipStream_t)stream, "vae_master_import");
+  return dmx_master_import(v->pt, masters, name, src, (hipStream_t)stream, "vae_master_import");
 }
 
 // scalars: device float[2] = (gradient norm before clipping, clip coefficient); workspace: nchunks floats.

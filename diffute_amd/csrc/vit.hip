@@ -34,6 +34,14 @@ __global__ __launch_bounds__(256) void dmx_vit_assemble_kernel(const bf16* emb, 
     *(u32x4*)(x + r * D + c) = pack_bf8(v);
   }
 }
+__global__ __launch_bounds__(256) void dmx_vit_assemble_f32_kernel(const float* emb, const float* cls, const float* pos, float* x, int B, int NP, int D) {
+  const size_t total = (size_t)B * (NP + 1) * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D); const size_t r = i / D;
+    const int tkn = (int)(r % (NP + 1)); const int b = (int)(r / (NP + 1));
+    x[i] = (tkn == 0 ? cls[c] : emb[((size_t)b * NP + (tkn - 1)) * D + c]) + pos[(size_t)tkn * D + c];
+  }
+}
 __global__ __launch_bounds__(256) void dmx_bf16_to_f32_kernel(const bf16* in, float* out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     out[i] = bf_bits2f(((const unsigned short*)in)[i]);
@@ -48,6 +56,9 @@ struct dmx_vit {
   size_t cls, pos, pw, pb, lng, lnb; int kpad = 0, np = 0;
   std::vector<VitLayer> layers;
   template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
+  // fp32 VALIDATION mode (dmx_vit_forward_f32, tests only): parameters from the caller's fp32 master arena (byte offsets double)
+  const char* masters_f32 = nullptr;
+  template <typename T> const T* W(size_t off) const { return masters_f32 ? (const T*)(masters_f32 + 2 * off) : (const T*)(arena + off); }
 };
 
 extern "C" dmx_vit* dmx_vit_create(const dmx_vit_config* cfg) {
@@ -127,40 +138,70 @@ int vit_run(dmx_vit* v, Exec& ex, const float* pixels, float* out, int B) {
   const dmx_vit_config& c = v->cfg;
   const int D = c.hidden_size, H = c.num_heads, S = v->np + 1, g = c.image_size / c.patch_size;
   // ---- patch embedding
-  Tn col = ex.make(B, g, g, v->kpad);
-  if (!ex.dry && !ex.rc) {
-    Im2colArgs a{}; a.f0 = pixels; a.c0 = c.num_channels; a.C = c.num_channels;
-    a.B = B; a.IH = a.IW = c.image_size; a.OH = a.OW = g; a.ksize = c.patch_size; a.stride = c.patch_size; a.pad = 0; a.out = col.p; a.Kpad = v->kpad;
-    ex.rc = dmx_im2col_small_launch(a, ex.stream);
+  Tn emb;
+  if (ex.f32) {                                        // NCHW -> NHWC, then the generic strided conv on the K-padded filter matrix
+    Tn xn = ex.make(B, c.image_size, c.image_size, c.num_channels);
+    if (!ex.dry && !ex.rc) ex.rc = dmx_concat_nchw_to_nhwc_f32_launch(pixels, c.num_channels, nullptr, 0, nullptr, 0, (float*)xn.p, B, c.image_size * c.image_size, ex.stream);
+    ConvOpts op; op.ksize = c.patch_size; op.stride = c.patch_size; op.pad = 0; op.bias = v->W<float>(v->pb); op.ldw = v->kpad;
+    emb = ex.conv(xn, nullptr, v->W<bf16>(v->pw), D, op);
+    ex.drop(xn);
+  } else {
+    Tn col = ex.make(B, g, g, v->kpad);
+    if (!ex.dry && !ex.rc) {
+      Im2colArgs a{}; a.f0 = pixels; a.c0 = c.num_channels; a.C = c.num_channels;
+      a.B = B; a.IH = a.IW = c.image_size; a.OH = a.OW = g; a.ksize = c.patch_size; a.stride = c.patch_size; a.pad = 0; a.out = col.p; a.Kpad = v->kpad;
+      ex.rc = dmx_im2col_small_launch(a, ex.stream);
+    }
+    emb = ex.linear(col, v->W<bf16>(v->pw), D, v->W<float>(v->pb), nullptr, false);
+    ex.drop(col);
   }
-  Tn emb = ex.linear(col, v->at<bf16>(v->pw), D, v->at<float>(v->pb), nullptr, false);
-  ex.drop(col);
   Tn x = ex.make(1, 1, B * S, D);
-  if (!ex.dry && !ex.rc) {
+  if (ex.f32) {
+    if (!ex.dry && !ex.rc) {
+      hipLaunchKernelGGL(dmx_vit_assemble_f32_kernel, dim3(4096), dim3(256), 0, ex.stream, (const float*)emb.p, v->W<float>(v->cls), v->W<float>(v->pos), (float*)x.p, B, v->np, D);
+      ex.rc = dmx_check_launch("dmx_vit_assemble_f32_kernel");
+    }
+  } else if (!ex.dry && !ex.rc) {
     const size_t total = (size_t)B * S * (D / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dmx_vit_assemble_kernel, dim3(blocks), dim3(256), 0, ex.stream, emb.p, v->at<float>(v->cls), v->at<float>(v->pos), x.p, B, v->np, D);
+    hipLaunchKernelGGL(dmx_vit_assemble_kernel, dim3(blocks), dim3(256), 0, ex.stream, emb.p, v->W<float>(v->cls), v->W<float>(v->pos), x.p, B, v->np, D);
     ex.rc = dmx_check_launch("dmx_vit_assemble_kernel");
   }
   ex.drop(emb);
   for (const VitLayer& L : v->layers) {
-    Tn n1 = ex.layernorm(x, v->at<float>(L.l1g), v->at<float>(L.l1b), c.layer_norm_eps);
-    Tn qkv = ex.linear(n1, v->at<bf16>(L.wqkv), 3 * D, v->at<float>(L.bqkv), nullptr, false);
+    Tn n1 = ex.layernorm(x, v->W<float>(L.l1g), v->W<float>(L.l1b), c.layer_norm_eps);
+    const float* bqkv = v->W<float>(L.bqkv);
+    float* btmp = nullptr;
+    if (ex.f32) {                                      // the q / k / v bias vectors are not adjacent in the fp32 master arena
+      btmp = (float*)ex.raw((size_t)3 * D * 4);
+      if (!ex.dry && !ex.rc)
+        for (int i = 0; i < 3 && !ex.rc; ++i)
+          if (hipMemcpyAsync(btmp + (size_t)i * D, v->W<float>(L.bqkv + (size_t)i * D * 4), (size_t)D * 4, hipMemcpyDeviceToDevice, ex.stream) != hipSuccess) {
+            dmx_set_error("hipMemcpyAsync failed (ViT q/k/v biases)"); ex.rc = DMX_ERR_HIP;
+          }
+      bqkv = btmp;
+    }
+    Tn qkv = ex.linear(n1, v->W<bf16>(L.wqkv), 3 * D, bqkv, nullptr, false);
     ex.drop(n1);
+    if (btmp) ex.drop(btmp);
     Tn a = ex.make(1, 1, B * S, D);
-    ex.attention(qkv.p, 3 * D, qkv.p + D, 3 * D, qkv.p + 2 * D, 3 * D, S, a.p, D, B, H, S, S, 0.125f);
+    ex.attention(qkv.p, 3 * D, ex.col(qkv, D), 3 * D, ex.col(qkv, 2 * D), 3 * D, S, a.p, D, B, H, S, S, 0.125f);
     ex.drop(qkv);
-    Tn x2 = ex.linear(a, v->at<bf16>(L.wo), D, v->at<float>(L.bo), &x, false);
+    Tn x2 = ex.linear(a, v->W<bf16>(L.wo), D, v->W<float>(L.bo), &x, false);
     ex.drop(a); ex.drop(x);
-    Tn n2 = ex.layernorm(x2, v->at<float>(L.l2g), v->at<float>(L.l2b), c.layer_norm_eps);
-    Tn h = ex.linear_gelu(n2, v->at<bf16>(L.w1), c.intermediate_size, v->at<float>(L.b1));
+    Tn n2 = ex.layernorm(x2, v->W<float>(L.l2g), v->W<float>(L.l2b), c.layer_norm_eps);
+    Tn h = ex.linear_gelu(n2, v->W<bf16>(L.w1), c.intermediate_size, v->W<float>(L.b1));
     ex.drop(n2);
-    x = ex.linear(h, v->at<bf16>(L.w2), D, v->at<float>(L.b2), &x2, false);
+    x = ex.linear(h, v->W<bf16>(L.w2), D, v->W<float>(L.b2), &x2, false);
     ex.drop(h); ex.drop(x2);
   }
-  Tn y = ex.layernorm(x, v->at<float>(v->lng), v->at<float>(v->lnb), c.layer_norm_eps);
+  Tn y = ex.layernorm(x, v->W<float>(v->lng), v->W<float>(v->lnb), c.layer_norm_eps);
   ex.drop(x);
-  if (!ex.dry && !ex.rc) {
+  if (ex.f32) {
+    if (!ex.dry && !ex.rc && hipMemcpyAsync(out, y.p, (size_t)B * S * D * 4, hipMemcpyDeviceToDevice, ex.stream) != hipSuccess) {
+      dmx_set_error("hipMemcpyAsync failed (ViT output)"); ex.rc = DMX_ERR_HIP;
+    }
+  } else if (!ex.dry && !ex.rc) {
     const size_t n = (size_t)B * S * D;
     int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(dmx_bf16_to_f32_kernel, dim3(blocks), dim3(256), 0, ex.stream, y.p, out, n);
@@ -176,6 +217,30 @@ extern "C" size_t dmx_vit_workspace_bytes(dmx_vit* v, int B) {
   Exec ex; ex.dry = true; ex.ws.reset(nullptr, 0, true);
   vit_run(v, ex, nullptr, nullptr, B);
   return ex.ws.peak() + 4096;
+}
+// ---- fp32 VALIDATION instantiation (tests only): the same walker on fp32 activations, the caller's fp32 master copy of the
+// parameters (dmx_vit_master_bytes, filled by dmx_vit_master_import) and the plain fp32 kernels of ref_f32.hip
+extern "C" size_t dmx_vit_master_bytes(const dmx_vit* v) { return v ? 2 * v->pt.total() : 0; }
+extern "C" int dmx_vit_master_import(const dmx_vit* v, void* masters, const char* name, const float* src, dmx_stream_t stream) {
+  DMX_REQUIRE(v && masters && name && src, "vit_master_import: null argument");
+  return dmx_master_import(v->pt, masters, name, src, (hipStream_t)stream, "vit_master_import");
+}
+extern "C" size_t dmx_vit_workspace_bytes_f32(dmx_vit* v, int B) {
+  if (!v) return 0;
+  Exec ex; ex.dry = true; ex.f32 = true; ex.ws.reset(nullptr, 0, true);
+  v->masters_f32 = (const char*)4096;
+  vit_run(v, ex, nullptr, nullptr, B);
+  v->masters_f32 = nullptr;
+  return ex.ws.peak() + 4096;
+}
+extern "C" int dmx_vit_forward_f32(dmx_vit* v, const void* masters, const float* pixel_values, float* last_hidden_state, int B,
+                                   void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(v && masters && pixel_values && last_hidden_state && workspace && B > 0, "vit_forward_f32: null argument");
+  Exec ex; ex.stream = (hipStream_t)stream; ex.f32 = true; ex.ws.reset(workspace, workspace_bytes, false);
+  v->masters_f32 = (const char*)masters;
+  const int rc = vit_run(v, ex, pixel_values, last_hidden_state, B);
+  v->masters_f32 = nullptr;
+  return rc;
 }
 // last_hidden_state [B][num_patches + 1][hidden] fp32 from pixel_values [B][C][image][image] fp32 (NCHW, already
 // resized / normalised by the processor)

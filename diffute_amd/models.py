@@ -900,3 +900,27 @@ class TrOCREncoder(_HipModel):
         if self._dtype != torch.float32 and pixel_values.dtype != torch.float32:
             out = out.to(pixel_values.dtype)
         return BaseModelOutput(last_hidden_state=out) if return_dict else (out,)
+
+    @torch.no_grad()
+    def forward_fp32(self, pixel_values):
+        """VALIDATION ONLY: `last_hidden_state` through the fp32 instantiation of the graph (fp32 activations, fp32 master
+        weights, plain fp32 kernels) - compared with transformers' ViTModel at north_star's 1e-3.  Slow."""
+        lib = _cabi.lib()
+        self._ensure_packed()
+        x = pixel_values.to(torch.float32).contiguous()
+        B = x.shape[0]
+        m = getattr(self, "_masters32", None)
+        if m is None or m[0] != self._packed_sig:
+            arena = torch.zeros(lib.dmx_vit_master_bytes(self._h) // 4, dtype=torch.float32, device=x.device)
+            st = _cabi.current_stream()
+            sd = dict(self.named_parameters())
+            for k in self._keys:
+                src = sd[k].detach().to(torch.float32).contiguous()
+                _cabi.check(lib.dmx_vit_master_import(self._h, _cabi.ptr(arena), k.encode(), _cabi.ptr(src), st), f"vit_master_import({k})")
+            m = self._masters32 = (self._packed_sig, arena)
+        n = (self.config.image_size // self.config.patch_size) ** 2 + 1
+        out = torch.empty(B, n, self.config.hidden_size, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.dmx_vit_workspace_bytes_f32(self._h, B), dtype=torch.uint8, device=x.device)
+        _cabi.check(lib.dmx_vit_forward_f32(self._h, _cabi.ptr(m[1]), _cabi.ptr(x), _cabi.ptr(out), B, _cabi.ptr(ws), ws.numel(),
+                                            _cabi.current_stream()), "vit_forward_f32")
+        return out

@@ -391,6 +391,14 @@ int dmx_vit_finalize(dmx_vit* v, dmx_stream_t stream);
 size_t dmx_vit_workspace_bytes(dmx_vit* v, int B);
 int dmx_vit_forward(dmx_vit* v, const float* pixel_values, float* last_hidden_state, int B,
                     void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+/* fp32 VALIDATION instantiation (tests only): the same walker on fp32 activations, the fp32 master copy of the parameters
+ * (`masters`: dmx_vit_master_bytes(v) bytes, zero-filled, then dmx_vit_master_import for every parameter) and the plain fp32
+ * kernels - compared with transformers' ViTModel output (tests/golden/vit_transformers.npz) at north_star's 1e-3. */
+size_t dmx_vit_master_bytes(const dmx_vit* v);
+int dmx_vit_master_import(const dmx_vit* v, void* masters, const char* name, const float* src, dmx_stream_t stream);
+size_t dmx_vit_workspace_bytes_f32(dmx_vit* v, int B);
+int dmx_vit_forward_f32(dmx_vit* v, const void* masters, const float* pixel_values, float* last_hidden_state, int B,
+                        void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
 typedef struct dmx_vae_config {
   int in_channels, out_channels, latent_channels;

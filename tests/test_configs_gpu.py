@@ -185,3 +185,8 @@ def test_glyph_encoder_vs_transformers_fixture(cuda):
             y = enc(torch.from_numpy(g[f"{name}_pixels"]).cuda()).last_hidden_state
         e = assert_close(y, torch.from_numpy(g[f"{name}_last_hidden_state"]), 5e-2, f"HIP ViT ({name}) vs transformers.ViTModel fixture")
         print(f"glyph encoder ({name}) vs transformers fixture: rel-L2 {e:.2e}")
+        # the fp32 validation instantiation of the same graph against the same fixture: north_star's 1e-3 against the
+        # reference's actual dependency
+        yf = enc.forward_fp32(torch.from_numpy(g[f"{name}_pixels"]).cuda())
+        ef = assert_close(yf, torch.from_numpy(g[f"{name}_last_hidden_state"]), 1e-3, f"HIP ViT fp32 path ({name}) vs transformers.ViTModel fixture")
+        print(f"glyph encoder ({name}) fp32 validation path vs transformers fixture: rel-L2 {ef:.2e}")
