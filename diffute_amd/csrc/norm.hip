@@ -215,7 +215,7 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
     // is what the load rate hangs on).  rows_per_group == HW (host-checked): bias and row bias are per-thread constants.
     typedef float FV __attribute__((ext_vector_type(2 * VEC)));
     typedef __attribute__((address_space(1))) FV GFV;
-    constexpr int UB = VEC == 4 ? 2 : (NU < 4 ? NU : 4);
+    constexpr int UB = VEC == 4 ? (NU < 2 ? NU : 2) : (NU < 4 ? NU : 4);
     static_assert(NU % UB == 0, "unit batches");
     FV bv, rbv;
 #pragma unroll
@@ -366,9 +366,11 @@ static bool gn_slab_launch(const GroupNormArgs& a, hipStream_t stream, bool dry 
     return true;                                                                                            \
   }
   // (instances whose slab would spill - 64 x 1, 44 x 2, 16 x 4 dwords per thread - are not built: those shapes take the two-launch path)
-  GN_SLAB(1, 8) GN_SLAB(1, 24)
-  GN_SLAB(2, 4) GN_SLAB(2, 16)
-  GN_SLAB(4, 2) GN_SLAB(4, 4) GN_SLAB(4, 8)
+  // (an instance walks all N_ units, masked: keep the ladder tight - the 32x32-level C = 640 slabs have 6 units and ran on the
+  // 16-unit instance at 11.9 us; on the 8-unit one: see DESIGN.md 5b)
+  GN_SLAB(1, 8) GN_SLAB(1, 16) GN_SLAB(1, 24)
+  GN_SLAB(2, 2) GN_SLAB(2, 4) GN_SLAB(2, 8) GN_SLAB(2, 16)
+  GN_SLAB(4, 1) GN_SLAB(4, 2) GN_SLAB(4, 4) GN_SLAB(4, 8)
 #undef GN_SLAB
   return false;
 }
