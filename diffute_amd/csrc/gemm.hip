@@ -846,7 +846,8 @@ static const TileCfg kCfg[15] = {            // measured (scripts/gemm_timeline.
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
-    {128, 64, 64, 256, 0.55, 6.0},          // deep ring (6 x 24 KB, 1 block/CU): small grids whose K loop is DMA-latency-bound
+    {128, 64, 64, 768, 0.55, 5.0},          // 128x64x64, eight waves, TWO-stage ring (49 KB): three blocks per CU so one block's prologue / epilogue
+                                            // overlaps the others' K loops (the K = C linears are 70 % prologue + epilogue); force_tn = 4 / tuned table
     {128, 128, 64, 256, 1.00, 7.0},         // deep ring (4 x 32 KB, 1 block/CU)
     {256, 256, 32, 256, 2.40, 16.0},        // 128 FLOP/B (experimental, force_tn = 6 only)
     {256, 128, 64, 256, 1.90, 11.0},        // warp-specialised 256x128x64: 4 MFMA waves + 4 DMA waves (~0.85 us per K-tile)
@@ -1042,7 +1043,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     if (c == 0) launch_cfg<2, 2, 32, 4>(a, grid, stream);
     else if (c == 1) launch_cfg<2, 1, 32, 4>(a, grid, stream);
     else if (c == 2) launch_cfg<4, 2, 64, 3>(a, grid, stream);
-    else if (c == 3) launch_cfg<2, 1, 64, 6>(a, grid, stream);
+    else if (c == 3) launch_cfg<4, 1, 64, 2, 1>(a, grid, stream);
     else if (c == 4) launch_cfg<2, 2, 64, 4>(a, grid, stream);
     else if (c == 5) launch_cfg<4, 4, 32, 4>(a, grid, stream);
     else if (c == 6) launch_cfg<2, 2, 64, 3, 4, 4>(a, grid, stream);
