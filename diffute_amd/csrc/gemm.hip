@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
       __builtin_amdgcn_s_barrier();
       const int rbase = ep * RPP;                      // first tile row of this pass
       if (geglu) {
-        if constexpr (TN >= 2) {
+        if constexpr (BN >= 64) {                      // (a 64-column tile holds exactly one packed group: 32 'a' + 32 gate columns)
           // BN/2 output columns per tile row: octet og -> packed group Gg ('a' rows 64Gg.., gate rows 64Gg+32..)
           constexpr int GI = RPP * (BN / 16) / NT;
 #pragma unroll
@@ -904,7 +904,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
     for (const TunedPlan& tp : g_plan_overrides)
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 15 && !(tp.cfg >= 12 && !dmx_lin_applicable(a, tp.cfg - 12)) && !(tp.cfg >= 10 && tp.cfg < 12 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
-          !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
+          !(no_split && tp.sk > 1)) {
         const int bk = kCfg[tp.cfg].bk, nkt = a.K / bk;
         if (tp.cfg >= 12) { *cfg_out = tp.cfg; *splitk_out = 1; *ktps_out = nkt; return; }
         if (a.K % bk || a.Cin % bk || a.cx0 % bk || a.Ktaps % bk || (a.Ktaps < a.K && a.cs0 % bk) || tp.sk < 1 || (tp.sk > 1 && nkt / tp.sk < 4)) break;   // not applicable: normal plan
@@ -916,7 +916,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) &&
           !(tp.cfg >= 12 && !dmx_lin_applicable(a, tp.cfg - 12)) &&
           !(tp.cfg >= 10 && tp.cfg < 12 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
-          !(a.geglu && (tp.cfg == 1 || tp.cfg == 3 || tp.cfg == 7)) && !(no_split && tp.sk > 1)) {
+          !(no_split && tp.sk > 1)) {
         const int nkt = a.K / kCfg[tp.cfg].bk;
         if (tp.cfg >= 12) { *cfg_out = tp.cfg; *splitk_out = 1; *ktps_out = nkt; return; }
         int ktps = cdiv(nkt, tp.sk);
@@ -931,7 +931,6 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     const TileCfg& T = kCfg[c];
     if ((c == 3 || c == 4 || c == 5 || c >= 7) && !a.force_tn) continue;   // deep rings / 256x256: no gain inside the UNet pass; kept for experiments
     if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
-    if (a.geglu && (c == 1 || c == 3 || c == 7)) continue;
     if (a.force_tn == 1 && c != 1) continue;
     if (a.force_tn == 2 && c != 0) continue;
     if (a.force_tn == 3 && c != 2) continue;
