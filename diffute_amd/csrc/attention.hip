@@ -321,34 +321,22 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   }
 }
 
-// block shape: 128 query rows (4 waves x 32) by default; 256 rows (4 waves x 64) once the grid still covers the chip with
-// the larger blocks (the 64x64-level and 768-px self / cross attention), DMX_ATTN_ROWS=128|256 pins it (measurement aid)
-static int attn_rows_per_block(const AttnArgs& a) {
-  static const int pin = getenv("DMX_ATTN_ROWS") ? atoi(getenv("DMX_ATTN_ROWS")) : 0;
-  if (pin == 128 || pin == 256) return pin;
-  const long blocks256 = (long)cdiv(a.Sq, 256) * a.H * a.B;
-  (void)blocks256;
-  return 128;                                        // measured: the 256-row blocks lose on every shape of the pass (fewer, fatter waves per SIMD)
-}
-
+// block shape: 128 query rows (4 waves x 32).  256-row blocks (4 waves x 64 rows, 8 waves x 32 rows) lose on every shape of the
+// pass (EXPERIMENTS.md); the template keeps the R / NW parameters, only <., 1, 4> is instantiated.
 int dmx_attention_launch(const AttnArgs& a, hipStream_t stream) {
   DMX_REQUIRE(a.B > 0 && a.H > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
   DMX_REQUIRE(a.kv_rows >= a.Skv, "attention: kv_rows=%d < Skv=%d", a.kv_rows, a.Skv);
   DMX_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "attention: strides must be multiples of 8 (ldq=%d ldk=%d)", a.ldq, a.ldk);
-  const int rows = attn_rows_per_block(a);
-  dim3 grid(cdiv(a.Sq, rows), a.H, a.B);
+  dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
   if (a.v) {
     DMX_REQUIRE(a.ldv % 8 == 0, "attention: ldv=%d must be a multiple of 8", a.ldv);
-    static const int r2 = getenv("DMX_ATTN_R2") ? 1 : 0;       // measurement aid: 4 waves x 64 rows instead of 8 waves x 32 rows
-    if (rows == 256 && r2) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 2, 4>), grid, dim3(256), 0, stream, a);
-    else if (rows == 256) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 8>), grid, dim3(512), 0, stream, a);
-#ifdef DMX_ATTN_PROBE
+#ifdef DMX_PROBES
 #define PB(N) else if (pb == N) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4, N>), grid, dim3(256), 0, stream, a);
-    else if (const int pb = getenv("DMX_ATTN_PROBE_BITS") ? atoi(getenv("DMX_ATTN_PROBE_BITS")) : 0; pb == 0) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4>), grid, dim3(256), 0, stream, a);
+    if (const int pb = getenv("DMX_ATTN_PROBE_BITS") ? atoi(getenv("DMX_ATTN_PROBE_BITS")) : 0; pb == 0) hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4>), grid, dim3(256), 0, stream, a);
     PB(1) PB(2) PB(4) PB(8) PB(16) PB(32) PB(96) PB(3) PB(7) PB(24) PB(31) PB(127) PB(120)
 #undef PB
 #else
-    else hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4>), grid, dim3(256), 0, stream, a);
 #endif
   } else {
     grid = dim3(cdiv(a.Sq, 128), a.H, a.B);

@@ -79,7 +79,6 @@ int dmx_master_import(const ParamTable& pt, void* masters, const char* name, con
 
 struct Tn {                 // NHWC bf16 activation [B*H*W][C] with row stride ld
   bf16* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0;
-  int def = -1;             // >= 0: index of the Exec::Deferred record of the split-K GEMM that produced it (see Exec::conv)
   int rows() const { return B * H * W; }
 };
 
@@ -99,10 +98,6 @@ struct ConvOpts {
   const Tn* res = nullptr;
   const Tn* sc0 = nullptr; const Tn* sc1 = nullptr;   // fused 1x1 shortcut sources
   int out_f32 = 0;
-  // split-K outputs whose next consumer is a GroupNorm: leave the fp32 partials un-reduced, the GroupNorm slab kernel
-  // reduces them while it loads its slab (Exec::groupnorm).  1 = the GroupNorm is the only consumer (the bf16 tensor is
-  // never written), 2 = the GroupNorm comes first and writes the bf16 tensor for the later consumers.
-  int defer = 0;
 };
 
 class Exec {
@@ -111,10 +106,6 @@ class Exec {
   bool dry = false;
   int rc = 0;
   Workspace ws;
-  // A split-K GEMM output that still sits in the workspace as fp32 partial sums.  Every op that takes a Tn calls
-  // ensure() on its inputs, so a tensor no GroupNorm picked up is reduced by the ordinary reduce kernel on first use.
-  struct Deferred { GemmArgs a; void* part = nullptr; int need_y = 0; bool done = false; std::vector<const void*> held; };
-  std::vector<Deferred> defs;
   // fp32 VALIDATION mode (ref_f32.hip): activations are floats (Tn::p points to float data), weights come from the fp32
   // master arena (callers pass float pointers typed as bf16*), every op runs the plain fp32 kernel.  Tests only.
   bool f32 = false;
@@ -135,11 +126,7 @@ class Exec {
     if (ws.failed() && !rc) { dmx_set_error("workspace too small"); rc = DMX_ERR_WORKSPACE; }
     return p;
   }
-  // a buffer a still-pending deferred reduce reads as its residual stays allocated until that reduce has run
-  void drop(const void* p) {
-    for (Deferred& d : defs) if (!d.done && p && (const void*)d.a.res == p) { d.held.push_back(p); return; }
-    ws.release(p);
-  }
+  void drop(const void* p) { ws.release(p); }
   void drop(const Tn& t) { drop((const void*)t.p); }
 
   // y = GroupNorm(x0|x1) [SiLU]
@@ -162,12 +149,8 @@ class Exec {
   // fused attention core; V row-major (LDS transpose-read path)
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                  bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale);
-  bool pending(const Tn& t) const { return t.def >= 0 && !defs[t.def].done; }
-  void ensure(const Tn& t);        // reduce now (the plain reduce kernel) if still pending
-  void ensure(const Tn* t) { if (t) ensure(*t); }
  private:
-  void run_gemm(GemmArgs& a, Tn* y = nullptr, int defer = 0);
-  void finish(const Tn& t);        // mark consumed, release the partials
+  void run_gemm(GemmArgs& a);
 };
 
 // ResnetBlock2D weights (offsets into the arena) shared by the UNet and VAE graphs

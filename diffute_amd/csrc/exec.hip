@@ -122,44 +122,16 @@ void Workspace::release(const void* p) {
 }
 
 // --------------------------------------------------------------------------- Exec ops
-void Exec::run_gemm(GemmArgs& a, Tn* y, int defer) {
+void Exec::run_gemm(GemmArgs& a) {
   if (rc) return;
   const size_t wsb = dmx_gemm_workspace_bytes(a);
   void* w = wsb ? raw(wsb) : nullptr;
-  // Measured (round 2): NOT a win on cfg1 - the slab kernel runs B * groups = 64 blocks, so the partial
-  // planes are read through a quarter of the CUs and the GroupNorm grows by what the (full-chip, ~4 us) reduce launch
-  // cost; 11.12 img/s without vs 11.08 with.  Off by default; DMX_DEFER_REDUCE=1 turns it on (tests run both schedules
-  // and compare them bit for bit).
-  const char* de = getenv("DMX_DEFER_REDUCE");
-  const bool keep = w && y && defer && !a.out_f32 && de && de[0] == '1';
-  a.defer_reduce = keep ? 1 : 0;
   if (!dry && !rc) rc = dmx_gemm_launch(a, w, wsb, stream);
-  if (keep) {                                          // same allocation sequence in the dry run: the partials live until the consumer
-    Deferred d; d.a = a; d.part = w; d.need_y = defer == 2;
-    int c, sk, ktps; dmx_gemm_plan(a, &c, &sk, &ktps);
-    d.a.partial = (float*)w; d.a.splitk = sk; d.a.kt_per_split = ktps;
-    y->def = (int)defs.size(); defs.push_back(d);
-    return;
-  }
   if (w) ws.release(w);
-}
-
-void Exec::finish(const Tn& t) {
-  Deferred& d = defs[t.def];
-  d.done = true;
-  ws.release(d.part);
-  for (const void* h : d.held) ws.release(h);
-  d.held.clear();
-}
-void Exec::ensure(const Tn& t) {
-  if (!pending(t)) return;
-  if (!dry && !rc) rc = dmx_splitk_reduce_launch(defs[t.def].a, stream);
-  finish(t);
 }
 
 Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, bool silu) {
   const int C = x0.C + (x1 ? x1->C : 0);
-  ensure(x1);
   Tn y = make(x0.B, x0.H, x0.W, C);
   if (f32) {
     if (!dry && !rc)
@@ -177,27 +149,12 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
     a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu ? 1 : 0;
     a.y = y.p; a.ldy = y.ld; a.partial = (float*)part;
     const bool one = dmx_gn_single_launch(a);
-    double extra = 0.0; int fsk = 0;
-    if (pending(x0)) {
-      const Deferred& d = defs[x0.def];
-      if (one && x0.ld == x0.C && d.a.N == x0.C && d.a.ldo == x0.C && (!d.a.rowbias || d.a.rows_per_group == x0.H * x0.W)) {
-        // the reduce pass of the split-K GEMM that produced x0 runs inside the slab kernel
-        a.gpart = d.a.partial; a.g_sk = fsk = d.a.splitk; a.g_plane = (size_t)d.a.M * d.a.N;
-        a.gbias = d.a.bias; a.growbias = d.a.rowbias; a.g_rpg = d.a.rows_per_group; a.g_ldrb = d.a.ldrb;
-        a.gres = d.a.res; a.g_ldres = d.a.ldres;
-        a.gy = d.need_y ? x0.p : nullptr; a.g_ldy = x0.ld;
-        extra = (4.0 * fsk - 2.0 + (d.need_y ? 2.0 : 0.0) + (d.a.res ? 2.0 : 0.0)) * (double)x0.rows() * x0.C;
-      } else {
-        rc = dmx_splitk_reduce_launch(d.a, stream);
-      }
-    }
-    char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d%s sk=%d", x0.rows(), C, one ? " slab" : "", fsk);
+    char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d%s", x0.rows(), C, one ? " slab" : "");
     // bf16: read x + write y when the slab stays in registers, otherwise x is read twice (stats, apply)
-    ProfScope ps(PROF_GNORM, stream, 0.0, (one ? 4.0 : 6.0) * (double)x0.rows() * C + extra, tag);
+    ProfScope ps(PROF_GNORM, stream, 0.0, (one ? 4.0 : 6.0) * (double)x0.rows() * C, tag);
     if (!rc) rc = dmx_groupnorm_launch(a, stream);
   }
   ws.release(part);
-  if (pending(x0)) finish(x0);
   return y;
 }
 
@@ -205,7 +162,6 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   int OH = x0.H, OW = x0.W;
   if (o.ups) { OH *= 2; OW *= 2; }
   if (o.stride > 1) { OH /= o.stride; OW /= o.stride; }          // (2 in the UNet / autoencoder; the ViT patch conv of the fp32 path: patch size)
-  ensure(x0); ensure(x1); ensure(o.res); ensure(o.sc0); ensure(o.sc1);
   Tn y; y.B = x0.B; y.H = OH; y.W = OW; y.C = Cout; y.ld = Cout;
   if (!o.out_f32) y = make(x0.B, OH, OW, Cout);
   if (f32) {
@@ -254,14 +210,13 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   a.bias = o.bias; a.rowbias = o.rowbias; a.rows_per_group = OH * OW; a.ldrb = o.ldrb;
   if (o.res) { a.res = o.res->p; a.ldres = o.res->ld; }
   a.out = o.out_f32 ? f32_out : (void*)y.p; a.ldo = Cout; a.out_f32 = o.out_f32;
-  run_gemm(a, &y, o.defer);
+  run_gemm(a);
   return y;
 }
 
 Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu,
                 RowStats* rowstats, const LnIn* ln) {
   const int Nout = geglu ? N / 2 : N;
-  ensure(x); ensure(res);
   Tn y = make(x.B, x.H, x.W, Nout);
   if (f32) {                                           // (the folded-LayerNorm / row-statistics protocol is a bf16-path fusion: callers normalise explicitly)
     GemmF32Args a{};
@@ -302,7 +257,6 @@ void Exec::gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N
 }
 
 Tn Exec::linear_gelu(const Tn& x, const bf16* w, int N, const float* bias) {
-  ensure(x);
   Tn y = make(x.B, x.H, x.W, N);
   if (f32) {
     GemmF32Args a{};
@@ -324,7 +278,6 @@ Tn Exec::linear_gelu(const Tn& x, const bf16* w, int N, const float* bias) {
 }
 
 Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps) {
-  ensure(x);
   Tn y = make(x.B, x.H, x.W, x.C);
   if (f32) {
     if (!dry && !rc) rc = dmx_layernorm_f32_launch((const float*)x.p, x.ld, (float*)y.p, y.ld, gamma, beta, x.rows(), x.C, eps, stream);
@@ -355,7 +308,6 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
 
 void Exec::tap(const Tn& t) {
   if (!taps) return;
-  ensure(t);
   if (dry || rc) return;
   const size_t n = (size_t)t.rows() * t.C;
   if (taps->n >= 16) return;                           // (only reachable with the DMX_TAPS_FINE debugging switch)
@@ -406,7 +358,6 @@ Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn
   Tn t1 = ex.groupnorm(x0, x1, F(r.n1g), F(r.n1b), groups, eps, true);
   ConvOpts o1; o1.bias = F(r.b1);
   if (r.temb_off >= 0 && tproj) { o1.rowbias = tproj + r.temb_off; o1.ldrb = tproj_total; }
-  o1.defer = 1;                                        // norm2 is conv1's only consumer
   Tn t2 = ex.conv(t1, nullptr, H(r.w1), r.cout, o1);
   ex.drop(t1);
   Tn t3 = ex.groupnorm(t2, nullptr, F(r.n2g), F(r.n2b), groups, eps, true);
@@ -414,8 +365,7 @@ Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn
   ConvOpts o2; o2.bias = F(r.b2);
   if (ex.f32 && r.shortcut) { o2.bias = F(r.b2raw); o2.bias2 = F(r.bscraw); }     // the folded bias is derived data: not in the master arena
   if (r.shortcut) { o2.sc0 = &x0; o2.sc1 = x1; } else { o2.res = &x0; }
-  o2.defer = 2;                                        // a GroupNorm comes next in every graph (next resnet / transformer / attention / out norm);
-  Tn y = ex.conv(t3, nullptr, H(r.w2), r.cout, o2);    // any other first consumer reduces it on use (Exec::ensure)
+  Tn y = ex.conv(t3, nullptr, H(r.w2), r.cout, o2);
   ex.drop(t3);
   return y;
 }

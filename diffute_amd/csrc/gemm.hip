@@ -49,7 +49,7 @@ struct RowSrc {          // per-thread state for one staged activation row
 //   11 <4,5,64,2,1,0,2> 128x320x64: eight waves (4 x 2) of 32x160 sub-tiles, 2-buffer ring (112 KB, 1 block/CU); five whole packed
 //                     GEGLU groups per tile, same epilogue as 10 plus folded LayerNorm + GEGLU: the FF1 GEMM of the 16x16 level
 //                     (1024 x 10240 x 1280) becomes 256 tiles = one full round instead of 640 tiles on 512 slots
-//   3, 4, 5           deep-ring and 256x256 experiments, force_tn only
+//   3, 4, 5           retired (two-stage 128x64, deep-ring 128x128x64, 256x256x32: measured, not adopted - EXPERIMENTS.md)
 // measurement aid: 100 MHz wall ticks, or (dbg bit 2) shader-clock cycles - their ratio is the effective clock
 __device__ __forceinline__ long long dmx_now(int dbg) {
   return (dbg & 4) ? (long long)__builtin_amdgcn_s_memtime() : (long long)__builtin_amdgcn_s_memrealtime();
@@ -842,7 +842,7 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[15] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[12] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
@@ -859,14 +859,7 @@ static const TileCfg kCfg[15] = {            // measured (scripts/gemm_timeline.
                                             // count of this UNet (320 k), so no column of a tile is wasted; force_tn = 11 / tuned table
     {128, 320, 64, 256, 2.00, 10.0},        // 128x320x64, eight waves (4 x 2), 32x160 sub-tiles, 2-buffer ring (112 KB, 1 block/CU): five whole
                                             // GEGLU groups per tile - the feed-forward GEMMs (N = 8C) tile without a partial round; force_tn = 12
-    // 12..14: the persistent direct-GEMM kernel of lin.hip (linear layers; no split-K): force_tn = 13 / 14 / 15 or the tuned table
-    {128, 160, 64, 256, 1.0, 5.0},          // 4 waves x (32 x 160), 3-stage ring
-    {128, 64, 64, 256, 0.6, 5.0},           // 4 waves x (32 x 64), 4-stage ring (small M: more tiles)
-    {128, 256, 32, 256, 1.2, 5.0},          // 8 waves (4 x 2) x (32 x 128), 4-stage ring of 32-deep K-tiles: GEGLU feed-forward and other wide-N linears
 };
-int dmx_lin_launch(const GemmArgs& a, int lin, hipStream_t stream);
-bool dmx_lin_applicable(const GemmArgs& a, int lin);
-int dmx_lin_cfg_strips(int lin);
 
 static double plan_cost(const GemmArgs& a, int c, int sk) {
   const TileCfg& T = kCfg[c];
@@ -903,10 +896,9 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
   if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
     const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
     for (const TunedPlan& tp : g_plan_overrides)
-      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 15 && !(tp.cfg >= 12 && !dmx_lin_applicable(a, tp.cfg - 12)) && !(tp.cfg >= 10 && tp.cfg < 12 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
+      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 12 && !(tp.cfg >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
           !(no_split && tp.sk > 1)) {
         const int bk = kCfg[tp.cfg].bk, nkt = a.K / bk;
-        if (tp.cfg >= 12) { *cfg_out = tp.cfg; *splitk_out = 1; *ktps_out = nkt; return; }
         if (a.K % bk || a.Cin % bk || a.cx0 % bk || a.Ktaps % bk || (a.Ktaps < a.K && a.cs0 % bk) || tp.sk < 1 || (tp.sk > 1 && nkt / tp.sk < 4)) break;   // not applicable: normal plan
         int ktps = cdiv(nkt, tp.sk);
         *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
@@ -914,29 +906,22 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
       }
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
       if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) &&
-          !(tp.cfg >= 12 && !dmx_lin_applicable(a, tp.cfg - 12)) &&
-          !(tp.cfg >= 10 && tp.cfg < 12 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
+          tp.cfg < 12 && !(tp.cfg >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
           !(no_split && tp.sk > 1)) {
         const int nkt = a.K / kCfg[tp.cfg].bk;
-        if (tp.cfg >= 12) { *cfg_out = tp.cfg; *splitk_out = 1; *ktps_out = nkt; return; }
         int ktps = cdiv(nkt, tp.sk);
         *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
         return;
       }
   }
-  if (a.force_tn >= 13 && a.force_tn <= 15 && dmx_lin_applicable(a, a.force_tn - 13)) {
-    *cfg_out = a.force_tn - 1; *splitk_out = 1; *ktps_out = a.K / kCfg[a.force_tn - 1].bk; return;
-  }
   for (int c = 0; c < 12; ++c) {
     const TileCfg& T = kCfg[c];
-    if ((c == 3 || c == 4 || c == 5 || c >= 7) && !a.force_tn) continue;   // deep rings / 256x256: no gain inside the UNet pass; kept for experiments
+    if (c == 3 || c == 4 || c == 5) continue;            // retired instances (two-stage / deep-ring / 256x256x32 experiments, EXPERIMENTS.md); ids kept so the tuned table's numbering is stable
+    if (c >= 7 && !a.force_tn) continue;                 // eight-wave / 160-column instances: tuned table or force_tn only
     if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
     if (a.force_tn == 1 && c != 1) continue;
     if (a.force_tn == 2 && c != 0) continue;
     if (a.force_tn == 3 && c != 2) continue;
-    if (a.force_tn == 4 && c != 3) continue;
-    if (a.force_tn == 5 && c != 4) continue;
-    if (a.force_tn == 6 && c != 5) continue;
     if (a.force_tn == 7 && c != 6) continue;
     if (a.force_tn == 8 && c != 7) continue;
     if (a.force_tn == 9 && c != 8) continue;
@@ -949,7 +934,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
     // 3x3 convolutions over <= 128 input channels (the 512^2 / 256^2 levels of the autoencoder, K = 1152): the weight operand is
     // as large as the activation operand per tile, so the 256-row tile's reuse buys nothing and its longer prologue / epilogue
     // shows - measured at batch 32 (scripts/vae_conv_probe.py): 128->128 3.54 vs 3.79 ms, 128->256 1.61 vs 1.76 ms
-    if (!a.force_tn && c == 2 && a.ksize == 3 && !a.direct && a.Cin <= 128 && a.Ktaps == a.K && !getenv("DMX_NO_THIN_RULE")) continue;
+    if (!a.force_tn && c == 2 && a.ksize == 3 && !a.direct && a.Cin <= 128 && a.Ktaps == a.K) continue;
     const int nkt = a.K / T.bk;
     const int max_sk = (a.geglu || a.act || (a.N % 4) != 0 || a.rowstats_out || a.ln_stats) ? 1 : 16;   // those epilogues live in the GEMM kernel
     for (int sk = 1; sk <= max_sk; ++sk) {
@@ -969,7 +954,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
 int dmx_gemm_tiles_n(const GemmArgs& a) {
   int c, sk, ktps;
   dmx_gemm_plan(a, &c, &sk, &ktps);
-  return cdiv(a.N, kCfg[c].bn) * (c >= 12 ? dmx_lin_cfg_strips(c - 12) : 1);     // lin.hip emits one row-statistics partial per wave column strip
+  return cdiv(a.N, kCfg[c].bn);
 }
 
 size_t dmx_gemm_workspace_bytes(const GemmArgs& a) {
@@ -1009,6 +994,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
                 a.Ktaps == a.K && a.K == 4 * a.Cin && a.w_phase_stride > 0, "gemm: inconsistent phase-decomposed upsample conv arguments");
     DMX_REQUIRE(!a.res && !a.rowbias && !a.geglu && !a.act && !a.ln_stats && !a.rowstats_out, "gemm: the phase-decomposed upsample conv takes a bias only");
   }
+  DMX_REQUIRE(a.force_tn < 4 || a.force_tn > 6, "gemm: tile instance %d was retired", a.force_tn);
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;
   int c, sk, ktps;
@@ -1023,14 +1009,6 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     a.partial = (float*)workspace;
   }
   const TileCfg& T = kCfg[c];
-  if (c >= 12) {
-    const double flops = 2.0 * a.M * (double)a.N * a.K;
-    const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * (a.geglu ? a.N / 2 : a.N));
-    char tag[96];
-    snprintf(tag, sizeof(tag), "M=%d N=%d K=%d ks=1 st=1 ups=0 tn=%d sk=1", a.M, a.N, a.K, c + 1);
-    ProfScope ps((ProfClass)(PROF_GEMM_CFG0 + c), stream, flops, bytes, tag);
-    return dmx_lin_launch(a, c - 12, stream);
-  }
   dim3 grid((a.ups2 ? 4 * cdiv(a.M4, T.bm) : cdiv(a.M, T.bm)) * cdiv(a.N, T.bn), sk, 1);
   // algorithmic work of this launch: 2*M*N*K flops; bytes = activations read once + weights + output
   const double flops = 2.0 * a.M * (double)a.N * a.K;
@@ -1042,9 +1020,6 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     if (c == 0) launch_cfg<2, 2, 32, 4>(a, grid, stream);
     else if (c == 1) launch_cfg<2, 1, 32, 4>(a, grid, stream);
     else if (c == 2) launch_cfg<4, 2, 64, 3>(a, grid, stream);
-    else if (c == 3) launch_cfg<4, 1, 64, 2, 1>(a, grid, stream);
-    else if (c == 4) launch_cfg<2, 2, 64, 4>(a, grid, stream);
-    else if (c == 5) launch_cfg<4, 4, 32, 4>(a, grid, stream);
     else if (c == 6) launch_cfg<2, 2, 64, 3, 4, 4>(a, grid, stream);
     else if (c == 7) launch_cfg<4, 1, 64, 3, 1>(a, grid, stream);
     else if (c == 8) launch_cfg<4, 2, 32, 4, 1>(a, grid, stream);
@@ -1054,7 +1029,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;
-  if (sk > 1 && !a.defer_reduce) rc = dmx_splitk_reduce_launch(a, stream);
+  if (sk > 1) rc = dmx_splitk_reduce_launch(a, stream);
   return rc;
 }
 

@@ -50,7 +50,6 @@ struct GemmArgs {
   int ln_C; float ln_eps;                      // normalised feature count (= K) and epsilon
   long long* timing;                           // optional per-block timeline (probe builds), normally null
   int dbg;                                     // measurement aid: bit0 skip the MFMA phase, bit1 skip the DMA refills (results invalid)
-  int defer_reduce;                            // split-K: leave the partials in the workspace, the consumer (GroupNorm slab kernel) reduces
   float* partial; int splitk, kt_per_split;   // filled by the launcher
   const bf16* zeros;                           // filled by the launcher
 };
@@ -91,13 +90,6 @@ struct GroupNormArgs {
   int C, groups; int B, HW;
   const float* gamma; const float* beta; float eps; int silu;
   bf16* y; int ldy;
-  // x0 given as the un-reduced output of a split-K GEMM (the reduce pass folded into this kernel; slab path only):
-  //   x0[row][c] = bf16( sum_s gpart[s][row*c0 + c] + gbias[c] + growbias[(row / g_rpg)*g_ldrb + c] + gres[row*g_ldres + c] )
-  // in the reduce kernel's operation order; written to gy (bf16, row stride g_ldy) when another consumer needs the tensor.
-  const float* gpart; int g_sk; size_t g_plane;
-  const float* gbias; const float* growbias; int g_rpg, g_ldrb;
-  const bf16* gres; int g_ldres;
-  bf16* gy; int g_ldy;
   float* partial;     // [B][nchunk][groups][2]
   float* stats_out;   // optional [B][groups][2] = (mean, rstd), kept for the backward pass (training)
   float* coef;        // [B][C][2] (filled by the launcher: lives behind partial in the workspace)

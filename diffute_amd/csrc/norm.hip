@@ -178,11 +178,7 @@ __device__ __forceinline__ float gn_block_sum(float v, float* red, int t, int nw
   return a;
 }
 
-// PART: the x0 part of the input is the un-reduced fp32 output of a split-K GEMM (GroupNormArgs::gpart ...): the reduce pass
-// (sum of the partial planes in split order + bias + time-embedding row bias + residual, one rounding to bf16 - exactly
-// dmx_splitk_reduce_kernel's arithmetic) happens while the slab is loaded, and the bf16 tensor is written out only when
-// another consumer needs it.  One launch and one HBM round trip less per split-K convolution.
-template <int VEC, int NU, bool SILU, bool PART = false>
+template <int VEC, int NU, bool SILU>
 __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p, int SU, int R, int dbg) {
   typedef typename GnVec<VEC>::T V;
   typedef __attribute__((address_space(1))) V GV;   // the opaque running pointers lose their address space: say global again
@@ -209,53 +205,6 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
   const char* const safe = (const char*)src;
   const char* lp = (const char*)(src + (size_t)r * ld);
   const size_t lstep = (size_t)R * ld * 2;
-  if (PART && c < p.c0) {
-    // this thread's channel unit lies in the split-K GEMM's output: reduce it here.  UB pixels at a time, every plane's
-    // loads of the batch issued together (the block is one of few - B * groups - so memory-level parallelism per thread
-    // is what the load rate hangs on).  rows_per_group == HW (host-checked): bias and row bias are per-thread constants.
-    typedef float FV __attribute__((ext_vector_type(2 * VEC)));
-    typedef __attribute__((address_space(1))) FV GFV;
-    constexpr int UB = VEC == 4 ? (NU < 2 ? NU : 2) : (NU < 4 ? NU : 4);
-    static_assert(NU % UB == 0, "unit batches");
-    FV bv, rbv;
-#pragma unroll
-    for (int e = 0; e < 2 * VEC; ++e) { bv[e] = p.gbias ? p.gbias[c + e] : 0.f; rbv[e] = p.growbias ? p.growbias[(size_t)b * p.g_ldrb + c + e] : 0.f; }
-    const size_t row0 = (size_t)b * p.HW;
-#pragma unroll
-    for (int k0 = 0; k0 < NU; k0 += UB) {
-      FV acc[UB]; V rv[UB]; size_t row[UB]; bool ok[UB];
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        ok[u] = active && (r + (k0 + u) * R < p.HW);
-        row[u] = row0 + (ok[u] ? r + (k0 + u) * R : 0);
-        acc[u] = *(const GFV*)(p.gpart + row[u] * p.c0 + c);
-      }
-      if (p.gres) {
-#pragma unroll
-        for (int u = 0; u < UB; ++u) rv[u] = *(const GV*)(p.gres + row[u] * p.g_ldres + c);
-      }
-      for (int sidx = 1; sidx < p.g_sk; ++sidx) {
-        FV tmp[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) tmp[u] = *(const GFV*)(p.gpart + (size_t)sidx * p.g_plane + row[u] * p.c0 + c);
-#pragma unroll
-        for (int u = 0; u < UB; ++u) acc[u] += tmp[u];
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        FV a = acc[u] + bv + rbv;                    // s + bias + rowbias with zeros for absent operands, as the reduce kernel has it
-        if (p.gres) {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) { const unsigned int w = gn_dw<VEC>(rv[u], i); a[2 * i] += __uint_as_float(w << 16); a[2 * i + 1] += __uint_as_float(w & 0xffff0000u); }
-        }
-        V o;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) gn_set<VEC>(o, i, pack_bf2(a[2 * i], a[2 * i + 1]));
-        v[k0 + u] = o;
-        if (p.gy && ok[u]) *(GV*)(p.gy + row[u] * p.g_ldy + c) = o;
-      }
-    }
-  } else {
 #pragma unroll
   for (int k = 0; k < NU; ++k) {
     const bool ok = active && (r + k * R < p.HW);
@@ -263,7 +212,6 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
     v[k] = *(const GV*)((ok && !(dbg & 2)) ? lp : safe);
     lp += lstep;
     __builtin_amdgcn_sched_barrier(0);               // issue each load before forming the next address
-  }
   }
 #pragma unroll
   for (int k = 0; k < NU; ++k) {
@@ -350,7 +298,7 @@ static bool gn_slab_launch(const GroupNormArgs& a, hipStream_t stream, bool dry 
   const int nu = cdiv(a.HW, R);
   const int threads = cdiv(R * SU, 64) * 64;
   const dim3 grid(a.B * a.groups), block(threads);
-#ifdef DMX_GN_SLAB_PROBE      // probe builds only (results invalid): 1 = no stores, 2 = no loads
+#ifdef DMX_PROBES      // probe builds only (results invalid): 1 = no stores, 2 = no loads
   static const int dbg = getenv("DMX_GN_SLAB_DBG") ? atoi(getenv("DMX_GN_SLAB_DBG")) : 0;
 #else
   constexpr int dbg = 0;
@@ -358,10 +306,7 @@ static bool gn_slab_launch(const GroupNormArgs& a, hipStream_t stream, bool dry 
 #define GN_SLAB(V_, N_)                                                                                      \
   if (vec == V_ && nu <= N_) {                                                                              \
     if (dry) return true;                                                                                   \
-    if (a.gpart) {                                                                                          \
-      if (a.silu) hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, true, true>), grid, block, 0, stream, a, SU, R, dbg);   \
-      else hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, false, true>), grid, block, 0, stream, a, SU, R, dbg);         \
-    } else if (a.silu) hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, true>), grid, block, 0, stream, a, SU, R, dbg);    \
+    if (a.silu) hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, true>), grid, block, 0, stream, a, SU, R, dbg);    \
     else hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, false>), grid, block, 0, stream, a, SU, R, dbg);          \
     return true;                                                                                            \
   }
@@ -376,8 +321,12 @@ static bool gn_slab_launch(const GroupNormArgs& a, hipStream_t stream, bool dry 
 }
 
 static bool gn_two_pass_forced() {
+#ifdef DMX_PROBES
   static const bool off = getenv("DMX_GN_TWO_PASS") != nullptr;          // measurement aid: force the two-launch path
   return off;
+#else
+  return false;
+#endif
 }
 // true when dmx_groupnorm_launch will take the single-launch path for this shape (1 read + 1 write of the tensor)
 bool dmx_gn_single_launch(GroupNormArgs a) {
@@ -399,7 +348,6 @@ int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream) {
   DMX_REQUIRE(a.partial != nullptr, "groupnorm: partial workspace is null");
   if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; }
   if (!gn_two_pass_forced() && gn_slab_launch(a, stream)) return dmx_check_launch("dmx_gn_slab_kernel");
-  DMX_REQUIRE(a.gpart == nullptr, "groupnorm: a split-K partial input needs the single-launch (slab) path - reduce it first");
   // ---- two-launch path (slabs that do not fit the register budget, e.g. 1024-px images)
   // thread = (row lane r < R, channel octet); wide blocks so each thread walks only a few rows
   const int oc = a.C / 8;

@@ -407,7 +407,11 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
   std::vector<Tn> skips; skips.push_back(h);
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L; ++j) {
+#ifdef DMX_PROBES
       static const bool fine = getenv("DMX_TAPS_FINE") != nullptr;      // debugging aid: also tap every resnet / transformer output of the down path
+#else
+      constexpr bool fine = false;
+#endif
       Tn y = f.resnet(u->down_res[i][j], h, nullptr);
       if (fine) ex.tap(y);
       if (cfg.down_has_attn[i]) { Tn z = f.xformer(u->down_xf[i][j], y); ex.drop(y); y = z; if (fine) ex.tap(y); }
@@ -434,8 +438,7 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
     }
     if (i < 3) {
       // nearest x2 + conv3x3 as four 2x2 phase convolutions on the source grid (pre-summed taps): 4/9 of the multiply-adds
-      static const bool env_direct = getenv("DMX_UPS_DIRECT") != nullptr;  // measurement aid: gather over the virtual upsampled grid
-      const bool direct = env_direct || ex.f32;                            // (the phase weights are derived data of the bf16 path)
+      const bool direct = ex.f32;                                          // (the phase weights are derived data of the bf16 path)
       ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = f.W<float>(u->up_us[i].b);
       Tn y = ex.conv(h, nullptr, direct ? f.W<bf16>(u->up_us[i].w) : u->at<bf16>(u->up_us[i].wp), boc[3 - i], o);
       ex.drop(h); h = y;

@@ -181,8 +181,7 @@ int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, in
     }
     if (i < 3) {
       // nearest x2 + conv3x3 as four 2x2 phase convolutions on the source grid (GemmArgs.ups2)
-      static const bool env_direct = getenv("DMX_UPS_DIRECT") != nullptr;  // measurement aid
-      const bool direct = env_direct || ex.f32;                            // (the phase weights are derived data of the bf16 path)
+      const bool direct = ex.f32;                                          // (the phase weights are derived data of the bf16 path)
       ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = v->W<float>(v->d_us[i].b);
       Tn y = ex.conv(h, nullptr, v->W<bf16>(direct ? v->d_us[i].w : v->d_us[i].wp), c.block_out_channels[3 - i], o);
       ex.drop(h); h = y;

@@ -130,8 +130,12 @@ def make_params(spec, seed=1234, dtype=torch.float32):
 
 # ----------------------------------------------------------------------------- math
 def _q(x, on):
-    """Round to bf16 and back (HBM materialisation point of the HIP path)."""
-    return x.to(torch.bfloat16).to(torch.float32) if on else x
+    """Round to the storage type and back (HBM materialisation point of the HIP path): `on` is False (plain fp32),
+    True / "bf16" (the bf16 build) or "fp16" (the fp16 build selected by `.to(dtype=torch.float16)`,
+    train_diffute_v1.py:789-797, BASELINE configs[4])."""
+    if not on:
+        return x
+    return x.to(torch.float16 if on == "fp16" else torch.bfloat16).to(torch.float32)
 
 
 def timestep_embedding(t, dim):

@@ -744,51 +744,6 @@ def test_cfg1_fp32_validation_path(cuda):
     print(f"cfg1 on the fp32 validation path: eps0 rel-L2 {e0:.2e}, final latents {e1:.2e}")
 
 
-def _profiled_launches(fn):
-    """(result, launches per profile class) of one call - the same per-launch bracket bench.py reads"""
-    import ctypes
-    from diffute_amd import _cabi
-    lib = _cabi.lib()
-    torch.cuda.synchronize()
-    lib.dmx_profile_begin()
-    out = fn()
-    buf = (ctypes.c_double * (4 * 25))()
-    _cabi.check(lib.dmx_profile_end(buf, len(buf)), "profile_end")
-    return out, [int(buf[4 * i]) for i in range(25)]
-
-
-def test_deferred_splitk_reduce_is_bit_identical(cuda, tiny_unet, tiny_vae, monkeypatch):
-    """The GroupNorm slab kernel reduces the fp32 partials of the split-K convolution that feeds it (Exec::groupnorm);
-    DMX_DEFER_REDUCE=1 selects that schedule (off by default: measured not to pay at cfg1).  Same arithmetic
-    in the same order: the UNet and VAE outputs are bit-identical, with fewer reduce launches and the same number of
-    GroupNorm launches."""
-    import diffute_amd as D
-    from diffute_amd.synthetic import synth_inputs, synth_images
-    SPLITK, GNORM = 2, 4                                  # ProfClass ids (csrc/kernels.h)
-    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, 128, device=cuda)
-    t = torch.tensor([981, 3], device=cuda)
-    img = synth_images(2, 64, 64, device=cuda)
-
-    def run(unet, vae):
-        with torch.no_grad():
-            unet.set_context(ctx)
-            (eps, n_u) = _profiled_launches(lambda: unet.forward_parts([lat, mask, mlat], t))
-            (mom, n_v) = _profiled_launches(lambda: vae.encode(img).latent_dist.parameters)
-        return eps, mom, n_u, n_v
-
-    eps2, mom2, nu2, nv2 = run(tiny_unet, tiny_vae)
-    monkeypatch.setenv("DMX_DEFER_REDUCE", "1")
-    # fresh instances: the first ones hold workspace sizes computed for the default schedule
-    u1 = D.UNet2DConditionModel(**TINY_UNET).cuda().requires_grad_(False); u1.load_state_dict(tiny_unet.state_dict())
-    v1 = D.AutoencoderKL(**TINY_VAE).cuda().requires_grad_(False); v1.load_state_dict(tiny_vae.state_dict())
-    eps1, mom1, nu1, nv1 = run(u1, v1)
-    assert torch.equal(eps1, eps2) and torch.equal(mom1, mom2)
-    print(f"tiny unet: reduce launches {nu1[SPLITK]} (deferred) vs {nu2[SPLITK]}, groupnorm {nu1[GNORM]} vs {nu2[GNORM]}; "
-          f"tiny vae encoder: {nv1[SPLITK]} vs {nv2[SPLITK]}")
-    assert nu1[GNORM] == nu2[GNORM] and nu1[SPLITK] < nu2[SPLITK]
-    assert nv1[SPLITK] <= nv2[SPLITK]
-
-
 def test_tiny_vae_fp32_validation_path(cuda, tiny_vae):
     """north_star's "within 1e-3 rel fp32" at model level for the autoencoder: the fp32 instantiation of the encode / decode
     graphs (fp32 activations, fp32 master weights, plain FMA kernels; AutoencoderKL.encode_fp32 / decode_fp32) against

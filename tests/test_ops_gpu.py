@@ -62,7 +62,7 @@ def test_conv(cuda, case):
     assert_close(nchw(out), ref, TOL, name)
 
 
-@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (4, 1), (5, 1), (6, 1), (6, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2), (11, 1), (11, 2), (12, 1), (12, 2)])
+@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2), (11, 1), (11, 2), (12, 1), (12, 2)])
 def test_conv_every_tile_config(cuda, tn, sk):
     """All three tile configurations (128x64, 128x128, 256x128) and split-K give the same conv + epilogue."""
     from diffute_amd import ops
@@ -165,7 +165,7 @@ def test_geglu(cuda):
     assert_close(out, ref, TOL, "geglu")
     # every tile instance with a GEGLU epilogue, incl. the 128x320 tile (5 whole packed groups, here with an N tail: 1024 = 3.2 tiles)
     x4 = x.to(cuda).to(torch.bfloat16).reshape(1, 1, M, C)
-    for tn in (1, 2, 3, 4, 7, 8, 9, 10, 12):
+    for tn in (1, 2, 3, 7, 8, 9, 10, 12):
         o = ops.conv_gemm(x4, ops.pack_linear_weight(w.to(cuda), geglu=True), 8 * C, ksize=1, pad=0, bias=ops.pack_geglu_bias(b.to(cuda)), geglu=True, force_tn=tn)
         assert_close(o.reshape(M, 4 * C), ref, TOL, f"geglu, tile instance {tn}")
 
@@ -265,80 +265,6 @@ def test_time_embedding(cuda):
     w = bf(seeded((1280, 320), 1, 1 / math.sqrt(320))); b = seeded((1280,), 2, 0.1)
     y = ops.linear_small(out, w.to(cuda).to(torch.bfloat16), b.to(cuda), silu_in=True)
     assert_close(y, F.linear(F.silu(ref), w, b), 1e-4, "linear_small")
-
-
-# ------------------------------------------------------------------------------------------------ persistent linear kernel (lin.hip)
-# (name, M, K, N): single-tile-per-block grids, persistent multi-tile grids (> 256 tiles), M / N tails, every instance
-LINK_CASES = [("k_eq_c_64", 16384, 320, 320), ("k_eq_c_16", 1024, 1280, 1280), ("tails", 577, 1024, 1000), ("tiny", 40, 64, 72),
-              ("persistent", 16384, 320, 2560), ("ff2", 4096, 2560, 640)]
-
-
-@pytest.mark.parametrize("case", LINK_CASES, ids=[c[0] for c in LINK_CASES])
-@pytest.mark.parametrize("tn", [13, 14, 15])
-def test_lin_kernel_bias_residual_rowstats(cuda, case, tn):
-    """K7 on the persistent kernel: out = x W^T + b + res (bf16) and the per-row (sum, sumsq) partials of the rounded output
-    that feed a following folded LayerNorm, for each tile instance (force_tn 13 = 128x160, 14 = 128x64, 15 = 128x256)."""
-    from diffute_amd import ops
-    name, M, K, N = case
-    x = bf(seeded((M, K), 1)); w = bf(seeded((N, K), 2, 1 / math.sqrt(K))); b = seeded((N,), 3, 0.1); r = bf(seeded((M, N), 4))
-    ref = bf(F.linear(x, w, b) + r)
-    xc = x.to(cuda).to(torch.bfloat16); wc = ops.pack_linear_weight(w.to(cuda))
-    out, st = ops.linear(xc, wc, bias=b.to(cuda), res=r.to(cuda).to(torch.bfloat16), force_tn=tn, rowstats=True)
-    assert_close(out, ref, TOL, f"{name} tn={tn}")
-    o32 = out.float().cpu()
-    s = st.sum(0).cpu()                                      # fold the partials
-    assert torch.allclose(s[:, 0], o32.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(s[:, 1], (o32 * o32).sum(1), rtol=1e-4, atol=1e-2), "row statistics"
-    out2 = ops.linear(xc, wc, force_tn=tn)                   # no bias, no residual
-    assert_close(out2, bf(F.linear(x, w)), TOL, f"{name} tn={tn} plain")
-    assert torch.equal(ops.linear(xc, wc, force_tn=tn), out2), "not deterministic"
-
-
-@pytest.mark.parametrize("tn", [13, 14, 15])
-def test_lin_kernel_folded_layernorm_and_gelu(cuda, tn):
-    """the consumer side of the folded LayerNorm: y = LN(h) W^T + b computed as rstd*(h W'^T - mean*c1) + c2 from the
-    producer's partial row sums; and the exact-GELU epilogue of the ViT MLP"""
-    from diffute_amd import ops
-    M, C, N = 1000, 320, 960
-    h = bf(seeded((M, C), 5)); g = 1 + 0.1 * seeded((C,), 6); be = 0.1 * seeded((C,), 7)
-    w = bf(seeded((N, C), 8, 1 / math.sqrt(C))); b = seeded((N,), 9, 0.1)
-    ref = bf(F.linear(F.layer_norm(h, (C,), g, be, 1e-5), w, b))
-    wp = bf(w * g)                                            # W' = W diag(gamma), rounded as the fold kernel does
-    c1 = wp.sum(1); c2 = (w * be).sum(1) + b
-    # producer partials: any GEMM whose rounded output is h; here an identity-free shortcut: build them on the host in 3 slices
-    parts = torch.stack([torch.stack([h[:, i::3].sum(1), (h[:, i::3] ** 2).sum(1)], 1) for i in range(3)], 0)
-    out = ops.linear(h.to(cuda).to(torch.bfloat16), ops.pack_linear_weight(wp.to(cuda)), force_tn=tn,
-                     ln=(parts.to(cuda).contiguous(), c1.to(cuda), c2.to(cuda), 1e-5))
-    mean = h.mean(1, keepdim=True); rstd = torch.rsqrt(h.var(1, unbiased=False, keepdim=True) + 1e-5)
-    same = bf(rstd * (F.linear(h, wp) - mean * c1) + c2)      # the same algebra in fp32 on the same rounded W'
-    assert_close(out, same, TOL, f"folded LayerNorm consumer tn={tn} vs the folded formula")
-    assert_close(out, ref, 4e-3, f"folded LayerNorm consumer tn={tn} vs LayerNorm + Linear")   # W' = bf16(W*gamma): one more rounding than W
-    x = bf(seeded((M, C), 1))
-    outg = ops.linear(x.to(cuda).to(torch.bfloat16), ops.pack_linear_weight(w.to(cuda)), bias=b.to(cuda), act=1, force_tn=tn)
-    assert_close(outg, bf(F.gelu(F.linear(x, w, b))), TOL, f"gelu epilogue tn={tn}")
-
-
-def test_lin_kernel_geglu(cuda):
-    """K8 on the 8-wave instance: packed (a | gate) 64-column groups -> a * gelu(gate), with and without the folded
-    LayerNorm, single-tile and persistent grids, M tail"""
-    from diffute_amd import ops
-    for (M, C) in ((384, 128), (16384, 320), (1000, 640)):
-        x = bf(seeded((M, C), 1)); w = bf(seeded((8 * C, C), 2, 1 / math.sqrt(C))); b = seeded((8 * C,), 3, 0.1)
-        gg = F.linear(x, w, b); a, gate = gg.chunk(2, dim=-1)
-        ref = bf(a * F.gelu(gate))
-        xc = x.to(cuda).to(torch.bfloat16)
-        out = ops.linear(xc, ops.pack_linear_weight(w.to(cuda), geglu=True), bias=ops.pack_geglu_bias(b.to(cuda)), geglu=True, force_tn=15)
-        assert_close(out, ref, TOL, f"lin geglu M={M} C={C}")
-        # folded LayerNorm in front (norm3 -> ff.net.0.proj)
-        g = 1 + 0.1 * seeded((C,), 6); be = 0.1 * seeded((C,), 7)
-        gl = F.linear(F.layer_norm(x, (C,), g, be, 1e-5), w, b); a2, gate2 = gl.chunk(2, dim=-1)
-        wp = bf(w * g); c1 = wp.sum(1); c2 = (w * be).sum(1) + b
-        parts = torch.stack([x.sum(1), (x * x).sum(1)], 1)[None]
-        out2 = ops.linear(xc, ops.pack_linear_weight(wp.to(cuda), geglu=True), geglu=True, force_tn=15,
-                          ln=(parts.to(cuda).contiguous(), ops.pack_geglu_bias(c1.to(cuda)), ops.pack_geglu_bias(c2.to(cuda)), 1e-5))
-        assert_close(out2, bf(a2 * F.gelu(gate2)), 4e-3, f"lin geglu + folded LayerNorm M={M} C={C}")
-        mean = x.mean(1, keepdim=True); rstd = torch.rsqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
-        gs = rstd * (F.linear(x, wp) - mean * c1) + c2; a3, gate3 = gs.chunk(2, dim=-1)
-        assert_close(out2, bf(a3 * F.gelu(gate3)), TOL, f"lin geglu + folded LayerNorm vs the folded formula M={M} C={C}")
 
 
 @pytest.mark.parametrize("shape", ["rising", "falling", "huge", "ragged_rising"])
