@@ -228,8 +228,7 @@ __global__ __launch_bounds__(256, 1) void dmx_attn_wide_kernel(const AttnWideArg
 template <int D>
 static int launch_wide(const AttnWideArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * 2 * 32 * D * 2;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attn_wide_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  DMX_LDS_OPT_IN((dmx_attn_wide_kernel<D>), lds);
   hipLaunchKernelGGL((dmx_attn_wide_kernel<D>), dim3(cdiv(a.Sq, 128), a.B), dim3(256), lds, stream, a);
   return dmx_check_launch("dmx_attn_wide_kernel");
 }

@@ -85,5 +85,16 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + erf_v);
 }
 
+// dynamic-LDS opt-in above 64 KB: a per-DEVICE function attribute, so it is set once per (kernel, device), result checked
+#define DMX_LDS_OPT_IN(kernel, bytes)                                                                        \
+  do {                                                                                                       \
+    static bool dmx_attr_[64] = {};                                                                          \
+    int dmx_dev_ = 0; DMX_HIP(hipGetDevice(&dmx_dev_));                                                      \
+    if (dmx_dev_ >= 64 || !dmx_attr_[dmx_dev_ & 63]) {                                                       \
+      DMX_HIP(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      dmx_attr_[dmx_dev_ & 63] = true;                                                                       \
+    }                                                                                                        \
+  } while (0)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -973,8 +973,9 @@ static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
   if (lds_epi > lds) lds = lds_epi;
   if (a.ln_stats || TN == 5) lds += (size_t)BM * 2 * sizeof(float);    // (mean, rstd) per row of the folded LayerNorm
   if (TN == 5) lds += (size_t)3 * BN * sizeof(float);                  // the tile's column vectors (160 / 320-column epilogue)
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr = true; }
+  static bool attr[64] = {};                          // the dynamic-LDS opt-in is per device
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr[dev] = true; }
   hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN>), grid, dim3(64 * (NWN * WM + NP)), lds, stream, a);
 }
 

@@ -359,8 +359,7 @@ int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream) {
   a.nchunk = cdiv(a.HW, rpc);
   a.coef = (float*)((char*)a.partial + (size_t)a.B * GN_MAX_CHUNKS * a.groups * 2 * sizeof(float));
   const size_t lds_stats = (size_t)(2 * R * a.C + 2 * a.C) * sizeof(float);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gn_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+  DMX_LDS_OPT_IN((dmx_gn_stats_kernel), 128 * 1024);
   hipLaunchKernelGGL(dmx_gn_stats_kernel, dim3(a.nchunk, a.B), dim3(threads), lds_stats, stream, a);
   int rc = dmx_check_launch("dmx_gn_stats_kernel");
   if (rc) return rc;

@@ -318,8 +318,7 @@ int dmx_groupnorm_bwd_launch(GroupNormBwdArgs a, hipStream_t stream) {
   a.ab = a.part + (size_t)a.B * nchunk * a.C * 2;
   const int threads = (a.C / 8) * R;
   const size_t lds = (size_t)2 * R * a.C * sizeof(float);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_gn_bwd_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  DMX_LDS_OPT_IN((dmx_gn_bwd_reduce_kernel), 160 * 1024);
   ProfScope ps(PROF_GNORM, stream, 0.0, 10.0 * a.B * (double)a.HW * a.C, "gn_bwd");
   hipLaunchKernelGGL(dmx_gn_bwd_reduce_kernel, dim3(nchunk, a.B), dim3(threads), lds, stream, a);
   int rc = dmx_check_launch("dmx_gn_bwd_reduce_kernel");

@@ -210,8 +210,7 @@ static int attention_f32_launch_d(const float* q, int ldq, const float* k, int l
                                   int B, int H, int Sq, int Skv, float scale, hipStream_t stream) {
   const size_t lds = (size_t)(16 * D + 16 * Skv) * sizeof(float);
   DMX_REQUIRE(lds <= 150 * 1024, "attention_f32: Skv=%d too long for the validation kernel (scores of 16 queries live in LDS)", Skv);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dmx_attention_f32_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+  DMX_LDS_OPT_IN((dmx_attention_f32_kernel<D>), 150 * 1024);
   hipLaunchKernelGGL((dmx_attention_f32_kernel<D>), dim3(cdiv(Sq, 16), H, B), dim3(256), lds, stream, q, ldq, k, ldk, v, ldv, kv_rows, o, ldo, H, Sq, Skv, scale);
   return dmx_check_launch("dmx_attention_f32_kernel");
 }

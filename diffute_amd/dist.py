@@ -124,10 +124,20 @@ def reduce_buckets(flat, plan, dist, group=None, wait_bucket=None, average_by=No
                     tail.div_(average_by)
 
 
-def broadcast_parameters(params, dist, src=0, group=None):
-    """D3 (accelerator.prepare, train_diffute_v1.py:780): every rank starts from rank `src`'s parameters."""
-    for p in params:
-        dist.broadcast(p.data, src=src, group=group)
+def broadcast_parameters(params, dist, src=0, group=None, module=None):
+    """D3 (accelerator.prepare, train_diffute_v1.py:780): every rank starts from rank `src`'s parameters.
+
+    The broadcast writes the Parameter itself under no_grad (an in-place write that bumps `p._version`), not `p.data`:
+    writes through `.data` are invisible to the packed-arena change detection of the HIP models (their version counter is
+    detached), so a broadcast after the first forward / after FusedAdamW(unet) would leave the arena and the fp32 masters
+    on the old weights.  Pass `module=` (or call `module.mark_parameters_changed()` yourself) to force the re-pack whatever
+    the backend does to the version counter."""
+    params = list(params)
+    with torch.no_grad():
+        for p in params:
+            dist.broadcast(p, src=src, group=group)
+    if module is not None and hasattr(module, "mark_parameters_changed"):
+        module.mark_parameters_changed()
 
 
 def gather_scalar(value, dist, world, device=None):

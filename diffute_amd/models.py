@@ -183,6 +183,15 @@ class _HipModel(nn.Module):
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def mark_parameters_changed(self):
+        """Tell the model its Parameters were rewritten in a way torch does not record.  The packed weights arena (and a
+        fused optimizer's fp32 masters) follow the Parameters through (data_ptr, _version); an in-place write through
+        `p.data` (`p.data.copy_(...)`, diffusers' `EMAModel.copy_to`, `dist.broadcast(p.data)`) bumps neither, so the next
+        forward would still run the old weights.  After such a write call this once; the next forward re-packs the arena and
+        re-imports the masters.  Writes on the Parameter itself under `torch.no_grad()`, `load_state_dict`, `.to()` and
+        optimizer steps are detected without it."""
+        self._packed_sig = None
+
     def _ensure_packed(self):
         dev = self.device
         if dev.type != "cuda":
@@ -205,8 +214,8 @@ class _HipModel(nn.Module):
         self._finalize(st)
         self._packed_sig = sig
         fused = getattr(self, "_fused", None)
-        if fused is not None:                        # the Parameters changed under a fused optimizer (load_state_dict,
-            fused.reimport_masters()                 # broadcast_parameters, ...): they are the new master copy
+        if fused is not None:                        # the Parameters changed under a fused optimizer (load_state_dict, an in-place
+            fused.reimport_masters()                 # write under no_grad, mark_parameters_changed()): they are the new master copy
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != self.device:
@@ -656,6 +665,10 @@ class AutoencoderKL(_HipModel):
                 if any(b != want for b in cfg[k]) or len(cfg[k]) != len(cfg["block_out_channels"]):
                     raise NotImplementedError(f"AutoencoderKL: {k}={cfg[k]!r} is not implemented (only {want!r} per level)")
         cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
+        if cfg["block_out_channels"][-1] not in (128, 256, 512):
+            # the fused single-head attention of the mid block (attention_wide.hip) is built for head widths 128 / 256 / 512
+            raise NotImplementedError(f"AutoencoderKL: mid-block width block_out_channels[-1]={cfg['block_out_channels'][-1]} "
+                                      "is not implemented (only 128, 256 or 512)")
         self.config = _Config(**cfg)
         c = _cabi.VAEConfig()
         c.in_channels = cfg["in_channels"]; c.out_channels = cfg["out_channels"]; c.latent_channels = cfg["latent_channels"]

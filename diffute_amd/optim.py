@@ -151,7 +151,10 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW.load_state_dict: arena size mismatch (different UNet config)")
         self.t = int(st["step"])
         self.masters.copy_(st["masters"]); self.exp_avg.copy_(st["exp_avg"]); self.exp_avg_sq.copy_(st["exp_avg_sq"])
-        if self.ema is not None and "ema" in st:
+        if self.ema is not None:
+            if "ema" not in st:
+                raise ValueError("FusedAdamW.load_state_dict: this optimizer keeps an EMA shadow (ema_decay=...) but the checkpoint "
+                                 "has no 'ema' entry; load it into an optimizer built without ema_decay, or re-create the shadow")
             self.ema.copy_(st["ema"])
         for g, src in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in src.items() if k != "params"})

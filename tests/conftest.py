@@ -1,5 +1,7 @@
 import os
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -7,9 +9,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+D1_WORLD2 = {"procs": None, "prefix": None}
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """The world-2 gradient-exchange check (tests/test_dist_gpu.py) needs two more processes on the GPU.  They are started
+    HERE, before anything in this process has initialised HIP: a process that has touched the GPU must not fork + exec on
+    the GPU pool.  (`device_count()` does not initialise the device; `is_available()` would.)"""
+    expr = session.config.getoption("markexpr", "") or ""
+    if "gpu" not in expr or "not gpu" in expr:
+        return
+    import torch
+    if torch.cuda.device_count() < 1:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    prefix = os.path.join(tempfile.mkdtemp(prefix="d1_world2_"), "res")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "d1_world2_worker.py")
+    D1_WORLD2["procs"] = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), prefix], env=env,
+                                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for r in range(2)]
+    D1_WORLD2["prefix"] = prefix
+
+
+def pytest_sessionfinish(session, exitstatus):
+    for p in D1_WORLD2["procs"] or []:
+        if p.poll() is None:
+            p.kill()
 
 
 @pytest.fixture(scope="session")
