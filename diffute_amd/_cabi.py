@@ -8,8 +8,12 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
 
 # DIFFUTE_HIP_LIB: A/B builds of the same library (kernel experiments); the default is the in-tree build
-_LIB_PATH = os.environ.get("DIFFUTE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffute_hip.so")
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+_LIB_PATH = os.environ.get("DIFFUTE_HIP_LIB") or os.path.join(_LIB_DIR, "libdiffute_hip.so")
+# the same sources compiled with -DDMX_F16: fp16 storage / MFMA operands (BASELINE configs[4]; `.to(dtype=torch.float16)`)
+_LIB_PATH_F16 = os.environ.get("DIFFUTE_HIP_LIB_F16") or os.path.join(_LIB_DIR, "libdiffute_hip_f16.so")
 _lib = None
+_lib_f16 = None
 
 
 class GemmDesc(ctypes.Structure):
@@ -47,6 +51,7 @@ _P = c_void_p
 _PROTOS = {
     "dmx_version": (c_int, []),
     "dmx_last_error": (c_char_p, []),
+    "dmx_element_type": (c_char_p, []),
     "dmx_conv_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "dmx_conv_gemm": (c_int, [POINTER(GemmDesc), _P, c_size_t, _P]),
     "dmx_conv_gemm_rowstats_tiles": (c_int, [POINTER(GemmDesc)]),
@@ -182,31 +187,59 @@ def lib_path():
     return _LIB_PATH
 
 
-def lib():
-    """Load (once) and return the C-ABI library; raises if it has not been built."""
-    global _lib
+def _load(path, want_elem):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"diffute_amd: HIP extension not built ({path} missing). "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C diffute_amd/csrc`. "
+            "There is no CPU fallback.")
+    l = ctypes.CDLL(path)                  # RTLD_LOCAL: the two builds export the same names and must not see each other
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(l, name)              # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = l.dmx_element_type().decode()
+    if got != want_elem:
+        raise RuntimeError(f"diffute_amd: {path} computes in {got}, expected the {want_elem} build")
+    return l
+
+
+def lib(elem="bf16"):
+    """Load (once) and return the C-ABI library - the bf16 build, or with elem="fp16" the fp16 build of the same sources;
+    raises if it has not been built."""
+    global _lib, _lib_f16
+    if elem == "fp16":
+        if _lib_f16 is None:
+            _lib_f16 = _load(_LIB_PATH_F16, "fp16")
+        return _lib_f16
+    if elem != "bf16":
+        raise ValueError(f"diffute_amd: no build for element type {elem!r}")
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise RuntimeError(
-                f"diffute_amd: HIP extension not built ({_LIB_PATH} missing). "
-                "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C diffute_amd/csrc`. "
-                "There is no CPU fallback.")
-        l = ctypes.CDLL(_LIB_PATH)
-        for name, (res, args) in _PROTOS.items():
-            fn = getattr(l, name)          # AttributeError if the .so lacks a declared symbol
-            fn.restype = res
-            fn.argtypes = args
-        _lib = l
+        _lib = _load(_LIB_PATH, "bf16")
     return _lib
+
+
+def elem_of(dtype):
+    """torch dtype a model was moved to -> the build that computes it: float16 -> "fp16"; float32 / bfloat16 -> "bf16"
+    (fp32 requests are served by the bf16 build: master parameters stay fp32, compute is bf16 MFMA, fp32 accumulation)."""
+    import torch
+    return "fp16" if dtype == torch.float16 else "bf16"
+
+
+def torch_elem(elem):
+    import torch
+    return torch.float16 if elem == "fp16" else torch.bfloat16
 
 
 def exported_symbols():
     return sorted(_PROTOS.keys())
 
 
-def check(rc, what=""):
+def check(rc, what="", l=None):
     if rc != 0:
-        msg = lib().dmx_last_error()
+        msg = (l or lib()).dmx_last_error()
+        if not msg and _lib_f16 is not None and l is None:
+            msg = _lib_f16.dmx_last_error()
         raise RuntimeError(f"diffute_amd: {what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 

@@ -6,6 +6,7 @@ const char* dmx_get_error();
 
 extern "C" int dmx_version(void) { return 100; }
 extern "C" const char* dmx_last_error(void) { return dmx_get_error(); }
+extern "C" const char* dmx_element_type(void) { return DMX_ELEM_NAME; }
 
 static GemmArgs to_args(const dmx_gemm_desc* d) {
   GemmArgs a{};

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
 #pragma unroll
           for (int j = 0; j < R; ++j) {
             if (PROBE & 8) { if (kk == 0) { s[j][kt] = zero; s[j][kt][0] = __builtin_bit_cast(float, (int)kf[kt][0][0] + (int)kf[kt][1][1] + (int)kf[kt][2][2] + (int)kf[kt][3][3]) * 1e-30f; } }
-            else s[j][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][kk], qf[j][kk], kk == 0 ? zero : s[j][kt], 0, 0, 0);
+            else s[j][kt] = DMX_MFMA_32x32x16(kf[kt][kk], qf[j][kk], kk == 0 ? zero : s[j][kt]);
           }
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // all eight fragment reads first ...
       __builtin_amdgcn_sched_group_barrier(0x008, 8 * R, 0);         // ... then the MFMAs in the order written
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
 #pragma unroll
           for (int j = 0; j < R; ++j) {
             if (PROBE & 16) { o[j][dt][s4] += __builtin_bit_cast(float, (int)vv[0] + (int)vv[5]) * 1e-30f + __builtin_bit_cast(float, (int)pf[j][s4][0] + (int)pf[j][s4][7]) * 1e-30f; }
-            else o[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j][s4], o[j][dt], 0, 0, 0);
+            else o[j][dt] = DMX_MFMA_32x32x16(__builtin_bit_cast(bf16x8, vv), pf[j][s4], o[j][dt]);
           }
         }
     } else {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
           const u32x2 hi = *(const u32x2*)(vp + 16);
           const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
-          for (int j = 0; j < R; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j][s4], o[j][dt], 0, 0, 0);
+          for (int j = 0; j < R; ++j) o[j][dt] = DMX_MFMA_32x32x16(__builtin_bit_cast(bf16x8, vv), pf[j][s4], o[j][dt]);
         }
     }
 

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_bwd_dq_kernel(const AttnBwdAr
       for (int kk = 0; kk < 4; ++kk) {
         const bf16x8 kf = *(const bf16x8*)(ks + (32 * c + lr) * (KROW * 2) + (2 * kk + lh) * 16);
         const bf16x8 vf = *(const bf16x8*)(vs + (32 * c + lr) * (KROW * 2) + (2 * kk + lh) * 16);
-        s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[c], 0, 0, 0);
-        dp[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp[c], 0, 0, 0);
+        s[c] = DMX_MFMA_32x32x16(kf, qf[kk], s[c]);
+        dp[c] = DMX_MFMA_32x32x16(vf, dof[kk], dp[c]);
       }
     }
     bf16x8 pf[4];
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_bwd_dq_kernel(const AttnBwdAr
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        dq[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_from_tr(v0[2 * s4], v0[2 * s4 + 1]), pf[s4], dq[0], 0, 0, 0);
-        dq[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_from_tr(v1[2 * s4], v1[2 * s4 + 1]), pf[s4], dq[1], 0, 0, 0);
+        dq[0] = DMX_MFMA_32x32x16(frag_from_tr(v0[2 * s4], v0[2 * s4 + 1]), pf[s4], dq[0]);
+        dq[1] = DMX_MFMA_32x32x16(frag_from_tr(v1[2 * s4], v1[2 * s4 + 1]), pf[s4], dq[1]);
       }
     }
     if (it + 1 < ntiles) write_tile((it + 1) & 1);
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_bwd_dkv_kernel(const AttnBwdA
     for (int kk = 0; kk < 4; ++kk) {
       const bf16x8 qa = *(const bf16x8*)(st + KV_QD + lr * (KROW * 2) + (2 * kk + lh) * 16);
       const bf16x8 da = *(const bf16x8*)(st + KV_DD + lr * (KROW * 2) + (2 * kk + lh) * 16);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);
+      s = DMX_MFMA_32x32x16(qa, kf[kk], s);
+      dp = DMX_MFMA_32x32x16(da, vf[kk], dp);
     }
     float pr[16], ds[16];
     const float* ls = (const float*)(st + KV_LS);
@@ -287,10 +287,10 @@ __global__ __launch_bounds__(256, 2) void dmx_attn_bwd_dkv_kernel(const AttnBwdA
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_from_tr(d0[2 * ks], d0[2 * ks + 1]), pfp[ks], dv[0], 0, 0, 0);
-        dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_from_tr(d1[2 * ks], d1[2 * ks + 1]), pfp[ks], dv[1], 0, 0, 0);
-        dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_from_tr(q0v[2 * ks], q0v[2 * ks + 1]), pfs[ks], dk[0], 0, 0, 0);
-        dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_from_tr(q1v[2 * ks], q1v[2 * ks + 1]), pfs[ks], dk[1], 0, 0, 0);
+        dv[0] = DMX_MFMA_32x32x16(frag_from_tr(d0[2 * ks], d0[2 * ks + 1]), pfp[ks], dv[0]);
+        dv[1] = DMX_MFMA_32x32x16(frag_from_tr(d1[2 * ks], d1[2 * ks + 1]), pfp[ks], dv[1]);
+        dk[0] = DMX_MFMA_32x32x16(frag_from_tr(q0v[2 * ks], q0v[2 * ks + 1]), pfs[ks], dk[0]);
+        dk[1] = DMX_MFMA_32x32x16(frag_from_tr(q1v[2 * ks], q1v[2 * ks + 1]), pfs[ks], dk[1]);
       }
     }
     if (it + 1 < ntiles) write_tile((it + 1) & 1);

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256, 1) void dmx_attn_wide_kernel(const AttnWideArg
         }
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
-          s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st & 1][j], qf[4 * st + j], (st == 0 && j == 0) ? zero : s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st & 1][j + 1], qf[4 * st + j + 1], (st == 0 && j == 0) ? zero : s1, 0, 0, 0);
+          s0 = DMX_MFMA_32x32x16(kf[st & 1][j], qf[4 * st + j], (st == 0 && j == 0) ? zero : s0);
+          s1 = DMX_MFMA_32x32x16(kf[st & 1][j + 1], qf[4 * st + j + 1], (st == 0 && j == 0) ? zero : s1);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void dmx_attn_wide_kernel(const AttnWideArg
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int dt = 2 * st + (j >> 1);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][j], pf[j & 1], o[dt], 0, 0, 0);
+          o[dt] = DMX_MFMA_32x32x16(vf[st & 1][j], pf[j & 1], o[dt]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -3,9 +3,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// The 16-bit storage / MFMA-operand element of this build.  The library is compiled twice from the same sources:
+//   libdiffute_hip.so      bf16  (default; `bf16` = __bf16, v_mfma_f32_32x32x16_bf16)
+//   libdiffute_hip_f16.so  fp16  (-DDMX_F16; `bf16` = _Float16, v_mfma_f32_32x32x16_f16) - what `.to(dtype=torch.float16)`
+//                          selects (train_diffute_v1.py:789-797, BASELINE configs[4]).
+// Throughout the sources the identifier `bf16` therefore means "the build's 16-bit element"; everything that depends on
+// its bit layout goes through the helpers below (DMX_MFMA_*, pack_bf2 / unpack_bf8 / h2f_lo / h2f_hi / f2bf_bits / bf_bits2f).
+// LDS images, fragment layouts and transpose reads are identical for both (16-bit lanes); accumulation is fp32 in both.
+#ifdef DMX_F16
+typedef _Float16 dmx_h16;
+#define DMX_ELEM_NAME "fp16"
+#define DMX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define DMX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
+typedef __bf16 dmx_h16;
+#define DMX_ELEM_NAME "bf16"
+#define DMX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define DMX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
+typedef dmx_h16 bf16;
+typedef __attribute__((ext_vector_type(8))) dmx_h16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) dmx_h16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -37,29 +55,38 @@ int dmx_check_launch(const char* what);
     }                                                                        \
   } while (0)
 
-// fp32 -> bf16, round-to-nearest-even: native casts so hipcc emits gfx950's v_cvt_pk_bf16_f32 (one instruction per
-// pair) instead of a ~7-op integer sequence per value.
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// fp32 -> 16-bit element, round-to-nearest-even: native casts so hipcc emits gfx950's v_cvt_pk_bf16_f32 (one instruction
+// per pair; v_cvt_f16_f32 + v_pack in the fp16 build) instead of a ~7-op integer sequence per value.
+typedef __attribute__((ext_vector_type(2))) dmx_h16 bf16x2;
 __device__ __forceinline__ unsigned short f2bf_bits(float f) {
-  const __bf16 h = (__bf16)f;
+  const dmx_h16 h = (dmx_h16)f;
   return __builtin_bit_cast(unsigned short, h);
 }
+#ifdef DMX_F16
+__device__ __forceinline__ float bf_bits2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+// the two elements of a packed dword (low / high half) as floats
+__device__ __forceinline__ float h2f_lo(unsigned int w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float h2f_hi(unsigned int w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+#else
 __device__ __forceinline__ float bf_bits2f(unsigned short b) {
   return __uint_as_float(((unsigned int)b) << 16);
 }
+__device__ __forceinline__ float h2f_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h2f_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
 // value of the lane N positions below within the 16-lane DPP row (0 for the first N lanes of a row)
 template <int N> __device__ __forceinline__ float dpp_row_shr(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
 }
 __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
-  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  const bf16x2 v = {(dmx_h16)lo, (dmx_h16)hi};
   return __builtin_bit_cast(unsigned int, v);
 }
 __device__ __forceinline__ void unpack_bf8(const u32x4 v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __uint_as_float(v[i] << 16);
-    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    f[2 * i] = h2f_lo(v[i]);
+    f[2 * i + 1] = h2f_hi(v[i]);
   }
 }
 __device__ __forceinline__ u32x4 pack_bf8(const float* f) {

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][a], xf[cur][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = DMX_MFMA_32x32x16(wf[cur][a], xf[cur][b], acc[a][b]);
         // pin the issue order the scheduler would otherwise undo: [ds_reads of k-step kk+1] then [MFMAs of kk]
         if (kk + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = DMX_MFMA_32x32x16(wf[a], xf[b], acc[a][b]);
       }
     }
   };
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][a], xf[buf][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = DMX_MFMA_32x32x16(wf[buf][a], xf[buf][b], acc[a][b]);
       };
 #define DMX_SB __builtin_amdgcn_sched_barrier(0)
       // one scheduling region = [TM+TN ds_reads of the next fragment set] interleaved, two per gap, behind the first
@@ -811,8 +811,8 @@ __global__ __launch_bounds__(256) void dmx_splitk_reduce_kernel(const GemmArgs p
   for (; k < p.splitk; ++k) s += *(const f32x4*)(q + (size_t)k * MN);
   float v[4] = {s[0] + bv[0] + rb[0], s[1] + bv[1] + rb[1], s[2] + bv[2] + rb[2], s[3] + bv[3] + rb[3]};
   if (p.res) {
-    v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
-    v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+    v[0] += h2f_lo(rv[0]); v[1] += h2f_hi(rv[0]);
+    v[2] += h2f_lo(rv[1]); v[3] += h2f_hi(rv[1]);
   }
   if (p.out_f32) {
     f32x4 o = {v[0], v[1], v[2], v[3]};

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const unsigned int w = gn_dw<VEC>(v[k], i);
-      u += __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
+      u += h2f_lo(w) + h2f_hi(w);
     }
     s += ok ? u : 0.f;
   }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const unsigned int w = gn_dw<VEC>(v[k], i);
-      const float d0 = __uint_as_float(w << 16) - mean, d1 = __uint_as_float(w & 0xffff0000u) - mean;
+      const float d0 = h2f_lo(w) - mean, d1 = h2f_hi(w) - mean;
       u += d0 * d0 + d1 * d1;
     }
     q += ok ? u : 0.f;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const unsigned int w = gn_dw<VEC>(v[k], i);
-        const float x0 = __uint_as_float(w << 16), x1 = __uint_as_float(w & 0xffff0000u);
+        const float x0 = h2f_lo(w), x1 = h2f_hi(w);
         float y0 = __builtin_fmaf(x0, A[2 * i], Bv[2 * i]);
         float y1 = __builtin_fmaf(x1, A[2 * i + 1], Bv[2 * i + 1]);
         if (SILU) {

@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void dmx_wgrad_kernel(const WgradArgs p) {
       const u32x4 av = {(unsigned)xv[2 * ks], (unsigned)(xv[2 * ks] >> 32), (unsigned)xv[2 * ks + 1], (unsigned)(xv[2 * ks + 1] >> 32)};
       const u32x4 b0 = {(unsigned)d0[2 * ks], (unsigned)(d0[2 * ks] >> 32), (unsigned)d0[2 * ks + 1], (unsigned)(d0[2 * ks + 1] >> 32)};
       const u32x4 b1 = {(unsigned)d1[2 * ks], (unsigned)(d1[2 * ks] >> 32), (unsigned)d1[2 * ks + 1], (unsigned)(d1[2 * ks + 1] >> 32)};
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b0), acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b1), acc[1], 0, 0, 0);
+      acc[0] = DMX_MFMA_32x32x16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b0), acc[0]);
+      acc[1] = DMX_MFMA_32x32x16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b1), acc[1]);
     }
   };
 

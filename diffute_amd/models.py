@@ -118,13 +118,50 @@ class _HipModel(nn.Module):
     """Shared plumbing: parameter tree from the C library's table, packed-weights arena, workspace."""
     _kind = None         # "unet" | "vae"
 
+    def _create_handle(self, elem):
+        l = _cabi.lib(elem)
+        h = getattr(l, f"dmx_{self._kind}_create")(ctypes.byref(self._cstruct))
+        if not h:
+            raise ValueError(f"{type(self).__name__}: " + l.dmx_last_error().decode())
+        return h
+
+    @property
+    def _lib(self):
+        """the build of the C-ABI library this model runs on: bf16 (default) or the fp16 build after `.to(dtype=torch.float16)`"""
+        return _cabi.lib(self._elem)
+
+    @property
+    def compute_dtype(self):
+        """torch dtype of the 16-bit storage / MFMA operands (accumulation is fp32 either way)"""
+        return _cabi.torch_elem(self._elem)
+
+    def _switch_build(self, elem):
+        """re-create the handle in the other build of the library; Parameters (fp32 masters) are untouched, the packed arena,
+        workspaces, context caches and captured graphs belong to the old handle and are dropped"""
+        if elem == self._elem:
+            return
+        if getattr(self, "_fused", None) is not None or getattr(self, "_tb", None) is not None:
+            raise NotImplementedError(f"{type(self).__name__}: changing the compute type after training state exists is not supported")
+        torch.cuda.synchronize() if torch.cuda.is_initialized() else None
+        getattr(_cabi.lib(self._elem), f"dmx_{self._kind}_destroy")(self._h)
+        self._h = None
+        self._elem = elem
+        self._h = self._create_handle(elem)
+        self._arena = None; self._packed_sig = None; self._ws = None
+        for attr in ("_masters32", "_train"):
+            if hasattr(self, attr):
+                setattr(self, attr, None)
+        if hasattr(self, "_slots"):
+            self._slots = {}
+
     def _setup(self, handle, seed, device):
         self._h = handle
+        self._elem = "bf16"
         self._dtype = torch.float32
         self._arena = None
         self._packed_sig = None
         self._ws = None
-        lib = _cabi.lib()
+        lib = self._lib
         n = getattr(lib, f"dmx_{self._kind}_param_count")(self._h)
         self._keys = []
         name = ctypes.c_char_p()
@@ -139,7 +176,7 @@ class _HipModel(nn.Module):
     def __del__(self):
         try:
             if getattr(self, "_h", None):
-                getattr(_cabi.lib(), f"dmx_{self._kind}_destroy")(self._h)
+                getattr(_cabi.lib(self._elem), f"dmx_{self._kind}_destroy")(self._h)
                 self._h = None
         except Exception:
             pass
@@ -164,9 +201,10 @@ class _HipModel(nn.Module):
         return self._dtype
 
     def to(self, *args, **kwargs):
-        """`.to(device, dtype=weight_dtype)` (train_diffute_v1.py:796): device moves are honoured; the
-        dtype is recorded as the I/O dtype only - master parameters stay fp32, compute is bf16 MFMA
-        with fp32 accumulation whatever the requested low-precision dtype."""
+        """`.to(device, dtype=weight_dtype)` (train_diffute_v1.py:789-797): device moves are honoured; master parameters stay
+        fp32 and accumulation is fp32 whatever the dtype.  The dtype selects the BUILD of the library that computes:
+        torch.float16 -> the fp16 build (fp16 storage, v_mfma_f32_32x32x16_f16; BASELINE configs[4]); torch.bfloat16 /
+        torch.float32 -> the bf16 build.  It is also the dtype low-precision inputs get their outputs back in."""
         dtype = kwargs.pop("dtype", None)
         args = list(args)
         for a in list(args):
@@ -174,6 +212,7 @@ class _HipModel(nn.Module):
                 dtype = a; args.remove(a)
         if dtype is not None:
             self._dtype = dtype
+            self._switch_build(_cabi.elem_of(dtype))
         if args or kwargs:
             super().to(*args, **kwargs)
             self._packed_sig = None
@@ -199,7 +238,7 @@ class _HipModel(nn.Module):
         sig = self._signature()
         if self._packed_sig == sig and self._arena is not None:
             return                                   # (a fused optimizer updates the arena in place and leaves the Parameters alone)
-        lib = _cabi.lib()
+        lib = self._lib
         k = self._kind
         nbytes = getattr(lib, f"dmx_{k}_arena_bytes")(self._h)
         if self._arena is None or self._arena.device != dev:
@@ -292,11 +331,9 @@ class UNet2DConditionModel(_HipModel):
             c.heads[i] = cfg["attention_head_dim"][i]
             c.down_has_attn[i] = int(cfg["down_block_types"][i].startswith("CrossAttn"))
             c.up_has_attn[i] = int(cfg["up_block_types"][i].startswith("CrossAttn"))
-        h = _cabi.lib().dmx_unet_create(ctypes.byref(c))
-        if not h:
-            raise ValueError("UNet2DConditionModel: " + _cabi.lib().dmx_last_error().decode())
+        self._cstruct = c
         self._slots = {}
-        self._setup(h, seed, device)
+        self._setup(self._create_handle("bf16"), seed, device)
 
     def _finalize(self, st):
         half = self.config.block_out_channels[0] // 2
@@ -304,7 +341,7 @@ class UNet2DConditionModel(_HipModel):
         exponent = -math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32)
         freq = torch.exp(exponent / (half - self.config.freq_shift)).contiguous()
         self._freq_host = freq
-        _cabi.check(_cabi.lib().dmx_unet_finalize(self._h, ctypes.c_void_p(freq.data_ptr()), st), "unet_finalize")
+        _cabi.check(self._lib.dmx_unet_finalize(self._h, ctypes.c_void_p(freq.data_ptr()), st), "unet_finalize")
         for sl in self._slots.values():
             sl["ctx_key"] = None
 
@@ -328,18 +365,18 @@ class UNet2DConditionModel(_HipModel):
         sl = self._slot(slot)
         ctx = encoder_hidden_states
         _cabi.require_cuda(ctx)
-        if ctx.dtype not in (torch.float32, torch.bfloat16):
+        if ctx.dtype not in (torch.float32, self.compute_dtype):
             ctx = ctx.to(torch.float32)
         ctx = ctx.contiguous()
         B, S, D = ctx.shape
         if D != self.config.cross_attention_dim:
             raise ValueError(f"encoder_hidden_states last dim {D} != cross_attention_dim {self.config.cross_attention_dim}")
-        lib = _cabi.lib()
+        lib = self._lib
         nb = lib.dmx_unet_context_bytes(self._h, B, S)
         if sl["ctx_cache"] is None or sl["ctx_cache"].numel() < nb or sl["ctx_cache"].device != ctx.device:
             sl["ctx_cache"] = torch.empty(nb, dtype=torch.uint8, device=ctx.device)
         ws = self._slot_workspace(sl, lib.dmx_unet_workspace_bytes(self._h, B, 8, 8, S))
-        _cabi.check(lib.dmx_unet_set_context(self._h, _cabi.ptr(ctx), int(ctx.dtype == torch.bfloat16), B, S,
+        _cabi.check(lib.dmx_unet_set_context(self._h, _cabi.ptr(ctx), int(ctx.dtype == self.compute_dtype), B, S,
                                              _cabi.ptr(sl["ctx_cache"]), sl["ctx_cache"].numel(),
                                              _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_set_context")
         # identity + version of the tensor object the K/V were projected from.  The strong reference keeps the allocator from
@@ -352,7 +389,7 @@ class UNet2DConditionModel(_HipModel):
         (fuses the torch.cat of app.ipynb:811); timesteps_dev = int64 cuda tensor [1] or [B];
         context must have been set with set_context() on the same slot.  graph=True replays a captured hipGraph
         when the same buffers are passed again (needs a non-default current stream)."""
-        lib = _cabi.lib()
+        lib = self._lib
         sl = self._slot(slot)
         x0 = parts[0]
         B, _, H, W = x0.shape
@@ -392,7 +429,7 @@ class UNet2DConditionModel(_HipModel):
     @torch.no_grad()
     def forward_taps(self, sample, timestep, encoder_hidden_states):
         """the product (bf16) forward plus the block outputs conv_in, down0..3, mid, up0..3 as NCHW fp32 tensors"""
-        lib = _cabi.lib()
+        lib = self._lib
         self._ensure_packed()
         self.set_context(encoder_hidden_states)
         sl = self._slot(0)
@@ -412,7 +449,7 @@ class UNet2DConditionModel(_HipModel):
         """VALIDATION ONLY: the same graph on fp32 activations, fp32 master weights and plain fp32 kernels (ref_f32.hip) -
         north_star's "within 1e-3 rel fp32" check against the fp32 reference path.  parts: one NCHW tensor or the list
         [latents, mask, masked_latents]; returns eps (and the block taps when taps=True).  Slow; never on the product path."""
-        lib = _cabi.lib()
+        lib = self._lib
         self._ensure_packed()
         if torch.is_tensor(parts):
             parts = [parts]
@@ -443,7 +480,7 @@ class UNet2DConditionModel(_HipModel):
     # ---- training (train_diffute_v1.py:913-925): forward that keeps activations + hand-written HIP backward
     def _train_buffers(self):
         """transposed-weights arena (data-gradient operands, refreshed when the weights change) and the fp32 gradient arena"""
-        lib = _cabi.lib()
+        lib = self._lib
         tb = getattr(self, "_tb", None)
         if tb is None or tb["wt"].device != self.device:
             tb = self._tb = dict(wt=torch.empty(lib.dmx_unet_train_wt_bytes(self._h), dtype=torch.uint8, device=self.device),
@@ -478,7 +515,7 @@ class UNet2DConditionModel(_HipModel):
     def _sync_plan(self, tb):
         if tb["plan"] is None:
             from .dist import plan_buckets
-            lib = _cabi.lib()
+            lib = self._lib
             b, e = ctypes.c_size_t(), ctypes.c_size_t()
             prs = []
             for k in self._keys:
@@ -495,7 +532,7 @@ class UNet2DConditionModel(_HipModel):
         return tb["plan"]
 
     def _train_forward(self, sample, timestep, ctx):
-        lib = _cabi.lib()
+        lib = self._lib
         self._ensure_packed()
         tb = self._train_buffers()
         B, _, H, W = sample.shape
@@ -506,7 +543,7 @@ class UNet2DConditionModel(_HipModel):
             tb["ws"] = torch.empty(int(need), dtype=torch.uint8, device=sample.device)
         pred = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=sample.device)
         _cabi.check(lib.dmx_unet_train_forward(self._h, _cabi.ptr(tb["wt"]), _cabi.ptr(sample), sample.shape[1], None, 0, None, 0,
-                                               _cabi.ptr(timestep), timestep.numel(), _cabi.ptr(ctx), int(ctx.dtype == torch.bfloat16), S,
+                                               _cabi.ptr(timestep), timestep.numel(), _cabi.ptr(ctx), int(ctx.dtype == self.compute_dtype), S,
                                                _cabi.ptr(pred), B, H, W, _cabi.ptr(tb["ws"]), tb["ws"].numel(), _cabi.current_stream()),
                     "unet_train_forward")
         tb["fwd_stream"] = torch.cuda.current_stream(sample.device)
@@ -514,7 +551,7 @@ class UNet2DConditionModel(_HipModel):
 
     def _train_backward(self, dpred):
         """-> list of parameter gradients (torch layouts, fp32) in self._keys order"""
-        lib = _cabi.lib()
+        lib = self._lib
         tb = self._tb
         sync = getattr(self, "_sync", None)
         if sync is not None:
@@ -576,6 +613,9 @@ class UNet2DConditionModel(_HipModel):
             t = timestep.reshape(-1).to(device=sample.device, dtype=torch.int64)
             if t.numel() not in (1, B):
                 raise ValueError(f"timestep must have 1 or {B} elements, got {t.numel()}")
+            if self._elem != "bf16":
+                raise NotImplementedError("UNet2DConditionModel: training runs on the bf16 build only (fp16 gradients need loss "
+                                          "scaling, which this library does not implement); use .to(dtype=torch.bfloat16)")
             ctx = encoder_hidden_states if encoder_hidden_states.dtype in (torch.float32, torch.bfloat16) else encoder_hidden_states.float()
             out = _UNetTrainFn.apply(self, sample.detach().to(torch.float32).contiguous(), t, ctx.detach().contiguous(), *self._param_list())
             if self._dtype != torch.float32 and sample.dtype != torch.float32:
@@ -675,13 +715,12 @@ class AutoencoderKL(_HipModel):
         c.layers_per_block = cfg["layers_per_block"]; c.norm_num_groups = cfg["norm_num_groups"]
         for i in range(4):
             c.block_out_channels[i] = cfg["block_out_channels"][i]
-        h = _cabi.lib().dmx_vae_create(ctypes.byref(c))
-        if not h:
-            raise ValueError("AutoencoderKL: " + _cabi.lib().dmx_last_error().decode())
+        self._cstruct = c
+        h = self._create_handle("bf16")
         self._setup(h, seed, device)
 
     def _finalize(self, st):
-        _cabi.check(_cabi.lib().dmx_vae_finalize(self._h, st), "vae_finalize")
+        _cabi.check(self._lib.dmx_vae_finalize(self._h, st), "vae_finalize")
 
     @staticmethod
     def _convert_legacy_keys(sd):
@@ -706,7 +745,7 @@ class AutoencoderKL(_HipModel):
         self._no_grad_check()
         _cabi.require_cuda(x)
         self._ensure_packed()
-        lib = _cabi.lib()
+        lib = self._lib
         x = x.to(torch.float32).contiguous()
         B, C, H, W = x.shape
         f = 2 ** (len(self.config.block_out_channels) - 1)
@@ -721,7 +760,7 @@ class AutoencoderKL(_HipModel):
         self._no_grad_check()
         _cabi.require_cuda(z)
         self._ensure_packed()
-        lib = _cabi.lib()
+        lib = self._lib
         z = z.to(torch.float32).contiguous()
         B, C, h, w = z.shape
         f = 2 ** (len(self.config.block_out_channels) - 1)
@@ -733,7 +772,7 @@ class AutoencoderKL(_HipModel):
 
     # ---- fp32 VALIDATION path (tests only): the same graphs on fp32 activations, fp32 master weights, plain fp32 kernels
     def _masters_fp32(self):
-        lib = _cabi.lib()
+        lib = self._lib
         self._ensure_packed()
         m = getattr(self, "_masters32", None)
         if m is None or m[0] != self._packed_sig:
@@ -749,7 +788,7 @@ class AutoencoderKL(_HipModel):
     def encode_fp32(self, x):
         """VALIDATION ONLY: `encode(x).latent_dist.parameters` (the moments) through the fp32 instantiation of the graph -
         north_star's "within 1e-3 rel fp32" check at model level.  Slow; images up to ~384 px."""
-        lib = _cabi.lib()
+        lib = self._lib
         m = self._masters_fp32()
         x = x.to(torch.float32).contiguous()
         B, C, H, W = x.shape
@@ -763,7 +802,7 @@ class AutoencoderKL(_HipModel):
     @torch.no_grad()
     def decode_fp32(self, z):
         """VALIDATION ONLY: `decode(z).sample` through the fp32 instantiation of the graph."""
-        lib = _cabi.lib()
+        lib = self._lib
         m = self._masters_fp32()
         z = z.to(torch.float32).contiguous()
         B, C, h, w = z.shape
@@ -776,7 +815,7 @@ class AutoencoderKL(_HipModel):
 
     # ---- training (train_vae.py:716-736): recon = decode(encode(x).mode()) with a HIP backward
     def _train_buffers(self):
-        lib = _cabi.lib()
+        lib = self._lib
         tb = getattr(self, "_tb", None)
         if tb is None or tb["wt"].device != self.device:
             tb = self._tb = dict(wt=torch.empty(lib.dmx_vae_train_wt_bytes(self._h), dtype=torch.uint8, device=self.device),
@@ -792,7 +831,7 @@ class AutoencoderKL(_HipModel):
         return [sd[k] for k in self._keys]
 
     def _train_forward(self, x):
-        lib = _cabi.lib()
+        lib = self._lib
         self._ensure_packed()
         tb = self._train_buffers()
         B, _, H, W = x.shape
@@ -807,7 +846,7 @@ class AutoencoderKL(_HipModel):
         return recon
 
     def _train_backward(self, drecon):
-        lib = _cabi.lib()
+        lib = self._lib
         tb = self._tb
         drecon = drecon.to(torch.float32).contiguous()
         out = []
@@ -829,6 +868,8 @@ class AutoencoderKL(_HipModel):
             _cabi.require_cuda(sample)
             if sample.shape[2] % 64 or sample.shape[3] % 64:
                 raise ValueError("AutoencoderKL training: image sides must be multiples of 64")
+            if self._elem != "bf16":
+                raise NotImplementedError("AutoencoderKL: training runs on the bf16 build only; use .to(dtype=torch.bfloat16)")
             dec = _VAETrainFn.apply(self, sample.detach().to(torch.float32).contiguous(), *self._param_list())
             return {"sample": dec} if return_dict else (dec,)
         post = self.encode(sample).latent_dist
@@ -861,14 +902,13 @@ class TrOCREncoder(_HipModel):
         c.image_size = cfg["image_size"]; c.patch_size = cfg["patch_size"]; c.num_channels = cfg["num_channels"]
         c.hidden_size = cfg["hidden_size"]; c.num_layers = cfg["num_hidden_layers"]; c.num_heads = cfg["num_attention_heads"]
         c.intermediate_size = cfg["intermediate_size"]; c.qkv_bias = int(bool(cfg["qkv_bias"])); c.layer_norm_eps = float(cfg["layer_norm_eps"])
-        h = _cabi.lib().dmx_vit_create(ctypes.byref(c))
-        if not h:
-            raise ValueError("TrOCREncoder: " + _cabi.lib().dmx_last_error().decode())
+        self._cstruct = c
+        h = self._create_handle("bf16")
         self._setup(h, seed, device)
         self.requires_grad_(False)
 
     def _finalize(self, st):
-        _cabi.check(_cabi.lib().dmx_vit_finalize(self._h, st), "vit_finalize")
+        _cabi.check(self._lib.dmx_vit_finalize(self._h, st), "vit_finalize")
 
     @staticmethod
     def _convert_legacy_keys(sd):
@@ -901,7 +941,7 @@ class TrOCREncoder(_HipModel):
             raise NotImplementedError("diffute_amd: the glyph encoder is forward-only (frozen in the reference, train_diffute_v1.py:638)")
         _cabi.require_cuda(pixel_values)
         self._ensure_packed()
-        lib = _cabi.lib()
+        lib = self._lib
         x = pixel_values.to(torch.float32).contiguous()
         B, C, H, W = x.shape
         if (C, H, W) != (self.config.num_channels, self.config.image_size, self.config.image_size):
@@ -918,7 +958,7 @@ class TrOCREncoder(_HipModel):
     def forward_fp32(self, pixel_values):
         """VALIDATION ONLY: `last_hidden_state` through the fp32 instantiation of the graph (fp32 activations, fp32 master
         weights, plain fp32 kernels) - compared with transformers' ViTModel at north_star's 1e-3.  Slow."""
-        lib = _cabi.lib()
+        lib = self._lib
         self._ensure_packed()
         x = pixel_values.to(torch.float32).contiguous()
         B = x.shape[0]

@@ -8,8 +8,33 @@ import ctypes
 
 import torch
 
+import contextlib
+
 from . import _cabi
-from ._cabi import GemmDesc, check, current_stream, lib, ptr
+from ._cabi import GemmDesc, check, current_stream, ptr
+
+_ELEM = "bf16"
+
+
+def lib():
+    """the build of the library the operator wrappers call: bf16, or fp16 inside `with element_type("fp16")`"""
+    return _cabi.lib(_ELEM)
+
+
+def h16():
+    """torch dtype of the 16-bit activation / weight element of the active build"""
+    return _cabi.torch_elem(_ELEM)
+
+
+@contextlib.contextmanager
+def element_type(elem):
+    """run the operator wrappers on the fp16 build (libdiffute_hip_f16.so): activations / packed weights are torch.float16"""
+    global _ELEM
+    old, _ELEM = _ELEM, elem
+    try:
+        yield
+    finally:
+        _ELEM = old
 
 
 def _ld(x):
@@ -21,7 +46,7 @@ def nchw_to_nhwc_bf16(x):
     """fp32 NCHW -> bf16 NHWC through dmx_nchw_f32_to_nhwc_bf16."""
     x = x.to(torch.float32).contiguous()
     B, C, H, W = x.shape
-    out = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(B, H, W, C, dtype=h16(), device=x.device)
     check(lib().dmx_nchw_f32_to_nhwc_bf16(ptr(x), ptr(out), C, B, C, H * W, current_stream()), "nchw_f32_to_nhwc_bf16")
     return out
 
@@ -39,7 +64,7 @@ def pack_conv_weight(w, shortcut_w=None):
     Cout, Cin, k, _ = w.shape
     K = k * k * Cin + (shortcut_w.shape[1] if shortcut_w is not None else 0)
     Kp = (K + 63) // 64 * 64
-    out = torch.zeros(Cout, Kp, dtype=torch.bfloat16, device=w.device)
+    out = torch.zeros(Cout, Kp, dtype=h16(), device=w.device)
     check(lib().dmx_pack_conv_weight(ptr(w), ptr(out), Cout, Cin, k, Kp, 0, current_stream()), "pack_conv_weight")
     if shortcut_w is not None:
         s = shortcut_w.to(torch.float32).contiguous()
@@ -49,7 +74,7 @@ def pack_conv_weight(w, shortcut_w=None):
 
 def pack_linear_weight(w, geglu=False):
     w = w.to(torch.float32).contiguous()
-    out = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    out = torch.empty(w.shape, dtype=h16(), device=w.device)
     check(lib().dmx_pack_linear_weight(ptr(w), ptr(out), w.shape[0], w.shape[1], w.shape[1], int(geglu), current_stream()), "pack_linear_weight")
     return out
 
@@ -58,7 +83,7 @@ def pack_conv_weight_t(w):
     """[Cout,Cin,k,k] fp32 -> bf16 [Cin][k*k*Cout]: flipped taps, channel roles swapped (data-gradient filter)."""
     w = w.to(torch.float32).contiguous()
     Cout, Cin, k, _ = w.shape
-    out = torch.empty(Cin, k * k * Cout, dtype=torch.bfloat16, device=w.device)
+    out = torch.empty(Cin, k * k * Cout, dtype=h16(), device=w.device)
     check(lib().dmx_pack_conv_weight_t(ptr(w), ptr(out), Cout, Cin, k, k * k * Cout, 0, current_stream()), "pack_conv_weight_t")
     return out
 
@@ -66,7 +91,7 @@ def pack_conv_weight_t(w):
 def pack_linear_weight_t(w):
     """[N,K] fp32 -> bf16 [K][N]"""
     w = w.to(torch.float32).contiguous()
-    out = torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=w.device)
+    out = torch.empty(w.shape[1], w.shape[0], dtype=h16(), device=w.device)
     check(lib().dmx_pack_linear_weight_t(ptr(w), ptr(out), w.shape[0], w.shape[1], w.shape[0], current_stream()), "pack_linear_weight_t")
     return out
 
@@ -78,13 +103,13 @@ def conv_dgrad(dy, wt, Cin, *, ksize=3, stride=1, ups=False, res=None):
     B, OH, OW, Cout = dy.shape
     g = dy
     if stride == 2:
-        g = torch.empty(B, 2 * OH, 2 * OW, Cout, dtype=torch.bfloat16, device=dy.device)
+        g = torch.empty(B, 2 * OH, 2 * OW, Cout, dtype=h16(), device=dy.device)
         check(lib().dmx_zero_insert2(ptr(dy), _ld(dy), ptr(g), B, OH, OW, Cout, current_stream()), "zero_insert2")
     du = conv_gemm(g, wt, Cin, ksize=ksize, stride=1, pad=ksize // 2, res=None if ups else res, out_f32=ups)
     if not ups:
         return du
     H, W = du.shape[1] // 2, du.shape[2] // 2
-    dx = res.clone() if res is not None else torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dy.device)
+    dx = res.clone() if res is not None else torch.empty(B, H, W, Cin, dtype=h16(), device=dy.device)
     check(lib().dmx_sumpool2(ptr(du), _ld(du), 1, ptr(dx), _ld(dx), B, H, W, Cin, int(res is not None), current_stream()), "sumpool2")
     return dx
 
@@ -98,7 +123,7 @@ def pack_geglu_bias(b):
 
 def pack_ups_phase_weights(w3, N, Cin):
     """taps-major packed 3x3 weights [N][9*Cin] (pack_conv_weight) -> [4][N][4*Cin] phase weights of conv_ups2x"""
-    wp = torch.empty(4, N, 4 * Cin, dtype=torch.bfloat16, device=w3.device)
+    wp = torch.empty(4, N, 4 * Cin, dtype=h16(), device=w3.device)
     check(lib().dmx_pack_ups_phase_weights(ptr(w3), w3.stride(0), ptr(wp), N, Cin, current_stream()), "pack_ups_phase_weights")
     return wp
 
@@ -106,7 +131,7 @@ def pack_ups_phase_weights(w3, N, Cin):
 def conv_ups2x(x, wp, N, bias=None, force_tn=0, force_splitk=0):
     """conv3x3(nearest_x2(x)) through four 2x2 phase convolutions on the source grid.  x NHWC bf16 -> NHWC bf16 [B,2H,2W,N]."""
     B, H, W, Cin = x.shape
-    out = torch.empty(B, 2 * H, 2 * W, N, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(B, 2 * H, 2 * W, N, dtype=h16(), device=x.device)
     wsb = lib().dmx_conv_ups2x_workspace_bytes(B, H, W, Cin, N, force_tn, force_splitk)
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
     check(lib().dmx_conv_ups2x(ptr(x), _ld(x), B, H, W, Cin, ptr(wp), N, ptr(bias) if bias is not None else None, ptr(out), N,
@@ -150,7 +175,7 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
     if res is not None:
         d.res = res.data_ptr(); d.ldres = _ld(res)
     Nout = N // 2 if geglu else N
-    out = torch.empty(B, OH, OW, Nout, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x0.device)
+    out = torch.empty(B, OH, OW, Nout, dtype=torch.float32 if out_f32 else h16(), device=x0.device)
     d.out = out.data_ptr(); d.ldo = Nout; d.out_f32 = int(out_f32); d.geglu = int(geglu)
     d.force_tn = force_tn; d.force_splitk = force_splitk; d.group_m = group_m; d.dbg = dbg; d.act = act
     if timing is not None:
@@ -228,7 +253,7 @@ def linear(x, w, bias=None, res=None, geglu=False, out_f32=False, act=0, force_t
 def groupnorm(x0, gamma, beta, groups, eps, silu, x1=None):
     B, H, W, C0 = x0.shape
     C = C0 + (x1.shape[-1] if x1 is not None else 0)
-    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x0.device)
+    y = torch.empty(B, H, W, C, dtype=h16(), device=x0.device)
     wsb = lib().dmx_groupnorm_workspace_bytes(B, H * W, groups)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x0.device)
     check(lib().dmx_groupnorm(ptr(x0), _ld(x0), ptr(x1), _ld(x1) if x1 is not None else 0, C0, C, groups, B, H * W,
@@ -240,7 +265,7 @@ def groupnorm_train(x0, gamma, beta, groups, eps, silu, x1=None):
     """forward GroupNorm that also returns the saved (mean, rstd) [B][groups][2]"""
     B, H, W, C0 = x0.shape
     C = C0 + (x1.shape[-1] if x1 is not None else 0)
-    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=x0.device)
+    y = torch.empty(B, H, W, C, dtype=h16(), device=x0.device)
     stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x0.device)
     wsb = lib().dmx_groupnorm_workspace_bytes(B, H * W, groups)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x0.device)
@@ -282,7 +307,7 @@ def layernorm_bwd(x, dy, gamma, eps=1e-5, res=None):
 def geglu_fwd(h):
     C2 = h.shape[-1] // 2
     rows = h.numel() // (2 * C2)
-    y = torch.empty(*h.shape[:-1], C2, dtype=torch.bfloat16, device=h.device)
+    y = torch.empty(*h.shape[:-1], C2, dtype=h16(), device=h.device)
     check(lib().dmx_geglu_fwd(ptr(h), 2 * C2, ptr(y), C2, rows, C2, current_stream()), "geglu_fwd")
     return y
 
@@ -305,7 +330,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
 
 def attention(q, k, vt, B, H, Sq, Skv, scale, kv_rows=None, skv_stride=None):
     """q [B*Sq, >=H*64], k [B*kv_rows, >=H*64], vt [H*64, >= B*skv_stride] (2-D, row-major views)."""
-    o = torch.empty(B * Sq, H * 64, dtype=torch.bfloat16, device=q.device)
+    o = torch.empty(B * Sq, H * 64, dtype=h16(), device=q.device)
     kv_rows = Skv if kv_rows is None else kv_rows
     skv_stride = Skv if skv_stride is None else skv_stride
     check(lib().dmx_attention_fwd(ptr(q), q.stride(0), ptr(k), k.stride(0), kv_rows, ptr(vt), vt.stride(0), skv_stride,
@@ -315,7 +340,7 @@ def attention(q, k, vt, B, H, Sq, Skv, scale, kv_rows=None, skv_stride=None):
 
 def attention_v(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
     """q [B*Sq, >=H*64], k / v [B*kv_rows, >=H*64] row-major 2-D views (V read through LDS transpose reads)."""
-    o = torch.empty(B * Sq, H * 64, dtype=torch.bfloat16, device=q.device)
+    o = torch.empty(B * Sq, H * 64, dtype=h16(), device=q.device)
     kv_rows = Skv if kv_rows is None else kv_rows
     check(lib().dmx_attention_fwd_v(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), kv_rows,
                                     ptr(o), H * 64, B, H, Sq, Skv, float(scale), current_stream()), "attention_fwd_v")
@@ -324,7 +349,7 @@ def attention_v(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
 
 def attention_wide(q, k, v, B, Sq, Skv, D, scale, kv_rows=None):
     """single head of width D (128 / 256 / 512): q [B*Sq, >=D], k / v [B*kv_rows, >=D] row-major 2-D views -> [B*Sq, D]"""
-    o = torch.empty(B * Sq, D, dtype=torch.bfloat16, device=q.device)
+    o = torch.empty(B * Sq, D, dtype=h16(), device=q.device)
     check(lib().dmx_attention_wide(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), Skv if kv_rows is None else kv_rows,
                                    ptr(o), D, B, Sq, Skv, D, float(scale), current_stream()), "attention_wide")
     return o
@@ -332,7 +357,7 @@ def attention_wide(q, k, v, B, Sq, Skv, D, scale, kv_rows=None):
 
 def attention_train(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
     """forward with row-major V that also returns lse [B,H,Sq] (log2 domain)"""
-    o = torch.empty(B * Sq, H * 64, dtype=torch.bfloat16, device=q.device)
+    o = torch.empty(B * Sq, H * 64, dtype=h16(), device=q.device)
     lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
     check(lib().dmx_attention_fwd_train(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), kv_rows or Skv,
                                         ptr(o), H * 64, ptr(lse), B, H, Sq, Skv, float(scale), current_stream()), "attention_fwd_train")
@@ -363,7 +388,7 @@ def im2col_small(sources=None, nhwc=None, ksize=3, stride=1, pad=1, Kpad=64):
         args += [None, 0]
     OH, OW = (H // stride, W // stride)
     dev = nhwc.device if nhwc is not None else srcs[0].device
-    out = torch.empty(B, OH, OW, Kpad, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(B, OH, OW, Kpad, dtype=h16(), device=dev)
     check(lib().dmx_im2col_small(*args, C, B, H, W, OH, OW, ksize, stride, pad, ptr(out), Kpad, current_stream()), "im2col_small")
     return out
 

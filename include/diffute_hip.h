@@ -10,7 +10,8 @@
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it is named
  *     `h_...` or is a `const char*` / descriptor struct (host memory);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
- *   - activations between kernels are NHWC ("pixel-major") bf16; model inputs / outputs at
+ *   - activations between kernels are NHWC ("pixel-major") bf16 (fp16 in the -DDMX_F16 build, see dmx_element_type);
+ *     model inputs / outputs at
  *     the Python boundary stay NCHW fp32 exactly as the reference passes them
  *     (app.ipynb:762, train_diffute_v1.py:731), converted inside the library;
  *   - functions return 0 on success, a negative DMX_ERR_* code otherwise; the message of
@@ -41,6 +42,11 @@ typedef struct dmx_vae dmx_vae;
 
 int dmx_version(void);
 const char* dmx_last_error(void);
+/* The 16-bit storage / MFMA operand type this build of the library computes in: "bf16" (libdiffute_hip.so) or "fp16"
+ * (libdiffute_hip_f16.so, the same sources compiled with -DDMX_F16).  Wherever this header says "bf16" for an activation,
+ * weight or context buffer it means this element type.  The host mirror loads the fp16 build for a model moved with
+ * `.to(dtype=torch.float16)` (vae.to(device, dtype=weight_dtype), train_diffute_v1.py:789-797; BASELINE configs[4]). */
+const char* dmx_element_type(void);
 
 /* ------------------------------------------------------------------------------------
  * Operator level.  Used by the parity tests and by the executors.

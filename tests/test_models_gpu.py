@@ -226,6 +226,71 @@ def test_cfg1_full_golden(cuda):
     print(f"cfg1 rel-L2: eps0 {e0:.2e}, final vs bf16emu {e1:.2e}, final vs fp32 {e2:.2e}")
 
 
+def test_cfg2_headline_workload_vs_golden(cuda):
+    """The workload bench.py times (BASELINE configs[1]: 512 px, 50 DDIM steps, batch 4, bf16) checked on its RESULT: sample 0
+    of the B=4 `denoise()` against the committed oracle run of that sample (tests/golden/cfg2_b1.npz from
+    scripts/make_golden.py --cfg2: eps at steps 0 / 25 / 49 and the final latents, fp32 oracle and bf16-emulating oracle), and
+    the reference's own scheduler - DDPM, 50 steps, injected variance noise (app.ipynb:545,806-816) - likewise.
+    Bounds: final latents <= 2e-2 vs the fp32 oracle, first-step eps <= 2.5e-2 vs the bf16-emulating oracle
+    (one forward); later eps are compared on THEIR OWN trajectories, which have drifted apart by then - hence the wider bound."""
+    import diffute_amd as D
+    from diffute_amd.init import normal
+    from diffute_amd.synthetic import synth_inputs
+    path = os.path.join(GOLD, "cfg2_b1.npz")
+    if not os.path.exists(path):
+        pytest.skip("cfg2_b1.npz not generated")
+    g = np.load(path)
+    unet = D.UNet2DConditionModel(device=cuda).requires_grad_(False)
+    lat, mask, mlat, ctx = synth_inputs(4, 64, 64, 577, 1024, device=cuda)
+    for sched, cls, nz in (("ddim", D.DDIMScheduler, None),
+                           ("ddpm", D.DDPMScheduler, normal(3, 31, 50 * 4 * 4 * 64 * 64, cuda).reshape(50, 4, 4, 64, 64))):
+        if f"final_{sched}_fp32" not in g.files:
+            continue
+        trace = {}
+        out = D.denoise(unet, cls(), lat, mask, mlat, ctx, 50, variance_noise=nz,
+                        callback=lambda i, t, x, eps: trace.__setitem__(i, (t, eps[:1].clone(), x[:1].clone())) if i in (0, 25, 49) else None)
+        assert [trace[i][0] for i in (0, 25, 49)] == [int(g[f"timesteps_{sched}"][i]) for i in (0, 25, 49)]
+        e0 = assert_close(trace[0][1], torch.from_numpy(g[f"eps0_{sched}_bf16emu"]), E2E_EMU, f"cfg2 {sched}: first-step eps vs bf16emu oracle")
+        e0f = assert_close(trace[0][1], torch.from_numpy(g[f"eps0_{sched}_fp32"]), 5e-2, f"cfg2 {sched}: first-step eps vs fp32 oracle")
+        e25 = assert_close(trace[25][1], torch.from_numpy(g[f"eps25_{sched}_fp32"]), 8e-2, f"cfg2 {sched}: eps at step 25 vs fp32 oracle")
+        e49 = assert_close(trace[49][1], torch.from_numpy(g[f"eps49_{sched}_fp32"]), 8e-2, f"cfg2 {sched}: eps at step 49 vs fp32 oracle")
+        x25 = assert_close(trace[25][2], torch.from_numpy(g[f"x25_{sched}_fp32"]), 2e-2, f"cfg2 {sched}: latents after step 25 vs fp32 oracle")
+        ef = assert_close(out[:1], torch.from_numpy(g[f"final_{sched}_fp32"]), 2e-2, f"cfg2 {sched}: final latents (50 steps) vs fp32 oracle")
+        eb = assert_close(out[:1], torch.from_numpy(g[f"final_{sched}_bf16emu"]), 2e-2, f"cfg2 {sched}: final latents (50 steps) vs bf16emu oracle")
+        print(f"cfg2 headline workload, sample 0 of B=4, 50 {sched.upper()} steps: eps0 {e0:.2e} (bf16emu) {e0f:.2e} (fp32), eps25 {e25:.2e}, eps49 {e49:.2e}, "
+              f"x25 {x25:.2e}, final latents {ef:.2e} (fp32 oracle) {eb:.2e} (bf16emu oracle); "
+              f"oracle bf16emu vs fp32 final {rel_l2(torch.from_numpy(g[f'final_{sched}_bf16emu']), torch.from_numpy(g[f'final_{sched}_fp32'])):.2e}")
+        assert torch.isfinite(out).all()
+
+
+def test_cfg1_full_size_block_taps(cuda):
+    """per-block checks at FULL size (SD2-inpaint config, cfg1's first UNet call): L2 norm, sum and a strided slice of every
+    block output - conv_in, down0..3, mid, up0..3 - against the committed oracle values (tests/golden/cfg1_taps.npz)."""
+    import diffute_amd as D
+    from diffute_amd.synthetic import synth_inputs
+    path = os.path.join(GOLD, "cfg1_taps.npz")
+    if not os.path.exists(path):
+        pytest.skip("cfg1_taps.npz not generated")
+    g = np.load(path)
+    unet = D.UNet2DConditionModel(device=cuda).requires_grad_(False)
+    lat, mask, mlat, ctx = synth_inputs(1, 32, 32, 577, 1024, device=cuda)
+    y, taps = unet.forward_taps(torch.cat([lat, mask, mlat], 1), torch.tensor(int(g["timestep"])), ctx)
+    rep = []
+    for k, v in taps.items():
+        v = v.float().cpu()
+        sl = v.flatten()[::97][:4096]
+        tol = 2e-3 if k == "conv_in" else 2.5e-2
+        e = assert_close(sl, torch.from_numpy(g[f"slice_bf16emu_{k}"]), tol, f"cfg1 block {k}: strided slice vs bf16emu oracle")
+        ef = assert_close(sl, torch.from_numpy(g[f"slice_fp32_{k}"]), 2 * tol, f"cfg1 block {k}: strided slice vs fp32 oracle")
+        l2 = float(v.double().pow(2).sum().sqrt())
+        assert abs(l2 / float(g[f"l2_bf16emu_{k}"]) - 1) < 5e-3, f"cfg1 block {k}: L2 norm {l2} vs {float(g[f'l2_bf16emu_{k}'])}"
+        sm = float(v.double().sum())
+        # per-element errors are ~1e-2 relative with random signs: the sum moves by ~1e-2 * ||v||_2; allow 5 sigma
+        assert abs(sm - float(g[f"sum_bf16emu_{k}"])) <= 5e-2 * float(g[f"l2_bf16emu_{k}"]), f"cfg1 block {k}: sum {sm} vs {float(g[f'sum_bf16emu_{k}'])}"
+        rep.append(f"{k} {e:.1e}/{ef:.1e}")
+    print("cfg1 full-size per-block slices, rel-L2 vs bf16emu / fp32 oracle: " + ", ".join(rep))
+
+
 def test_full_size_properties(cuda):
     """cfg2-sized call (B=4, 512 px): size-independent properties - finite output, batch independence
     (sample i of a batch == the same sample run alone), determinism."""

@@ -317,3 +317,76 @@ def test_attention_wide(cuda, case):
     out = ops.attention_wide(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, S, D, D ** -0.5)
     assert_close(out, ref, 4e-3, name)
     assert torch.equal(ops.attention_wide(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, S, D, D ** -0.5), out)
+
+
+# ------------------------------------------------------------------------------------------------ the fp16 build (libdiffute_hip_f16.so)
+def h16r(x):
+    """round to fp16 and back (fp32 container)"""
+    return x.to(torch.float16).to(torch.float32)
+
+
+def test_fp16_build_operators(cuda):
+    """The same sources compiled with -DDMX_F16 (fp16 storage, v_mfma_f32_32x32x16_f16; BASELINE configs[4]): conv3x3 with two
+    sources + time-embedding row bias + residual, linear + residual, GEGLU, GroupNorm + SiLU over a concat, LayerNorm, the
+    d = 64 attention (self, and cross with the ragged 577-key tail) and the wide-head attention of the VAE - each against
+    fp32 math on fp16-rounded inputs, rel-L2 <= 1e-3 (attention 2e-3: P is rounded to fp16, 2^-12 relative)."""
+    from diffute_amd import ops
+    H16 = torch.float16
+    with ops.element_type("fp16"):
+        assert ops.h16() == H16
+        nh = lambda x: ops.nchw_to_nhwc_bf16(x.to(cuda))                        # noqa: E731  (the build's 16-bit element)
+        nc = lambda y: ops.nhwc_bf16_to_nchw(y).cpu()                           # noqa: E731
+        # conv (K1 + K10 concat + epilogue)
+        B, Hh, Ww, C0, C1, Co = 2, 24, 24, 128, 64, 192
+        h = h16r(seeded((B, C0, Hh, Ww), 1)); s_ = h16r(seeded((B, C1, Hh, Ww), 2)); x = torch.cat([h, s_], 1)
+        w = h16r(seeded((Co, C0 + C1, 3, 3), 3, 1 / math.sqrt(9 * (C0 + C1)))); b = seeded((Co,), 4, 0.1)
+        temb = seeded((B, Co), 5); r = h16r(seeded((B, Co, Hh, Ww), 6))
+        ref = h16r(F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + r)
+        for tn, sk in ((0, 0), (3, 2), (7, 1), (11, 1)):
+            out = ops.conv_gemm(nh(h), ops.pack_conv_weight(w.to(cuda)), Co, x1=nh(s_), bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(),
+                                res=nh(r), force_tn=tn, force_splitk=sk)
+            assert out.dtype == H16
+            assert_close(nc(out), ref, TOL, f"fp16 conv tn={tn} sk={sk}")
+        # linear + residual, GEGLU
+        M, K, N = 577, 1024, 640
+        xl = h16r(seeded((M, K), 1)); wl = h16r(seeded((N, K), 2, 1 / math.sqrt(K))); bl = seeded((N,), 3, 0.1); rl = h16r(seeded((M, N), 4))
+        out = ops.linear(xl.to(cuda).to(H16), ops.pack_linear_weight(wl.to(cuda)), bias=bl.to(cuda), res=rl.to(cuda).to(H16))
+        assert_close(out, h16r(F.linear(xl, wl, bl) + rl), TOL, "fp16 linear")
+        M, C = 384, 128
+        xg = h16r(seeded((M, C), 1)); wg = h16r(seeded((8 * C, C), 2, 1 / math.sqrt(C))); bg = seeded((8 * C,), 3, 0.1)
+        gg = F.linear(xg, wg, bg); a_, gate = gg.chunk(2, dim=-1)
+        out = ops.linear(xg.to(cuda).to(H16), ops.pack_linear_weight(wg.to(cuda), geglu=True), bias=ops.pack_geglu_bias(bg.to(cuda)), geglu=True)
+        assert_close(out, h16r(a_ * F.gelu(gate)), TOL, "fp16 geglu")
+        # GroupNorm (+SiLU) over a two-source concat, slab and two-launch shapes; LayerNorm
+        for (Bg, Hg, Wg, Ca, Cb) in ((2, 8, 8, 640, 320), (1, 64, 64, 640, 0)):
+            x0 = h16r(seeded((Bg, Ca, Hg, Wg), 1) * 2 + 0.5); x1 = h16r(seeded((Bg, Cb, Hg, Wg), 2) * 0.5 - 1.0) if Cb else None
+            g = 1 + 0.1 * seeded((Ca + Cb,), 3); be = 0.1 * seeded((Ca + Cb,), 4)
+            refg = F.silu(F.group_norm(x0 if x1 is None else torch.cat([x0, x1], 1), 32, g, be, 1e-5))
+            out = ops.groupnorm(nh(x0), g.to(cuda), be.to(cuda), 32, 1e-5, True, x1=None if x1 is None else nh(x1))
+            assert_close(nc(out), h16r(refg), TOL, f"fp16 groupnorm {Ca}+{Cb} @ {Hg}x{Wg}")
+        xn = h16r(seeded((300, 640), 1) * 3 + 1); g = 1 + 0.1 * seeded((640,), 2); be = 0.1 * seeded((640,), 3)
+        assert_close(ops.layernorm(xn.to(cuda).to(H16), g.to(cuda), be.to(cuda)), h16r(F.layer_norm(xn, (640,), g, be, 1e-5)), TOL, "fp16 layernorm")
+        # attention d = 64: self (fused q|k|v buffer) and cross with the ragged 577-key tail
+        for (Ba, Ha, Sq, Skv) in ((2, 2, 256, 256), (2, 2, 256, 577)):
+            q = h16r(seeded((Ba, Sq, Ha * 64), 1)); k = h16r(seeded((Ba, Skv, Ha * 64), 2)); v = h16r(seeded((Ba, Skv, Ha * 64), 3))
+            k[0, 17] *= 6.0
+            qh = q.view(Ba, Sq, Ha, 64).transpose(1, 2); kh = k.view(Ba, Skv, Ha, 64).transpose(1, 2); vh = v.view(Ba, Skv, Ha, 64).transpose(1, 2)
+            refa = h16r((torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(Ba * Sq, Ha * 64))
+            Cc = Ha * 64
+            if Sq == Skv:
+                qkv = torch.cat([q, k, v], dim=-1).reshape(Ba * Sq, 3 * Cc).to(cuda).to(H16)
+                out = ops.attention_v(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], Ba, Ha, Sq, Skv, 0.125)
+            else:
+                pad = (Skv + 63) // 64 * 64
+                kp = torch.zeros(Ba, pad, Cc); kp[:, :Skv] = k
+                vp = torch.zeros(Ba, pad, Cc); vp[:, :Skv] = v
+                kv = torch.cat([kp, vp], dim=-1).reshape(Ba * pad, 2 * Cc).to(cuda).to(H16)
+                out = ops.attention_v(q.reshape(Ba * Sq, -1).to(cuda).to(H16), kv[:, :Cc], kv[:, Cc:], Ba, Ha, Sq, Skv, 0.125, kv_rows=pad)
+            assert_close(out, refa, 2e-3, f"fp16 attention Sq={Sq} Skv={Skv}")
+        # wide-head attention (VAE mid block)
+        Bw, Dw, Sw = 1, 512, 1024
+        q = h16r(seeded((Bw, Sw, Dw), 1)); k = h16r(seeded((Bw, Sw, Dw), 2)); v = h16r(seeded((Bw, Sw, Dw), 3))
+        k[0, 37] *= 5.0
+        refw = h16r((torch.softmax(q @ k.transpose(-1, -2) * Dw ** -0.5, -1) @ v).reshape(Bw * Sw, Dw))
+        qkv = torch.cat([q, k, v], dim=-1).reshape(Bw * Sw, 3 * Dw).to(cuda).to(H16)
+        assert_close(ops.attention_wide(qkv[:, :Dw], qkv[:, Dw:2 * Dw], qkv[:, 2 * Dw:], Bw, Sw, Sw, Dw, Dw ** -0.5), refw, 2e-3, "fp16 wide attention")
