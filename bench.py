@@ -27,16 +27,18 @@ if ROOT not in sys.path:
 # hipEvent bracketing costs about this much per launch in the profiled pass (measured: sum of bracketed launch times minus the
 # un-profiled pass time, divided by the launch count; round 1: (387 - 365) ms / 16 k launches); subtracted when ranking kernels
 EVENT_OVERHEAD_US = 1.4
-GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2>"), ("gemm_128x64x32", "<2, 1, 32, 4, 2, 0, 2>"), ("gemm_256x128x64", "<4, 2, 64, 3, 2, 0, 2>"),
-             ("gemm_128x64x64_deep", "<2, 1, 64, 6, 2, 0, 2>"), ("gemm_128x128x64_deep", "<2, 2, 64, 4, 2, 0, 2>"), ("gemm_256x256x32", "<4, 4, 32, 4, 2, 0, 2>"),
-             ("gemm_256x128x64_ws", "<2, 2, 64, 3, 4, 4, 2>"), ("gemm_128x64x64_8w", "<4, 1, 64, 3, 1, 0, 2>"), ("gemm_128x128x32_8w", "<4, 2, 32, 4, 1, 0, 2>"),
-             ("gemm_128x128x64_8w", "<4, 2, 64, 3, 1, 0, 2>"), ("gemm_128x160x64", "<4, 5, 64, 2, 1, 0, 1>"), ("gemm_128x320x64", "<4, 5, 64, 2, 1, 0, 2>")]
-LIN_CFGS = [("lin_128x160x64", "<1, 5, 64, 3, 2, false>"), ("lin_128x64x64", "<1, 2, 64, 4, 2, false>"), ("lin_128x256x32", "<2, 4, 32, 4, 1, false>")]
+# plan id -> (class name, template arguments of dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP, NWN, PS, MF>); ids 3-5 and 13 are retired
+GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2, false, 32>"), ("gemm_128x64x32", "<2, 1, 32, 4, 2, 0, 2, false, 32>"),
+             ("gemm_256x128x64", "<4, 2, 64, 3, 2, 0, 2, false, 32>"), ("retired_3", ""), ("retired_4", ""), ("retired_5", ""),
+             ("gemm_256x128x64_ws", "<2, 2, 64, 3, 4, 4, 2, false, 32>"), ("gemm_128x64x64_8w", "<4, 1, 64, 3, 1, 0, 2, false, 32>"),
+             ("gemm_128x128x32_8w", "<4, 2, 32, 4, 1, 0, 2, false, 32>"), ("gemm_128x128x64_8w", "<4, 2, 64, 3, 1, 0, 2, false, 32>"),
+             ("gemm_128x160x64", "<4, 5, 64, 2, 1, 0, 1, false, 32>"), ("gemm_128x320x64", "<4, 5, 64, 2, 1, 0, 2, false, 32>"),
+             ("streamk_256x160x64", "<8, 5, 64, 3, 1, 0, 1, true, 32>"), ("retired_13", ""),
+             ("streamk_256x128x64", "<8, 4, 64, 3, 1, 0, 1, true, 32>"), ("streamk_256x160x64_mf16", "<4, 5, 64, 3, 4, 0, 2, true, 16>")]
 KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % t for n, t in GEMM_CFGS}
-KERNEL_NAMES.update({n: "void dmx_lin_kernel%s(GemmArgs, int, int, int)" % t for n, t in LIN_CFGS})
 KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true, 1, 4>(AttnArgs)"
 PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
-                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS] + [n for n, _ in LIN_CFGS]
+                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS]
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
@@ -44,7 +46,7 @@ def pmc_traffic(kernel_name):
     """bytes per launch of `kernel_name` from the committed PMC summary (scripts/rocprof_to_profiles.py), or None"""
     import csv
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(here, f) for f in ("r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if os.path.exists(os.path.join(here, f))), None)
+    path = next((os.path.join(here, f) for f in ("r03_pmc_traffic.csv", "r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if os.path.exists(os.path.join(here, f))), None)
     if path is None:
         return None
     for r in csv.DictReader(open(path)):
@@ -166,7 +168,7 @@ def main():
         # which would otherwise penalise the classes with many short launches)
         def corrected_ms(k):
             return max(classes[k]["total_ms"] - classes[k]["launches"] * EVENT_OVERHEAD_US * 1e-3, 1e-6)
-        dom = max((k for k in classes if k.startswith("gemm") or k.startswith("lin_") or k == "attention_d64"), key=corrected_ms)
+        dom = max((k for k in classes if k.startswith("gemm") or k.startswith("streamk") or k == "attention_d64"), key=corrected_ms)
         n, ms, fl, by = buf[4 * PROF_CLASSES.index(dom):4 * PROF_CLASSES.index(dom) + 4]
         ms = corrected_ms(dom)
         ach = fl / (ms * 1e-3) / 1e12

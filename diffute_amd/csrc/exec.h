@@ -126,6 +126,9 @@ class Exec {
     if (ws.failed() && !rc) { dmx_set_error("workspace too small"); rc = DMX_ERR_WORKSPACE; }
     return p;
   }
+  // Persistent stream-K GEMMs (gemm.hip) need one zeroed int per block.  The first such GEMM of a forward takes a pool from
+  // the workspace and zeroes it with ONE memset node; every launch gets its own slice (a launch never reuses flags).
+  int* flag_pool = nullptr; size_t flag_cap = 0, flag_used = 0;
   void drop(const void* p) { ws.release(p); }
   void drop(const Tn& t) { drop((const void*)t.p); }
 

@@ -124,6 +124,15 @@ void Workspace::release(const void* p) {
 // --------------------------------------------------------------------------- Exec ops
 void Exec::run_gemm(GemmArgs& a) {
   if (rc) return;
+  if (const int pg = dmx_gemm_persist_blocks(a)) {
+    constexpr size_t POOL = 64 * 1024;                 // ints: 256 launches of 256 blocks
+    if (!flag_pool) {
+      flag_pool = (int*)raw(POOL * sizeof(int)); flag_cap = POOL; flag_used = 0;
+      if (!dry && !rc && hipMemsetAsync(flag_pool, 0, POOL * sizeof(int), stream) != hipSuccess) { dmx_set_error("flag pool memset failed"); rc = DMX_ERR_HIP; return; }
+    }
+    const size_t n = align_up((size_t)pg, 64);
+    if (flag_used + n <= flag_cap) { a.flags = flag_pool + flag_used; flag_used += n; }   // else: the launcher zeroes a slice of its own workspace
+  }
   const size_t wsb = dmx_gemm_workspace_bytes(a);
   void* w = wsb ? raw(wsb) : nullptr;
   if (!dry && !rc) rc = dmx_gemm_launch(a, w, wsb, stream);

@@ -54,41 +54,49 @@ struct RowSrc {          // per-thread state for one staged activation row
 __device__ __forceinline__ long long dmx_now(int dbg) {
   return (dbg & 4) ? (long long)__builtin_amdgcn_s_memtime() : (long long)__builtin_amdgcn_s_memrealtime();
 }
-template <int WM, int TN, int BKT, int NSTAGE, int TM = 2, int NP = 0, int NWN = 2>
+template <int WM, int TN, int BKT, int NSTAGE, int TM = 2, int NP = 0, int NWN = 2, bool PS = false, int MF = 32>
 __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2) void dmx_gemm_kernel(const GemmArgs p) {
   static_assert(NWN == 1 || NWN == 2, "one or two waves along n");
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * NWN;
+  // MF = MFMA fragment size: 32 -> v_mfma_f32_32x32x16 (wave tile 32 TM x 32 TN), 16 -> v_mfma_f32_16x16x32 (16 TM x 16 TN: the
+  // 64 x 80 wave tiles of the 256x160 persistent instance - 25 % fewer LDS fragment bytes per FLOP than 32 x 160 wave tiles)
+  static_assert(MF == 32 || (MF == 16 && TN == 5 && PS && NP == 0 && BKT == 64), "16x16 fragments: 160-column persistent instance only");
+  constexpr int NGRP = MF == 32 ? 4 : 1;               // float4 groups per accumulator fragment and lane
+  typedef float accv __attribute__((ext_vector_type(4 * NGRP)));
+  constexpr int BM = MF * TM * WM, BN = MF * TN * NWN;
   constexpr int NC = NWN * WM;                         // consumer (MFMA) waves: WM along m x NWN along n
   constexpr int NT = 64 * (NC + NP);                   // block threads
   constexpr int NL = NP ? 64 * NP : NT;                // threads that stage tiles (all of them unless warp-specialised)
   constexpr int CPR = BKT / 8;                         // 16-byte chunks per LDS row
   constexpr int ROWB = BKT * 2;                        // LDS row bytes
   constexpr int RSTEP = NL / CPR;                      // row distance between a thread's consecutive chunks
-  constexpr int XL = BM * CPR / NL, WL = BN * CPR / NL; // DMA loads per thread per K-tile (activations, weights)
+  constexpr int XL = BM * CPR / NL;                    // DMA loads per thread per K-tile (activations)
+  constexpr int WL = (BN * CPR + NL - 1) / NL;         // ... and weights; when BN*CPR is not a multiple of the staging threads (160 rows
+  constexpr int WREM = BN * CPR - NL * (WL - 1);       // over 512 threads) the last round covers WREM chunks: the upper waves repeat the lower
+                                                       // waves' loads (same bytes to the same LDS address) so every thread issues NLOADS
+  static_assert(BM * CPR % NL == 0 && (WREM & (WREM - 1)) == 0 && WREM % 64 == 0, "staging rounds");
   constexpr int NLOADS = XL + WL;
   constexpr int X_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = X_BYTES + W_BYTES;
-  constexpr int KSTEPS = BKT / 16;
+  constexpr int KSTEPS = BKT / (MF == 32 ? 16 : 32);   // MFMA k-steps per K-tile
+  constexpr int CPS = 64 / MF;                         // 16-byte k-chunks per k-step and fragment row (2 lane halves / 4 lane quarters)
   static_assert(XL >= 1 && WL >= 1, "tile too small for the block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto swz = [](int r) { return BKT == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); };
 
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   long long tm0 = 0, tm1 = 0, tm2 = 0;
   if (p.timing) tm0 = dmx_now(p.dbg);
-  const bool is_loader = (NP == 0) || wave >= NC, is_consumer = (NP == 0) || wave < NC;
-  const int lt = NP ? t - 64 * NC : t;                 // index among the staging threads (loaders only)
-  const int lwave = NP ? wave - NC : wave;
-  const int wm = wave % WM, wn = NWN == 2 ? (wave / WM) & 1 : 0;
 
-  // ---- block -> tile mapping.  Blocks are dealt round-robin to the 8 XCDs, so first give every XCD a contiguous
-  // range of tile ids, then rasterise that range in GROUP_M x tiles_n super-tiles: the blocks resident on one XCD at
-  // a time cover a compact (m, n) patch and share both their activation rows and their weight rows through that
-  // XCD's L2 (otherwise every n-tile of a conv re-reads the whole activation tensor from HBM / Infinity Cache).
-  int bid = blockIdx.x;
+  // ---- work items.  Classic launch: one block = one (tile, K-slice) - tile from blockIdx.x, split-K slice from blockIdx.y.
+  // Persistent stream-K launch (p.persist; grid = one block per CU): the flattened (tile, K-tile) iteration space is cut
+  // into gridDim.x equal contiguous ranges; a block walks its range tile by tile.  A range that starts inside a tile makes
+  // the block a HELPER for that tile (its first work item): it parks its fp32 accumulators in slab[position] and raises
+  // flag[position].  The block whose range holds the tile's K-tile 0 is the tile's OWNER: that item is the LAST of its
+  // range, so by then the helpers (who met the tile FIRST in theirs) are long done; it adds their slabs in K order (fixed
+  // order -> deterministic) and runs the epilogue.  No reduce pass, no tile quantisation.
+  // Blocks are dealt round-robin to the 8 XCDs, so first give every XCD a contiguous range (of tile ids / of the iteration
+  // space), then rasterise tile ids in GROUP_M x tiles_n super-tiles: the blocks resident on one XCD at a time cover a
+  // compact (m, n) patch and share both their activation rows and their weight rows through that XCD's L2 (otherwise
+  // every n-tile of a conv re-reads the whole activation tensor from HBM / Infinity Cache).
   const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
   // ups2 (phase-decomposed nearest-x2 upsample + 3x3 conv): the m-tiles are 4 phase blocks of tiles over the SOURCE grid
   const int Mlim = p.ups2 ? p.M4 : p.M;               // rows of the gathered operand (per phase)
   const int tiles_mp = (Mlim + BM - 1) / BM;
@@ -96,10 +104,55 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
   const int tiles_n = (p.N + BN - 1) / BN;
   const int gm = p.group_m > 0 ? p.group_m : 8;
   const int width = gm * tiles_n;
-  const int gid = bid / width;
+  const int nkt_total = p.K / BKT;
+  const int pos = ((nblk & 7) == 0) ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const long long it_total = (long long)tiles_m * tiles_n * nkt_total;
+  long long it, it_last;                               // [it, it_last): this block's part of the iteration space
+  // range boundary of position q: it_total * q / nblk, and a boundary that falls INSIDE a tile is moved PS_BIAS K-tiles later:
+  // the owner of a shared tile (the range holding its K-tile 0) gets a little more of it than the helpers, so the helpers have
+  // published their slabs by the time the owner's K loop ends (with equal shares - e.g. 2 blocks per tile - the owner sat
+  // waiting for the helper's store + release, measured ~4 us of a 46 us kernel)
+  constexpr int PS_BIAS = 2;
+  auto bound = [&](int q) -> long long {
+    long long b = it_total * q / nblk;
+    if (q > 0 && q < nblk) {
+      const long long r = b % nkt_total;
+      if (r != 0 && nkt_total >= 8 * PS_BIAS) b += (r + PS_BIAS < nkt_total) ? PS_BIAS : (nkt_total - 1 - r);
+    }
+    return b;
+  };
+  if constexpr (PS) {
+    it = bound(pos); it_last = bound(pos + 1);
+  } else {
+    int kb = 0, ke = nkt_total;
+    if (p.splitk > 1) { kb = blockIdx.y * p.kt_per_split; ke = min(kb + p.kt_per_split, nkt_total); }
+    it = (long long)pos * nkt_total + kb; it_last = it + (ke - kb);
+  }
+  bool later_item = false;
+  do {
+  // (persistent instances: the thread index is made opaque per work item, so nothing derived from it is hoisted out of the
+  // item loop and carried through the epilogue of every item - that costs 50+ VGPRs and spills)
+  int t = threadIdx.x;
+  if constexpr (PS) asm volatile("" : "+v"(t));
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool is_loader = (NP == 0) || wave >= NC, is_consumer = (NP == 0) || wave < NC;
+  const int lt = NP ? t - 64 * NC : t;                 // index among the staging threads (loaders only)
+  const int lwave = NP ? wave - NC : wave;
+  const int wm = wave % WM, wn = NWN == 2 ? (wave / WM) & 1 : 0;
+  const int tile_id = (int)(it / nkt_total);
+  const int kt_begin = (int)(it - (long long)tile_id * nkt_total);
+  const int kt_end = (int)min((long long)nkt_total, kt_begin + (it_last - it));
+  it += kt_end - kt_begin;
+  if (PS && later_item) {                              // the previous item's epilogue / slab pass is done with LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  later_item = true;
+  const int gid = tile_id / width;
   const int first_m = gid * gm;
   const int gsz = min(tiles_m - first_m, gm);
-  const int rem_id = bid - gid * width;
+  const int rem_id = tile_id - gid * width;
   const int tile_mv = first_m + rem_id % gsz;
   const int tile_n = rem_id / gsz;
   const int phase = p.ups2 ? tile_mv / tiles_mp : 0;   // (output row parity, output column parity)
@@ -113,13 +166,6 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
     const int q = m / p.IW;                            // n*IH + i
     return (size_t)2 * m + (size_t)2 * p.IW * q + (size_t)(pa * 2 * p.IW + pb);
   };
-
-  const int nkt_total = p.K / BKT;
-  int kt_begin = 0, kt_end = nkt_total;
-  if (p.splitk > 1) {
-    kt_begin = blockIdx.y * p.kt_per_split;
-    kt_end = min(kt_begin + p.kt_per_split, nkt_total);
-  }
 
   // ---- per-thread staging rows (loader threads): 16-byte chunk q = lt + NL*i -> row q/CPR, slot q%CPR
   const int slot = lt % CPR;
@@ -154,7 +200,8 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
   const char* wp[WL]; int winc[WL];
 #pragma unroll
   for (int i = 0; i < WL; ++i) {
-    const int r = lt / CPR + RSTEP * i;
+    const int ltw = (i == WL - 1) ? (lt & (WREM - 1)) : lt;
+    const int r = ltw / CPR + RSTEP * i;
     const int n = n0 + r;
     const int kc = (slot ^ swz(r)) * 8;
     if (n < p.N) { wp[i] = (const char*)(p.w + (size_t)phase * p.w_phase_stride + (size_t)n * p.ldw + (size_t)kt_begin * BKT + kc); winc[i] = ROWB; }
@@ -210,7 +257,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
       }
 #pragma unroll
       for (int i = 0; i < WL; ++i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(ws + (lwave * 64 + NL * i) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(ws + ((i == WL - 1 ? (lwave * 64) & (WREM - 1) : lwave * 64) + NL * i) * 16), 16, 0, 0);
         wp[i] += winc[i];
       }
       ++p_kt; --p_left;
@@ -221,28 +268,32 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
     }
   };
 
-  f32x16 acc[TN][TM];
+  accv acc[TN][TM];
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll
     for (int b = 0; b < TM; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 4 * NGRP; ++r) acc[a][b][r] = 0.f;
 
+  auto mfma_ = [](const bf16x8& w_, const bf16x8& x_, const accv& c_) -> accv {
+    if constexpr (MF == 32) return DMX_MFMA_32x32x16(w_, x_, c_);
+    else return DMX_MFMA_16x16x32(w_, x_, c_);
+  };
   // fragment read addresses for this lane (stage offset is an immediate: the loop is unrolled over the ring)
-  const int lr = lane & 31, lh = lane >> 5;
+  const int lr = lane & (MF - 1), lh = lane / MF;
   int xad[TM][KSTEPS], wad[TN][KSTEPS];
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
-    const int r = wm * (32 * TM) + b * 32 + lr;
+    const int r = wm * (MF * TM) + b * MF + lr;
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) xad[b][kk] = r * ROWB + (((2 * kk + lh) ^ swz(r)) << 4);
+    for (int kk = 0; kk < KSTEPS; ++kk) xad[b][kk] = r * ROWB + (((CPS * kk + lh) ^ swz(r)) << 4);
   }
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
-    const int r = wn * 32 * TN + a * 32 + lr;
+    const int r = wn * MF * TN + a * MF + lr;
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) wad[a][kk] = X_BYTES + r * ROWB + (((2 * kk + lh) ^ swz(r)) << 4);
+    for (int kk = 0; kk < KSTEPS; ++kk) wad[a][kk] = X_BYTES + r * ROWB + (((CPS * kk + lh) ^ swz(r)) << 4);
   }
   // MFMA phase of one K-tile.  Fragments are double-buffered in registers: the ds_reads of k-step kk+1 are issued
   // before the MFMAs of k-step kk, so LDS latency hides under the matrix pipe instead of serialising with it.
@@ -267,7 +318,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b)
-            acc[a][b] = DMX_MFMA_32x32x16(wf[cur][a], xf[cur][b], acc[a][b]);
+            acc[a][b] = mfma_(wf[cur][a], xf[cur][b], acc[a][b]);
         // pin the issue order the scheduler would otherwise undo: [ds_reads of k-step kk+1] then [MFMAs of kk]
         if (kk + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
@@ -284,9 +335,46 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b)
-            acc[a][b] = DMX_MFMA_32x32x16(wf[a], xf[b], acc[a][b]);
+            acc[a][b] = mfma_(wf[a], xf[b], acc[a][b]);
       }
     }
+  };
+
+  // MFMA phase of one K-tile for the ping-pong loop below: register double-buffered fragments for ANY wave tile (the ds_reads of
+  // k-step kk+1 ride in the gaps of the MFMAs of k-step kk, two per gap), s_setprio 1 around it so that this wave's MFMAs win
+  // the issue arbitration against its SIMD partner, which is in its DMA phase.
+  auto compute_pp = [&](const int J) {
+    const char* st = smem + J * STAGE;
+    bf16x8 xf[2][TM], wf[2][TN];
+    auto rd = [&](const int buf, const int kk) {
+#pragma unroll
+      for (int b = 0; b < TM; ++b) xf[buf][b] = *(const bf16x8*)(st + xad[b][kk]);
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[buf][a] = *(const bf16x8*)(st + wad[a][kk]);
+    };
+    rd(0, 0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      const int cur = kk & 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 1 < KSTEPS) rd(cur ^ 1, kk + 1);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+          acc[a][b] = mfma_(wf[cur][a], xf[cur][b], acc[a][b]);
+      if (kk + 1 < KSTEPS) {
+#pragma unroll
+        for (int q_ = 0; q_ < (TM + TN + 1) / 2; ++q_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN + 1) / 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- folded LayerNorm (consumer side): the GEMM runs on the RAW rows x with W' = W*diag(gamma); the epilogue
@@ -352,7 +440,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b)
-            acc[a][b] = DMX_MFMA_32x32x16(wf[buf][a], xf[buf][b], acc[a][b]);
+            acc[a][b] = mfma_(wf[buf][a], xf[buf][b], acc[a][b]);
       };
 #define DMX_SB __builtin_amdgcn_sched_barrier(0)
       // one scheduling region = [TM+TN ds_reads of the next fragment set] interleaved, two per gap, behind the first
@@ -392,6 +480,40 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
 #undef DMX_CSUB
 #undef DMX_SB
     }
+  } else if constexpr (PS) {
+    // ---- two-group ping-pong (persistent instances).  Waves w and w + NC/2 share a SIMD; group A = waves [0, NC/2), group B the
+    // rest.  Per K-tile every wave runs a DMA phase (its share of tile j+1 -> stage (j+1) % NSTAGE), a barrier, an MFMA phase
+    // (tile j), a barrier.  Both groups run the SAME instruction stream, but B takes one extra barrier up front (and A one at the
+    // end), so B is always one phase behind: on every SIMD one wave is in its MFMA phase while its partner issues LDS-DMA.  (An
+    // LDS-DMA instruction costs its wave ~60-180 issue cycles; in a lock-step loop both waves of a SIMD pay that at the same
+    // time and the matrix pipe idles: measured 1.29 us per 256x160x64 K-tile against 0.88 MFMA-only / 0.64 DMA-only.)
+    //   barrier k:   A: dma(j+1) |2j+1| mfma(j) |2j+2| ...        B: |1| ... dma(j+1) |2j+2| mfma(j) |2j+3| ...
+    // A wave confirms its pieces of tile j+1 (vmcnt(0)) at the END of mfma(j) - they were issued a whole phase earlier - so
+    // every piece of tile j+1 is confirmed by barrier 2j+3 at the latest (B's), the barrier before A's mfma(j+1).  Stage
+    // (j+1) % NSTAGE held tile j-2 (NSTAGE = 3), last read by B before barrier 2j-1; A refills it after barrier 2j.
+    static_assert(NSTAGE >= 3 && NC % 2 == 0, "ping-pong loop: three stages, an even number of waves");
+    const bool grpB = wave >= NC / 2;
+    advance_segment(); produce(0);
+    if (p.timing) tm1 = dmx_now(p.dbg);
+    if (grpB) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    int kt = kt_begin;
+#define DMX_PP(J)                                                                            \
+  {                                                                                          \
+    advance_segment();                                                                       \
+    if (!(p.dbg & 2)) produce((J + 1) % NSTAGE);                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");                            \
+    __builtin_amdgcn_s_barrier();                                                            \
+    if (!(p.dbg & 1)) compute_pp(J);                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_s_barrier();                                                            \
+    if (++kt >= kt_end) break;                                                               \
+  }
+    for (;;) {
+      DMX_PP(0) DMX_PP(1) DMX_PP(2)
+      if constexpr (NSTAGE >= 4) DMX_PP(3)
+    }
+#undef DMX_PP
+    if (!grpB) __builtin_amdgcn_s_barrier();           // (group B's extra barrier of the prologue)
   } else {
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) { advance_segment(); produce(s); }
@@ -418,21 +540,89 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
   }
   if (p.timing) tm2 = dmx_now(p.dbg);
 
+  // ---------------------------------------------------------------- stream-K fix-up (persistent launches)
+  // slab[position]: the block's accumulators in register order, [16*TN*TM/4 float4 groups][consumer thread] - every store /
+  // load is a fully coalesced 16 B per lane; no row-major staging.
+  constexpr int NCT = 64 * NC;                         // consumer threads
+  constexpr int SLAB_F4 = TN * TM * NGRP * NCT;           // float4 groups per slab (= BM*BN/4)
+  bool helper = false;
+  if constexpr (PS) {
+  __builtin_amdgcn_sched_barrier(0);                   // keep the epilogue's loads below the fix-up (register pressure)
+  if (kt_begin > 0) {
+    helper = true;
+    if (is_consumer) {
+      f32x4* sl = (f32x4*)p.partial + (size_t)pos * SLAB_F4 + t;
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int g = 0; g < NGRP; ++g) {
+            const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+            *sl = v; sl += NCT;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+    }
+    // publish: every wave's stores drained -> block barrier -> one agent-scope release -> the flag (cdna guide, Guideline 16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(p.flags + pos, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (kt_end < nkt_total) {
+    // owner of a tile whose K tail other blocks computed: positions pos+1 ... while their range starts inside this tile
+    const long long tile_end_it = (long long)(tile_id + 1) * nkt_total;
+    int q_end = pos + 1;
+    while (q_end < nblk && bound(q_end) < tile_end_it) ++q_end;
+    if (t == 0) {
+      for (int q = pos + 1; q < q_end; ++q)
+        while (__hip_atomic_load(p.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (is_consumer) {
+      for (int q = pos + 1; q < q_end; ++q) {
+        const f32x4* sl = (const f32x4*)p.partial + (size_t)q * SLAB_F4 + t;
+        // the block is alone on its CU and the slab comes from L2 / the fabric: what the pass costs is round trips, so all
+        // loads of a batch are issued before the first add (SB groups = 4*SB registers in flight)
+        constexpr int NG = TN * TM * NGRP, SB = NG % 5 == 0 ? 5 : 8;
+        static_assert(NG % SB == 0, "slab batches");
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += SB) {
+          f32x4 v[SB];
+#pragma unroll
+          for (int u = 0; u < SB; ++u) v[u] = sl[(size_t)(g0 + u) * NCT];
+#pragma unroll
+          for (int u = 0; u < SB; ++u) {
+            const int gi = g0 + u, ab = gi / NGRP, g = gi % NGRP, a = ab / TM, b = ab % TM;
+            acc[a][b][4 * g] += v[u][0]; acc[a][b][4 * g + 1] += v[u][1]; acc[a][b][4 * g + 2] += v[u][2]; acc[a][b][4 * g + 3] += v[u][3];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  }   // PS
   // ---------------------------------------------------------------- epilogue
   // acc[a][b][4g+e] = out[m = m0 + wm*64 + b*32 + lr][n = n0 + wn*32*TN + a*32 + 8g + 4lh + e]
-  if (p.splitk > 1) {
+  if (helper) {
+    // nothing more: the tile's owner finishes it
+  } else if (p.splitk > 1) {
     float* part = p.partial + (size_t)blockIdx.y * p.M * p.N;
     if (is_consumer)
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm * (32 * TM) + b * 32 + lr;
+        const int m = m0 + wm * (MF * TM) + b * MF + lr;
         if (m >= Mlim) continue;
         const size_t orow = out_row(m);                  // partials are kept in output-row order: the reduce pass needs no map
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * 32 * TN + a * 32 + 8 * g + 4 * lh;
+        for (int g = 0; g < NGRP; ++g) {
+          const int n = n0 + wn * MF * TN + a * MF + 8 * g + 4 * lh;
           float* o = part + orow * p.N + n;
           if (n + 3 < p.N && (p.N & 3) == 0) {
             f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
@@ -472,11 +662,11 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
           for (int a = 0; a < TN; ++a)
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-              const int r = (wm % (WM / EP)) * (32 * TM) + b * 32 + lr;
+              const int r = (wm % (WM / EP)) * (MF * TM) + b * MF + lr;
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
+              for (int g = 0; g < NGRP; ++g) {
                 const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-                *(f32x4*)(tile + r * LDT + wn * 32 * TN + a * 32 + 8 * g + 4 * lh) = v;
+                *(f32x4*)(tile + r * LDT + wn * MF * TN + a * MF + 8 * g + 4 * lh) = v;
               }
             }
         }
@@ -582,14 +772,14 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
     if (p.rowbias && is_consumer) {                    // uniform branch; columns past N are clamped (never stored)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        int m = m0 + wm * (32 * TM) + b * 32 + lr; if (m >= p.M) m = p.M - 1;
+        int m = m0 + wm * (MF * TM) + b * MF + lr; if (m >= p.M) m = p.M - 1;
         const float* rb = p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb;
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
           if (TN * TM > 4) asm volatile("" ::: "memory");   // wide tiles: do not hoist all 8 x 4 row-bias loads at once (VGPRs)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            int nn = n0 + wn * 32 * TN + a * 32 + 8 * g + 4 * lh; if (nn > p.N - 4) nn = p.N - 4;
+          for (int g = 0; g < NGRP; ++g) {
+            int nn = n0 + wn * MF * TN + a * MF + 8 * g + 4 * lh; if (nn > p.N - 4) nn = p.N - 4;
             const f32x4 bv = *(const f32x4*)(rb + nn);
             acc[a][b][4 * g] += bv[0]; acc[a][b][4 * g + 1] += bv[1]; acc[a][b][4 * g + 2] += bv[2]; acc[a][b][4 * g + 3] += bv[3];
           }
@@ -641,11 +831,11 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         for (int a = 0; a < TN; ++a)
 #pragma unroll
           for (int b = 0; b < TM; ++b) {
-            const int r = (EP == 1 ? wm * (32 * TM) : 0) + b * 32 + lr;
+            const int r = (EP == 1 ? wm * (MF * TM) : 0) + b * MF + lr;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < NGRP; ++g) {
               const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-              *(f32x4*)(tile + r * LDT + wn * 32 * TN + a * 32 + 8 * g + 4 * lh) = v;
+              *(f32x4*)(tile + r * LDT + wn * MF * TN + a * MF + 8 * g + 4 * lh) = v;
             }
           }
       }
@@ -755,13 +945,13 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm * (32 * TM) + b * 32 + lr;
+        const int m = m0 + wm * (MF * TM) + b * MF + lr;
         if (m >= Mlim) continue;
         const size_t orow = out_row(m);
         const float* rb = p.rowbias ? (p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb) : nullptr;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * 32 * TN + a * 32 + 8 * g + 4 * lh;
+        for (int g = 0; g < NGRP; ++g) {
+          const int n = n0 + wn * MF * TN + a * MF + 8 * g + 4 * lh;
           if (n >= p.N) continue;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -777,7 +967,8 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
       }
     (void)vec_ok;
   }
-  if (p.timing && t == 0) {        // measurement aid: per-block timeline in 10 ns ticks (s_memrealtime)
+  } while (PS && it < it_last);   // work items
+  if (p.timing && threadIdx.x == 0) {        // measurement aid: per-block timeline in 10 ns ticks (s_memrealtime)
     long long* o = p.timing + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
     o[0] = tm0; o[1] = tm1; o[2] = tm2; o[3] = dmx_now(p.dbg);
   }
@@ -842,7 +1033,7 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[12] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[16] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
@@ -859,20 +1050,54 @@ static const TileCfg kCfg[12] = {            // measured (scripts/gemm_timeline.
                                             // count of this UNet (320 k), so no column of a tile is wasted; force_tn = 11 / tuned table
     {128, 320, 64, 256, 2.00, 10.0},        // 128x320x64, eight waves (4 x 2), 32x160 sub-tiles, 2-buffer ring (112 KB, 1 block/CU): five whole
                                             // GEGLU groups per tile - the feed-forward GEMMs (N = 8C) tile without a partial round; force_tn = 12
+    // 12..14: PERSISTENT stream-K instances (one block per CU walks (tile, K-range) items, fix-up in the kernel, no reduce pass;
+    //         two-group ping-pong K loop over a 3+ stage ring):
+    {256, 160, 64, 256, 1.6, 8.0},          // 12: 256x160x64, eight waves in one column (32x160 sub-tiles), 3-stage ring (156 KB); force_tn = 13
+    {256, 256, 32, 256, 1.2, 9.0},          // 13: 256x256x32, eight waves (4 x 2) of 64x128 sub-tiles, 4-stage ring (128 KB); force_tn = 14
+    {256, 128, 64, 256, 1.3, 7.0},          // 14: 256x128x64, eight waves in one column (32x128 sub-tiles), 3-stage ring (144 KB); force_tn = 15
+    {256, 160, 64, 256, 1.4, 8.0},          // 15: 256x160x64 with 16x16x32 MFMAs: eight waves (4 x 2) of 64x80 sub-tiles, 3-stage ring; force_tn = 16
 };
+
+static bool cfg_persistent(int c) { return c >= 12; }
+
+// number of blocks of a persistent launch: one per CU, fewer when the iteration space is small (>= 4 K-tiles per block),
+// a multiple of 8 so the XCD-contiguous remap applies
+static int persist_grid(const GemmArgs& a, int c) {
+  static int n_cu = 0;
+  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+  const TileCfg& T = kCfg[c];
+  const long tiles = (long)(a.ups2 ? 4 * cdiv(a.M4, T.bm) : cdiv(a.M, T.bm)) * cdiv(a.N, T.bn);
+  const long total = tiles * (a.K / T.bk);
+  long g = total / 4; if (g > n_cu) g = n_cu; if (g < 1) g = 1;
+  if (g >= 8) g &= ~7L;
+  return (int)g;
+}
+
+// what an instance can run: K-tile alignment of every K segment, and what its epilogue covers
+static bool cfg_applicable(const GemmArgs& a, int c) {
+  const TileCfg& T = kCfg[c];
+  if (c == 3 || c == 4 || c == 5 || c == 13) return false;   // retired / unused instances (13: the 256x256 tile spills - 128 accumulators + the ping-pong loop) (EXPERIMENTS.md); ids kept so the tuned table's numbering is stable
+  if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) return false;
+  const bool col160 = (c == 10 || c == 11 || c == 12 || c == 15);   // the 160 / 320-column epilogue: bias | folded LayerNorm, row bias, residual (+ GEGLU on 320)
+  if (col160 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (c != 11 && a.geglu))) return false;
+  if (cfg_persistent(c) && ((a.N & 7) || a.out_f32)) return false;   // stream-K owners finish through the coalesced bf16 epilogue
+  return true;
+}
 
 static double plan_cost(const GemmArgs& a, int c, int sk) {
   const TileCfg& T = kCfg[c];
   const int nkt = a.K / T.bk;
   const long tiles = (long)cdiv(a.M, T.bm) * cdiv(a.N, T.bn);
+  if (cfg_persistent(c)) {                                     // every block gets total / grid K-tiles; ~2 tile boundaries per block
+    const int g = persist_grid(a, c);
+    return (double)cdiv((int)(tiles * nkt), g) * T.per_ktile + T.fixed * (1.0 + (double)tiles / g);
+  }
   const long nb = tiles * sk;
   const double t_block = cdiv(nkt, sk) * T.per_ktile + T.fixed;
   const int per_round = 256;                                   // CUs
   double rounds = (double)((nb + per_round - 1) / per_round);
   if (T.slots == 512) {                                        // two co-resident blocks overlap each other's stalls
     if (nb <= 256) rounds = 1.2; 
-  } else {
-    rounds *= 1.0;
   }
   double t = rounds * t_block;
   if (sk > 1) t += 12.0 + ((double)a.M * a.N * 4.0 * (sk + 1) / 5.0e12) / 0.45e-6;   // reduce pass: ~5 us + traffic
@@ -891,54 +1116,47 @@ void dmx_gemm_plan_override_set(int M, int N, int K, int st, int ups, int cfg, i
   g_plan_overrides.push_back(TunedPlan{M, N, K, 0, st, ups, cfg, sk});
 }
 
+// force_tn -> plan id: 1 -> 1 (128x64), 2 -> 0 (128x128), n >= 3 -> n - 1
+static int force_to_cfg(int force_tn) { return force_tn == 1 ? 1 : force_tn == 2 ? 0 : force_tn - 1; }
+
 void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_out) {
-  int best_c = 0, best_sk = 1; double best = 1e300;
+  const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act || (a.N % 4) != 0;   // those epilogues live in the GEMM kernel
+  auto take = [&](int c, int sk) -> bool {
+    if (c < 0 || c >= 16 || !cfg_applicable(a, c)) return false;
+    const int nkt = a.K / kCfg[c].bk;
+    if (cfg_persistent(c)) { *cfg_out = c; *splitk_out = 1; *ktps_out = nkt; return true; }
+    if (sk < 1 || (sk > 1 && (no_split || nkt / sk < 4))) return false;
+    const int ktps = cdiv(nkt, sk);
+    *cfg_out = c; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
+    return true;
+  };
   if (!a.force_tn && !a.force_splitk && (a.N % 4) == 0) {
-    const bool no_split = a.rowstats_out || a.ln_stats || a.geglu || a.act;
     for (const TunedPlan& tp : g_plan_overrides)
-      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && tp.cfg < 12 && !(tp.cfg >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
-          !(no_split && tp.sk > 1)) {
-        const int bk = kCfg[tp.cfg].bk, nkt = a.K / bk;
-        if (a.K % bk || a.Cin % bk || a.cx0 % bk || a.Ktaps % bk || (a.Ktaps < a.K && a.cs0 % bk) || tp.sk < 1 || (tp.sk > 1 && nkt / tp.sk < 4)) break;   // not applicable: normal plan
-        int ktps = cdiv(nkt, tp.sk);
-        *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
-        return;
+      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups)) {
+        if (take(tp.cfg, tp.sk)) return;
+        break;                                                 // not applicable: normal plan
       }
     for (const TunedPlan& tp : kTuned)      // keyed on the GEMM view (M, N, K) + gather flavour; tap structure does not matter
-      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) &&
-          tp.cfg < 12 && !(tp.cfg >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (tp.cfg == 10 && a.geglu))) &&
-          !(no_split && tp.sk > 1)) {
-        const int nkt = a.K / kCfg[tp.cfg].bk;
-        int ktps = cdiv(nkt, tp.sk);
-        *cfg_out = tp.cfg; *splitk_out = cdiv(nkt, ktps); *ktps_out = ktps;
-        return;
-      }
+      if (tp.M == a.M && tp.N == a.N && tp.K == a.K && tp.st == a.stride && tp.ups == (a.ups2 ? 2 : a.ups) && take(tp.cfg, tp.sk)) return;
   }
-  for (int c = 0; c < 12; ++c) {
+  int best_c = 0, best_sk = 1; double best = 1e300;
+  for (int c = 0; c < 16; ++c) {
     const TileCfg& T = kCfg[c];
-    if (c == 3 || c == 4 || c == 5) continue;            // retired instances (two-stage / deep-ring / 256x256x32 experiments, EXPERIMENTS.md); ids kept so the tuned table's numbering is stable
-    if (c >= 7 && !a.force_tn) continue;                 // eight-wave / 160-column instances: tuned table or force_tn only
-    if (a.K % T.bk != 0 || a.Cin % T.bk != 0 || a.cx0 % T.bk != 0 || a.Ktaps % T.bk != 0 || (a.Ktaps < a.K && a.cs0 % T.bk != 0)) continue;
-    if (a.force_tn == 1 && c != 1) continue;
-    if (a.force_tn == 2 && c != 0) continue;
-    if (a.force_tn == 3 && c != 2) continue;
-    if (a.force_tn == 7 && c != 6) continue;
-    if (a.force_tn == 8 && c != 7) continue;
-    if (a.force_tn == 9 && c != 8) continue;
-    if (a.force_tn == 10 && c != 9) continue;
-    if (a.force_tn == 11 && c != 10) continue;
-    if (a.force_tn == 12 && c != 11) continue;
-    if (c >= 10 && (a.rowstats_out || a.act || a.out_f32 || (a.N & 7) || (c == 10 && a.geglu))) continue;   // what their epilogue covers
-    if (!a.force_tn && c != 1 && c != 3 && a.N <= 64) continue;
-    if (!a.force_tn && (c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
-    // 3x3 convolutions over <= 128 input channels (the 512^2 / 256^2 levels of the autoencoder, K = 1152): the weight operand is
-    // as large as the activation operand per tile, so the 256-row tile's reuse buys nothing and its longer prologue / epilogue
-    // shows - measured at batch 32 (scripts/vae_conv_probe.py): 128->128 3.54 vs 3.79 ms, 128->256 1.61 vs 1.76 ms
-    if (!a.force_tn && c == 2 && a.ksize == 3 && !a.direct && a.Cin <= 128 && a.Ktaps == a.K) continue;
+    if (!cfg_applicable(a, c)) continue;
+    if (a.force_tn) { if (c != force_to_cfg(a.force_tn)) continue; }
+    else {
+      if (c >= 7) continue;                               // eight-wave / 160-column / persistent instances: tuned table or force_tn only
+      if (c != 1 && a.N <= 64) continue;
+      if ((c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
+      // 3x3 convolutions over <= 128 input channels (the 512^2 / 256^2 levels of the autoencoder, K = 1152): the weight operand is
+      // as large as the activation operand per tile, so the 256-row tile's reuse buys nothing and its longer prologue / epilogue
+      // shows - measured at batch 32 (scripts/vae_conv_probe.py): 128->128 3.54 vs 3.79 ms, 128->256 1.61 vs 1.76 ms
+      if (c == 2 && a.ksize == 3 && !a.direct && a.Cin <= 128 && a.Ktaps == a.K) continue;
+    }
     const int nkt = a.K / T.bk;
-    const int max_sk = (a.geglu || a.act || (a.N % 4) != 0 || a.rowstats_out || a.ln_stats) ? 1 : 16;   // those epilogues live in the GEMM kernel
+    const int max_sk = (no_split || cfg_persistent(c)) ? 1 : 16;
     for (int sk = 1; sk <= max_sk; ++sk) {
-      if (a.force_splitk && sk != a.force_splitk) continue;
+      if (a.force_splitk && sk != a.force_splitk && !cfg_persistent(c)) continue;
       if (sk > 1 && nkt / sk < (T.bk == 64 ? 4 : 8)) break;
       if (c == 6 && !a.force_tn && nkt / sk < 40) break;      // the warp-specialised loop pays off from ~2.5k of K per block
       const double cst = plan_cost(a, c, sk);
@@ -951,32 +1169,44 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
   *cfg_out = best_c; *splitk_out = best_sk; *ktps_out = ktps;
 }
 
+int dmx_gemm_persist_blocks(const GemmArgs& a) {
+  int c, sk, ktps;
+  dmx_gemm_plan(a, &c, &sk, &ktps);
+  return cfg_persistent(c) ? persist_grid(a, c) : 0;
+}
+
 int dmx_gemm_tiles_n(const GemmArgs& a) {
   int c, sk, ktps;
   dmx_gemm_plan(a, &c, &sk, &ktps);
   return cdiv(a.N, kCfg[c].bn);
 }
 
+// split-K: sk fp32 planes of the output.  Persistent stream-K: 256 bytes of flags per 64 blocks, then one accumulator slab per block.
+static size_t persist_flag_bytes(int grid) { return align_up((size_t)grid * sizeof(int), 256); }
 size_t dmx_gemm_workspace_bytes(const GemmArgs& a) {
   int c, sk, ktps;
   dmx_gemm_plan(a, &c, &sk, &ktps);
+  if (cfg_persistent(c)) {
+    const int g = persist_grid(a, c);
+    return persist_flag_bytes(g) + (size_t)g * kCfg[c].bm * kCfg[c].bn * sizeof(float);
+  }
   return sk > 1 ? (size_t)sk * a.M * a.N * sizeof(float) : 0;
 }
 
-template <int WM, int TN, int BKT, int NST, int TM = 2, int NP = 0, int NWN = 2>
+template <int WM, int TN, int BKT, int NST, int TM = 2, int NP = 0, int NWN = 2, bool PS = false, int MF = 32>
 static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * NWN;
+  constexpr int BM = MF * TM * WM, BN = MF * TN * NWN;
   size_t lds = (size_t)NST * (BM + BN) * BKT * 2;
   size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);             // fp32 staging tile of the coalesced epilogue
   if (TN == 5) lds_epi /= 2;                                           // the 160 / 320-column tiles stage half their rows per pass
-  else if (lds_epi > 152 * 1024) lds_epi /= WM;                            // (only the experimental 256x256 tile)                            // staged one 64-row slab at a time
+  else if (lds_epi > 152 * 1024) lds_epi /= WM;                        // the 256x256 tiles stage one 64-row slab (one wave row) per pass
   if (lds_epi > lds) lds = lds_epi;
   if (a.ln_stats || TN == 5) lds += (size_t)BM * 2 * sizeof(float);    // (mean, rstd) per row of the folded LayerNorm
   if (TN == 5) lds += (size_t)3 * BN * sizeof(float);                  // the tile's column vectors (160 / 320-column epilogue)
   static bool attr[64] = {};                          // the dynamic-LDS opt-in is per device
   int dev = 0; (void)hipGetDevice(&dev);
-  if (dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr[dev] = true; }
-  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN>), grid, dim3(64 * (NWN * WM + NP)), lds, stream, a);
+  if (dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float) > 163840 ? 163840 : lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr[dev] = true; }
+  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF>), grid, dim3(64 * (NWN * WM + NP)), lds, stream, a);
 }
 
 int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -996,12 +1226,28 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     DMX_REQUIRE(!a.res && !a.rowbias && !a.geglu && !a.act && !a.ln_stats && !a.rowstats_out, "gemm: the phase-decomposed upsample conv takes a bias only");
   }
   DMX_REQUIRE(a.force_tn < 4 || a.force_tn > 6, "gemm: tile instance %d was retired", a.force_tn);
+  if (a.force_tn) DMX_REQUIRE(a.force_tn <= 16 && cfg_applicable(a, force_to_cfg(a.force_tn)), "gemm: tile instance %d cannot run this problem (K-tile alignment / epilogue)", a.force_tn);
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;
   int c, sk, ktps;
   dmx_gemm_plan(a, &c, &sk, &ktps);
-  a.splitk = sk; a.kt_per_split = ktps;
-  if (sk > 1) {
+  a.splitk = sk; a.kt_per_split = ktps; a.persist = 0;
+  const TileCfg& T = kCfg[c];
+  dim3 grid((a.ups2 ? 4 * cdiv(a.M4, T.bm) : cdiv(a.M, T.bm)) * cdiv(a.N, T.bn), sk, 1);
+  if (cfg_persistent(c)) {
+    const int g = persist_grid(a, c);
+    const size_t fb = persist_flag_bytes(g), need = fb + (size_t)g * T.bm * T.bn * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) {
+      dmx_set_error("gemm: the persistent stream-K plan needs %zu bytes of workspace, got %zu", need, workspace_bytes);
+      return DMX_ERR_WORKSPACE;
+    }
+    a.persist = 1; a.partial = (float*)((char*)workspace + fb);
+    if (!a.flags) {                                            // standalone call: the executors hand out slices of a pool they zero once per forward
+      a.flags = (int*)workspace;
+      DMX_HIP(hipMemsetAsync(a.flags, 0, fb, stream));
+    }
+    grid = dim3(g, 1, 1);
+  } else if (sk > 1) {
     const size_t need = (size_t)sk * a.M * a.N * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) {
       dmx_set_error("gemm: split-K needs %zu bytes of workspace, got %zu", need, workspace_bytes);
@@ -1009,8 +1255,6 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     }
     a.partial = (float*)workspace;
   }
-  const TileCfg& T = kCfg[c];
-  dim3 grid((a.ups2 ? 4 * cdiv(a.M4, T.bm) : cdiv(a.M, T.bm)) * cdiv(a.N, T.bn), sk, 1);
   // algorithmic work of this launch: 2*M*N*K flops; bytes = activations read once + weights + output
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = 2.0 * ((double)(a.ups2 ? a.M4 : a.M) * (a.K / (a.direct ? 1 : (a.ksize * a.ksize))) + (double)a.N * a.K * (a.ups2 ? 4 : 1) + (double)a.M * (a.geglu ? a.N / 2 : a.N));
@@ -1026,7 +1270,11 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     else if (c == 8) launch_cfg<4, 2, 32, 4, 1>(a, grid, stream);
     else if (c == 9) launch_cfg<4, 2, 64, 3, 1>(a, grid, stream);
     else if (c == 10) launch_cfg<4, 5, 64, 2, 1, 0, 1>(a, grid, stream);
-    else launch_cfg<4, 5, 64, 2, 1, 0, 2>(a, grid, stream);
+    else if (c == 11) launch_cfg<4, 5, 64, 2, 1, 0, 2>(a, grid, stream);
+    else if (c == 12) launch_cfg<8, 5, 64, 3, 1, 0, 1, true>(a, grid, stream);
+    else if (c == 14) launch_cfg<8, 4, 64, 3, 1, 0, 1, true>(a, grid, stream);
+    else if (c == 15) launch_cfg<4, 5, 64, 3, 4, 0, 2, true, 16>(a, grid, stream);
+    else { dmx_set_error("gemm: plan id %d has no instance", c); return DMX_ERR_ARG; }
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;

@@ -7,7 +7,7 @@
 // Optional per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg).
 enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN = 3, PROF_GNORM = 4, PROF_LNORM = 5,
                  PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_WGRAD = 8, PROF_GEMM256WS = 9,
-                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_NCLASS = 25 };
+                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_NCLASS = 26 };
 struct ProfScope {
   ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag = nullptr);
   ~ProfScope();
@@ -51,6 +51,9 @@ struct GemmArgs {
   long long* timing;                           // optional per-block timeline (probe builds), normally null
   int dbg;                                     // measurement aid: bit0 skip the MFMA phase, bit1 skip the DMA refills (results invalid)
   float* partial; int splitk, kt_per_split;   // filled by the launcher
+  // persistent stream-K launch (filled by the launcher): grid = one block per CU walking (tile, K-range) items; `partial` holds
+  // one accumulator slab per block, `flags` one int per block, all zero at launch (see the kernel's work-item loop)
+  int persist; int* flags;
   const bf16* zeros;                           // filled by the launcher
 };
 int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
@@ -58,6 +61,7 @@ size_t dmx_gemm_workspace_bytes(const GemmArgs& a);
 void dmx_gemm_plan(const GemmArgs& a, int* tn, int* splitk, int* ktps);
 int dmx_zero_page(const bf16** out);
 void dmx_gemm_plan_override_set(int M, int N, int K, int st, int ups, int cfg, int sk);   // tuning aid; cfg < 0 clears all
+int dmx_gemm_persist_blocks(const GemmArgs& a);   // grid of the persistent stream-K plan this problem will run on, 0 for a classic plan
 int dmx_gemm_tiles_n(const GemmArgs& a);       // n-tiles of the plan that dmx_gemm_launch will pick (rowstats_out sizing)
 // W' = bf16(W*gamma) and the c1 / c2 vectors of the folded LayerNorm, from the raw bf16 weights (rows may be GEGLU-packed)
 // [4][N][4*Cin] phase weights of GemmArgs.ups2 from taps-major 3x3 weights [N][ldw3]

@@ -26,13 +26,14 @@ def main():
         import torch
         import torch.distributed as dist
         import diffute_amd as D
+        from diffute_amd import dist as DD
         from diffute_amd.models import mse_loss
         from diffute_amd.synthetic import synth_inputs
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         model = D.UNet2DConditionModel(**TINY_UNET).cuda()              # seeded init: the same weights on every rank
-        D.dist.broadcast_parameters(model.parameters(), dist, src=0, module=model)     # D3 anyway (train_diffute_v1.py:780)
+        DD.broadcast_parameters(model.parameters(), dist, src=0, module=model)     # D3 anyway (train_diffute_v1.py:780)
 
         def inputs(r):
             lat, mask, mlat, ctx = synth_inputs(1, 8, 8, 20, 128, seed=10 * r, device=dev)
@@ -53,7 +54,7 @@ def main():
         lr, gs = grads(rank)
         res["exposed_ms"] = model.exposed_exchange_ms()
         model.set_gradient_sync(None)
-        res["loss_mean"] = D.dist.gather_scalar(lr, dist, world)       # D2
+        res["loss_mean"] = DD.gather_scalar(lr, dist, world)       # D2
         res["loss_expected"] = (l0 + l1) / 2
         res["rel_err"] = float((gs - want).norm() / want.norm())
         res["max_abs_err"] = float((gs - want).abs().max())

@@ -62,7 +62,7 @@ def test_conv(cuda, case):
     assert_close(nchw(out), ref, TOL, name)
 
 
-@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2), (11, 1), (11, 2), (12, 1), (12, 2)])
+@pytest.mark.parametrize("tn,sk", [(1, 1), (2, 1), (3, 1), (3, 2), (2, 3), (1, 2), (7, 1), (7, 2), (8, 1), (8, 2), (9, 1), (9, 3), (10, 1), (10, 2), (11, 1), (11, 2), (12, 1), (12, 2), (13, 1), (15, 1), (16, 1)])
 def test_conv_every_tile_config(cuda, tn, sk):
     """All three tile configurations (128x64, 128x128, 256x128) and split-K give the same conv + epilogue."""
     from diffute_amd import ops
@@ -74,7 +74,11 @@ def test_conv_every_tile_config(cuda, tn, sk):
     out = ops.conv_gemm(nhwc(h, cuda), ops.pack_conv_weight(w.to(cuda)), Co, x1=nhwc(s_, cuda), bias=b.to(cuda),
                         rowbias=temb.to(cuda).contiguous(), res=nhwc(r, cuda), force_tn=tn, force_splitk=sk)
     assert_close(nchw(out), ref, TOL, f"conv tn={tn} sk={sk}")
-    if True:
+    if tn >= 13:      # persistent stream-K instances: partial tiles are finished in a fixed order -> bit-reproducible
+        again = ops.conv_gemm(nhwc(h, cuda), ops.pack_conv_weight(w.to(cuda)), Co, x1=nhwc(s_, cuda), bias=b.to(cuda),
+                              rowbias=temb.to(cuda).contiguous(), res=nhwc(r, cuda), force_tn=tn, force_splitk=sk)
+        assert torch.equal(again, out), f"conv tn={tn}: stream-K result differs between two runs"
+    if tn not in (11, 13, 16):      # (the 160-column tiles have no GEGLU epilogue)
         M, C = 640, 128
         xg = bf(seeded((M, C), 7)); wg = bf(seeded((8 * C, C), 8, 1 / math.sqrt(C))); bg = seeded((8 * C,), 9, 0.1)
         g = F.linear(xg, wg, bg); a_, gate = g.chunk(2, dim=-1)
@@ -112,6 +116,30 @@ def test_conv_ups2x_phase_decomposition(cuda, case):
         assert_close(nchw(out), bf(ref), tol, f"{name}: {what} vs torch")
         direct = ops.conv_gemm(nhwc(x, cuda), w3, Cout, ksize=3, pad=1, ups=True, bias=b.to(cuda))
         assert_close(nchw(out), nchw(direct), tol, f"{name}: {what} vs the direct upsample gather")
+
+
+STREAMK_CASES = [("conv_64x64_320", 4, 64, 64, 320, 320, 13), ("conv_64x64_256_w128", 4, 64, 64, 256, 256, 15),
+                 ("conv_32x32_640", 2, 32, 32, 640, 640, 13), ("conv_24x24_tails", 3, 24, 24, 192, 328, 13), ("conv_16x16_deepK_w128", 1, 16, 16, 1280, 512, 15),
+                 ("conv_64x64_320_mf16", 4, 64, 64, 320, 320, 16), ("conv_24x24_tails_mf16", 3, 24, 24, 192, 328, 16)]
+
+
+@pytest.mark.parametrize("case", STREAMK_CASES, ids=[c[0] for c in STREAMK_CASES])
+def test_streamk_persistent_conv(cuda, case):
+    """The persistent stream-K instances (one block per CU walks (tile, K-range) items; helpers park fp32 accumulator slabs, the
+    tile's owner adds them in K order and runs the epilogue) at grids where most tiles are shared by 2-4 blocks: conv3x3 + bias +
+    time-embedding row bias + residual against F.conv2d, against the classic plan, and twice for bit-reproducibility."""
+    from diffute_amd import ops
+    name, B, H, W, Cin, Co, tn = case
+    x = bf(seeded((B, Cin, H, W), 1)); w = bf(seeded((Co, Cin, 3, 3), 2, 1 / math.sqrt(9 * Cin))); b = seeded((Co,), 3, 0.1)
+    temb = seeded((B, Co), 5); r = bf(seeded((B, Co, H, W), 6))
+    ref = bf(F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + r)
+    xs = nhwc(x, cuda); wp = ops.pack_conv_weight(w.to(cuda)); rs = nhwc(r, cuda); tb = temb.to(cuda).contiguous()
+    out = ops.conv_gemm(xs, wp, Co, bias=b.to(cuda), rowbias=tb, res=rs, force_tn=tn)
+    assert_close(nchw(out), ref, TOL, f"{name} tn={tn} vs torch")
+    for _ in range(3):
+        assert torch.equal(ops.conv_gemm(xs, wp, Co, bias=b.to(cuda), rowbias=tb, res=rs, force_tn=tn), out), f"{name}: not bit-reproducible"
+    classic = ops.conv_gemm(xs, wp, Co, bias=b.to(cuda), rowbias=tb, res=rs)
+    assert_close(nchw(out), nchw(classic).float(), 3e-3, f"{name} tn={tn} vs the classic plan")
 
 
 def test_conv_concat_temb_shortcut(cuda):
@@ -165,7 +193,7 @@ def test_geglu(cuda):
     assert_close(out, ref, TOL, "geglu")
     # every tile instance with a GEGLU epilogue, incl. the 128x320 tile (5 whole packed groups, here with an N tail: 1024 = 3.2 tiles)
     x4 = x.to(cuda).to(torch.bfloat16).reshape(1, 1, M, C)
-    for tn in (1, 2, 3, 7, 8, 9, 10, 12):
+    for tn in (1, 2, 3, 7, 8, 9, 10, 12, 15):
         o = ops.conv_gemm(x4, ops.pack_linear_weight(w.to(cuda), geglu=True), 8 * C, ksize=1, pad=0, bias=ops.pack_geglu_bias(b.to(cuda)), geglu=True, force_tn=tn)
         assert_close(o.reshape(M, 4 * C), ref, TOL, f"geglu, tile instance {tn}")
 
