@@ -55,6 +55,76 @@ def pmc_traffic(kernel_name):
     return None
 
 
+def secondary_configs(dev, unet):
+    """One timed repetition (after one warm-up) of the other BASELINE configs and of the reference's own operating point, so the
+    driver sees them: cfg3 (AutoencoderKL encode + decode, 512 px, batch 32), the reference's loop (app.ipynb:545,806-816,914:
+    DDPMScheduler, 150 steps, batch 1 - weight-bandwidth bound, priced against HBM), cfg5 (768 px, 50 steps, batch 2, FP16: the
+    fp16 build of the library) and one cfg4 training step at the per-GPU shape (8 x 512 px, forward + backward + fused AdamW).
+    Builder-side detail: scripts/bench_extra.py, scripts/bench_train.py."""
+    import torch
+    import diffute_amd as D
+    from diffute_amd.flops import unet_flops
+    from diffute_amd.synthetic import synth_inputs, text_crop_images
+    out = {}
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, r
+
+    try:
+        # ---- the reference's operating point: B = 1, 150 DDPM steps (injected variance noise = the device randn it draws)
+        lat, mask, mlat, ctx = synth_inputs(1, 64, 64, 577, 1024, device=dev)
+        nz = torch.randn(150, 1, 4, 64, 64, device=dev)
+        t, o = timed(lambda: D.denoise(unet, D.DDPMScheduler(), lat, mask, mlat, ctx, 150, variance_noise=nz))
+        wbytes = 2.0 * sum(p.numel() for p in unet.parameters())
+        out["b1_ddpm150"] = {"config": "reference operating point: 512 px, batch 1, 150 DDPM steps, bf16 (app.ipynb:545,914)", "ms": round(t * 1e3, 1),
+                             "images_per_s": round(1 / t, 3), "ms_per_unet_step": round(t * 1e3 / 150, 3),
+                             "roofline": {"bound": "hbm", "achieved": round(wbytes * 150 / t / 1e9, 1), "peak": 6300.0, "unit": "GB/s",
+                                          "frac": round(wbytes * 150 / t / 6.3e12, 4), "note": "algorithmic bytes = the 1.73 GB of bf16 weights every UNet call must stream; peak = 6.3 TB/s achievable HBM"},
+                             "finite": bool(torch.isfinite(o).all())}
+        # ---- cfg5: 768 px, fp16 build
+        unet.to(dtype=torch.float16)
+        lat, mask, mlat, ctx = synth_inputs(2, 96, 96, 577, 1024, device=dev)
+        t, o = timed(lambda: D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 50))
+        fl = 50 * unet_flops(unet.config, 2, 96, 96, 577, True, phase_upsample=True)
+        out["cfg5_768px_fp16"] = {"config": "768x768, 50 DDIM steps, batch 2, fp16 (libdiffute_hip_f16.so)", "ms_per_batch": round(t * 1e3, 1), "images_per_s": round(2 / t, 3),
+                                  "loop_tflops": round(fl / t / 1e12, 1), "mfma_frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "finite": bool(torch.isfinite(o).all())}
+        unet.to(dtype=torch.bfloat16)
+        unet._slots = {}
+        torch.cuda.empty_cache()
+        # ---- cfg3: SD-VAE encode + decode, batch 32, 512 px
+        vae = D.AutoencoderKL(device=dev).requires_grad_(False)
+        img = text_crop_images(32, 512, 512, device=dev)
+        with torch.no_grad():
+            te, post = timed(lambda: vae.encode(img).latent_dist)
+            z = post.mode()
+            td, rec = timed(lambda: vae.decode(z).sample)
+        fe, fd = 1.1167e12 * 32, 2.5145e12 * 32
+        out["cfg3_vae_b32"] = {"config": "AutoencoderKL encode + decode, 512x512, batch 32, bf16", "encode_ms": round(te * 1e3, 1), "decode_ms": round(td * 1e3, 1),
+                               "images_per_s": round(32 / (te + td), 1), "tflops": round((fe + fd) / (te + td) / 1e12, 1),
+                               "mfma_frac": round((fe + fd) / (te + td) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "finite": bool(torch.isfinite(rec).all())}
+        del img, rec, z, post
+        torch.cuda.empty_cache()
+        # ---- cfg4 per-GPU shape: one training step (VAE encodes + forward + backward + clip + AdamW), 8 x 512 px
+        from diffute_amd.training import train_step
+        unet.requires_grad_(True)
+        opt = D.FusedAdamW(unet, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0)
+        g = torch.Generator(device=dev).manual_seed(5)
+        batch = dict(pixel_values=torch.rand(8, 3, 512, 512, device=dev, generator=g) * 2 - 1, masked_images=torch.rand(8, 3, 512, 512, device=dev, generator=g) * 2 - 1,
+                     masks=(torch.rand(8, 1, 512, 512, device=dev, generator=g) > 0.7).float(), ocr_embeddings=torch.randn(8, 577, 1024, device=dev, generator=g))
+        sched = D.DDPMScheduler()
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            t, r = timed(lambda: train_step(unet, vae, sched, opt, batch, generator=g))
+        out["cfg4_train_step_b8"] = {"config": "one training step at the cfg4 per-GPU shape: 8 x 512 px, bf16, VAE encodes + UNet forward + backward + clip + fused AdamW (1 GPU, no exchange)",
+                                     "ms_per_step": round(t * 1e3, 1), "images_per_s": round(8 / t, 2), "loss": float(r["loss"]),
+                                     "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+    except Exception as e:                                     # noqa: BLE001 - the headline line must still print
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +135,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--micro-batches", type=int, default=1, help="independent chains of the batch run concurrently on separate streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the one-rep timings of the other BASELINE configs (cfg3, cfg5, train step, B=1 DDPM-150)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-csv", default="", help="write one row per kernel launch of the profiled pass")
     ap.add_argument("--mode", choices=("denoise", "train"), default="denoise",
@@ -130,9 +201,8 @@ def main():
     assert torch.isfinite(out).all(), "non-finite latents"
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # executed work: the upsampler convs run phase-decomposed (4/9 of the reference formulation's multiply-adds) unless
-    # DMX_UPS_DIRECT pins the direct gather
-    loop_flops = T * unet_flops(unet.config, B, hw, hw, 577, True, phase_upsample="DMX_UPS_DIRECT" not in os.environ) + context_kv_flops(unet.config, B, 577)
+    # executed work: the upsampler convs run phase-decomposed (4/9 of the reference formulation's multiply-adds)
+    loop_flops = T * unet_flops(unet.config, B, hw, hw, 577, True, phase_upsample=True) + context_kv_flops(unet.config, B, 577)
     result = {
         "metric": "512x512 50-step denoise images/sec", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -205,6 +275,8 @@ def main():
                                   "sample": f"1 UNet forward (B=1, {hw * 8} px, fp32 torch-CPU oracle, {nthreads} threads) = "
                                             f"{t_fwd:.2f} s, x{T} steps extrapolated linearly",
                                   "gpu_vs_cpu_eps_rel_l2": round(rel, 5)}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        result["secondary"] = secondary_configs(dev, unet)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -27,7 +27,7 @@ class GemmDesc(ctypes.Structure):
         ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("geglu", c_int),
         ("force_tn", c_int), ("force_splitk", c_int), ("group_m", c_int), ("timing", c_void_p), ("dbg", c_int), ("act", c_int),
         ("rowstats_out", c_void_p), ("ln_stats", c_void_p), ("ln_tiles", c_int), ("ln_c1", c_void_p), ("ln_c2", c_void_p),
-        ("ln_C", c_int), ("ln_eps", c_float),
+        ("ln_C", c_int), ("ln_eps", c_float), ("colstats", c_void_p), ("cs_rows", c_int),
     ]
 
 
@@ -55,6 +55,9 @@ _PROTOS = {
     "dmx_conv_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "dmx_conv_gemm": (c_int, [POINTER(GemmDesc), _P, c_size_t, _P]),
     "dmx_conv_gemm_rowstats_tiles": (c_int, [POINTER(GemmDesc)]),
+    "dmx_conv_gemm_colstats_ok": (c_int, [POINTER(GemmDesc)]),
+    "dmx_set_gn_producer_stats": (c_int, [c_int]),
+    "dmx_groupnorm_from_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, _P, _P, c_int, _P]),
     "dmx_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(GemmDesc), c_int]),
     "dmx_conv_wgrad": (c_int, [POINTER(GemmDesc), _P, c_int, _P, c_int, _P, c_size_t, _P]),
     "dmx_colsum_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

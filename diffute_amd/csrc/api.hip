@@ -22,8 +22,10 @@ static GemmArgs to_args(const dmx_gemm_desc* d) {
   a.force_tn = d->force_tn; a.force_splitk = d->force_splitk; a.group_m = d->group_m; a.timing = d->timing; a.dbg = d->dbg; a.act = d->act;
   a.rowstats_out = d->rowstats_out; a.ln_stats = d->ln_stats; a.ln_tiles = d->ln_tiles; a.ln_c1 = d->ln_c1; a.ln_c2 = d->ln_c2;
   a.ln_C = d->ln_C; a.ln_eps = d->ln_eps;
+  a.colstats = d->colstats; a.cs_rows = d->cs_rows;
   return a;
 }
+extern "C" int dmx_conv_gemm_colstats_ok(const dmx_gemm_desc* d) { return d && dmx_gemm_colstats_ok(to_args(d)) ? 1 : 0; }
 extern "C" int dmx_conv_gemm_rowstats_tiles(const dmx_gemm_desc* d) {
   if (!d) return 0;
   GemmArgs a = to_args(d);
@@ -103,6 +105,16 @@ extern "C" int dmx_groupnorm(const void* x0, int ldx0, const void* x1, int ldx1,
   a.C = C; a.groups = groups; a.B = B; a.HW = HW; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
   a.y = (bf16*)y; a.ldy = ldy; a.partial = (float*)workspace;
   return dmx_groupnorm_launch(a, (hipStream_t)stream);
+}
+extern "C" int dmx_groupnorm_from_stats(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
+                                        int B, int HW, const float* gamma, const float* beta, float eps, int silu,
+                                        const long long* st0, const long long* st1, void* y, int ldy, dmx_stream_t stream) {
+  DMX_REQUIRE(x0 && y && gamma && beta && st0 && (!x1 || st1), "groupnorm_from_stats: null argument");
+  GroupNormArgs a{};
+  a.x0 = (const bf16*)x0; a.ldx0 = ldx0; a.x1 = (const bf16*)x1; a.ldx1 = ldx1; a.c0 = x1 ? c0 : C;
+  a.C = C; a.groups = groups; a.B = B; a.HW = HW; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
+  a.y = (bf16*)y; a.ldy = ldy; a.st0 = st0; a.st1 = x1 ? st1 : st0;
+  return dmx_groupnorm_sums_launch(a, (hipStream_t)stream);
 }
 extern "C" int dmx_groupnorm_train(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
                                    int B, int HW, const float* gamma, const float* beta, float eps, int silu,

@@ -79,6 +79,9 @@ int dmx_master_import(const ParamTable& pt, void* masters, const char* name, con
 
 struct Tn {                 // NHWC bf16 activation [B*H*W][C] with row stride ld
   bf16* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0;
+  // GroupNorm statistics of this tensor, written by the epilogue of the GEMM that produced it (GemmArgs.colstats): [B][C][2]
+  // fixed-point (sum, sum of squares); null when the producer could not emit them (split-K plans, fp32 mode, ...)
+  const long long* cst = nullptr;
   int rows() const { return B * H * W; }
 };
 
@@ -98,6 +101,7 @@ struct ConvOpts {
   const Tn* res = nullptr;
   const Tn* sc0 = nullptr; const Tn* sc1 = nullptr;   // fused 1x1 shortcut sources
   int out_f32 = 0;
+  int stats = 0;            // 1: emit the GroupNorm statistics of the output when the plan allows it (its next consumer is a GroupNorm)
 };
 
 class Exec {
@@ -129,6 +133,9 @@ class Exec {
   // Persistent stream-K GEMMs (gemm.hip) need one zeroed int per block.  The first such GEMM of a forward takes a pool from
   // the workspace and zeroes it with ONE memset node; every launch gets its own slice (a launch never reuses flags).
   int* flag_pool = nullptr; size_t flag_cap = 0, flag_used = 0;
+  // Statistics slices (Tn::cst) come from a pool zeroed once per forward as well (the producers ADD into them).
+  long long* cs_pool = nullptr; size_t cs_cap = 0, cs_used = 0;
+  void want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B);
   void drop(const void* p) { ws.release(p); }
   void drop(const Tn& t) { drop((const void*)t.p); }
 
@@ -142,7 +149,7 @@ class Exec {
   struct LnIn { const float* stats = nullptr; int tiles = 0; const float* c1 = nullptr; const float* c2 = nullptr; float eps = 1e-5f; };
   struct RowStats { float* buf = nullptr; int tiles = 0; };
   Tn linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu,
-            RowStats* rowstats = nullptr, const LnIn* ln = nullptr);
+            RowStats* rowstats = nullptr, const LnIn* ln = nullptr, bool gn_stats = false);
   // y = gelu(x W^T + b), exact erf GELU in the GEMM epilogue (ViT MLP)
   Tn linear_gelu(const Tn& x, const bf16* w, int N, const float* bias);
   // generic gemm on raw pointers (swapped-role V^T projection etc.)

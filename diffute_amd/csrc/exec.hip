@@ -122,6 +122,25 @@ void Workspace::release(const void* p) {
 }
 
 // --------------------------------------------------------------------------- Exec ops
+// tuning aid (A/B inside one process, like dmx_gemm_plan_override): 0 switches the producer-side GroupNorm statistics off
+static int g_gn_producer_stats = 1;
+extern "C" int dmx_set_gn_producer_stats(int on) { const int old = g_gn_producer_stats; g_gn_producer_stats = on; return old; }
+
+void Exec::want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B) {
+  if (rc || f32 || !g_gn_producer_stats) return;
+  a.cs_rows = rows_per_sample;
+  if (!dmx_gemm_colstats_ok(a)) { a.cs_rows = 0; return; }
+  if (!cs_pool) {
+    cs_cap = (size_t)B * 64 * 1024;                    // 64 k channels per sample over the forward (SD2 UNet: ~42 k) x 2 values
+    cs_pool = (long long*)raw(cs_cap * 2 * sizeof(long long)); cs_used = 0;
+    if (!dry && !rc && hipMemsetAsync(cs_pool, 0, cs_cap * 2 * sizeof(long long), stream) != hipSuccess) { dmx_set_error("statistics pool memset failed"); rc = DMX_ERR_HIP; return; }
+  }
+  const size_t n = (size_t)B * a.N;
+  if (cs_used + n > cs_cap) { a.cs_rows = 0; return; }        // pool exhausted: the consumer computes its own statistics
+  a.colstats = cs_pool + 2 * cs_used; cs_used += n;
+  y.cst = a.colstats;
+}
+
 void Exec::run_gemm(GemmArgs& a) {
   if (rc) return;
   if (const int pg = dmx_gemm_persist_blocks(a)) {
@@ -146,6 +165,20 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
     if (!dry && !rc)
       rc = dmx_groupnorm_f32_launch((const float*)x0.p, x0.ld, x0.C, x1 ? (const float*)x1->p : nullptr, x1 ? x1->ld : 0, C, groups, x0.B, x0.H * x0.W,
                                     gamma, beta, eps, silu ? 1 : 0, (float*)y.p, y.ld, stream);
+    return y;
+  }
+  if (x0.cst && (!x1 || x1->cst)) {                    // statistics came with the tensor(s): one apply-only launch
+    if (!dry && !rc) {
+      GroupNormArgs a{};
+      a.x0 = x0.p; a.ldx0 = x0.ld; a.c0 = x0.C;
+      a.x1 = x1 ? x1->p : nullptr; a.ldx1 = x1 ? x1->ld : 0;
+      a.C = C; a.groups = groups; a.B = x0.B; a.HW = x0.H * x0.W;
+      a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu ? 1 : 0;
+      a.y = y.p; a.ldy = y.ld; a.st0 = x0.cst; a.st1 = x1 ? x1->cst : x0.cst;
+      char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d sums", x0.rows(), C);
+      ProfScope ps(PROF_GNORM, stream, 0.0, 4.0 * (double)x0.rows() * C, tag);
+      rc = dmx_groupnorm_sums_launch(a, stream);
+    }
     return y;
   }
   const size_t pb = dmx_gn_workspace_bytes(x0.B, x0.H * x0.W, groups);
@@ -219,12 +252,13 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   a.bias = o.bias; a.rowbias = o.rowbias; a.rows_per_group = OH * OW; a.ldrb = o.ldrb;
   if (o.res) { a.res = o.res->p; a.ldres = o.res->ld; }
   a.out = o.out_f32 ? f32_out : (void*)y.p; a.ldo = Cout; a.out_f32 = o.out_f32;
+  if (o.stats && !o.out_f32) want_stats(a, y, (o.ups && o.ups2) ? x0.H * x0.W : OH * OW, x0.B);
   run_gemm(a);
   return y;
 }
 
 Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu,
-                RowStats* rowstats, const LnIn* ln) {
+                RowStats* rowstats, const LnIn* ln, bool gn_stats) {
   const int Nout = geglu ? N / 2 : N;
   Tn y = make(x.B, x.H, x.W, Nout);
   if (f32) {                                           // (the folded-LayerNorm / row-statistics protocol is a bf16-path fusion: callers normalise explicitly)
@@ -251,6 +285,7 @@ Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* 
     rowstats->buf = (float*)raw((size_t)rowstats->tiles * a.M * 2 * sizeof(float));
     a.rowstats_out = rowstats->buf;
   }
+  if (gn_stats && !geglu) want_stats(a, y, x.H * x.W, x.B);
   run_gemm(a);
   return y;
 }
@@ -365,13 +400,13 @@ Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn
   auto F = [&](size_t off) { return (const float*)(arena + off * (size_t)wmul); };
   auto H = [&](size_t off) { return (const bf16*)(arena + off * (size_t)wmul); };
   Tn t1 = ex.groupnorm(x0, x1, F(r.n1g), F(r.n1b), groups, eps, true);
-  ConvOpts o1; o1.bias = F(r.b1);
+  ConvOpts o1; o1.bias = F(r.b1); o1.stats = 1;        // norm2 reads conv1's output
   if (r.temb_off >= 0 && tproj) { o1.rowbias = tproj + r.temb_off; o1.ldrb = tproj_total; }
   Tn t2 = ex.conv(t1, nullptr, H(r.w1), r.cout, o1);
   ex.drop(t1);
   Tn t3 = ex.groupnorm(t2, nullptr, F(r.n2g), F(r.n2b), groups, eps, true);
   ex.drop(t2);
-  ConvOpts o2; o2.bias = F(r.b2);
+  ConvOpts o2; o2.bias = F(r.b2); o2.stats = 1;        // a GroupNorm comes next in every graph (next resnet / transformer / out norm)
   if (ex.f32 && r.shortcut) { o2.bias = F(r.b2raw); o2.bias2 = F(r.bscraw); }     // the folded bias is derived data: not in the master arena
   if (r.shortcut) { o2.sc0 = &x0; o2.sc1 = x1; } else { o2.res = &x0; }
   Tn y = ex.conv(t3, nullptr, H(r.w2), r.cout, o2);

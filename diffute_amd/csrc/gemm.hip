@@ -54,8 +54,10 @@ struct RowSrc {          // per-thread state for one staged activation row
 __device__ __forceinline__ long long dmx_now(int dbg) {
   return (dbg & 4) ? (long long)__builtin_amdgcn_s_memtime() : (long long)__builtin_amdgcn_s_memrealtime();
 }
-template <int WM, int TN, int BKT, int NSTAGE, int TM = 2, int NP = 0, int NWN = 2, bool PS = false, int MF = 32>
-__global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2) void dmx_gemm_kernel(const GemmArgs p) {
+// CS: this instance also emits the GroupNorm column statistics of its output (GemmArgs.colstats) - a separate instantiation so
+// that the 16 registers the partials cost do not touch the occupancy of the plain instances
+template <int WM, int TN, int BKT, int NSTAGE, int TM = 2, int NP = 0, int NWN = 2, bool PS = false, int MF = 32, bool CS = false>
+__global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : ((WM == 4 && TM == 1 && TN <= 2 && NP == 0 && NWN == 2) ? 4 : 2)) void dmx_gemm_kernel(const GemmArgs p) {
   static_assert(NWN == 1 || NWN == 2, "one or two waves along n");
   // MF = MFMA fragment size: 32 -> v_mfma_f32_32x32x16 (wave tile 32 TM x 32 TN), 16 -> v_mfma_f32_16x16x32 (16 TM x 16 TN: the
   // 64 x 80 wave tiles of the 256x160 persistent instance - 25 % fewer LDS fragment bytes per FLOP than 32 x 160 wave tiles)
@@ -606,6 +608,30 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
   }
   __builtin_amdgcn_sched_barrier(0);
   }   // PS
+  // ---- GroupNorm statistics of the tile's output (GemmArgs.colstats): per-channel (sum, sum of squares) of the ROUNDED outputs.
+  // Inside the tile everything is float arithmetic in a fixed order (per-thread partials over the thread's rows, then a fixed-
+  // order fold of the row lanes through LDS); across tiles the per-tile sums are added as 64-bit FIXED-POINT integers with
+  // global atomics (integer addition is associative: the totals are bit-reproducible whatever order the tiles finish in).
+  // colstats[(sample*N + n)*2 + {0,1}] += {sum * 2^20, sumsq * 2^32}; the buffer is zero before the launch.
+  auto publish_colstats = [&](const float* cs_s, const float* cs_q, int o, int rl, int nrl, bool active, float* red) {
+    __builtin_amdgcn_s_barrier();                      // every thread is done with the staged tile
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[(rl * BN + o * 8 + e) * 2] = cs_s[e]; red[(rl * BN + o * 8 + e) * 2 + 1] = cs_q[e]; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int c = t; c < BN; c += NT) {
+      if (n0 + c >= p.N) continue;
+      float sa = 0.f, sq = 0.f;
+      for (int k = 0; k < nrl; ++k) { sa += red[(k * BN + c) * 2]; sq += red[(k * BN + c) * 2 + 1]; }
+      const int smp = m0 / p.cs_rows;
+      long long* dst = p.colstats + ((size_t)smp * p.N + n0 + c) * 2;
+      const float sc = fminf(fmaxf(sa, -4.0e12f), 4.0e12f), qc = fminf(sq, 2.0e9f);
+      __hip_atomic_fetch_add(dst, (long long)(sc * 1048576.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(dst + 1, (long long)(qc * 4294967296.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   // ---------------------------------------------------------------- epilogue
   // acc[a][b][4g+e] = out[m = m0 + wm*64 + b*32 + lr][n = n0 + wn*32*TN + a*32 + 8g + 4lh + e]
   if (helper) {
@@ -654,10 +680,13 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         colv[BN + c] = p.ln_stats ? p.ln_c1[n] : 0.f;
         colv[2 * BN + c] = rb_one ? p.rowbias[(size_t)(m0 / p.rows_per_group) * p.ldrb + n] : 0.f;
       }
+      float cs_s[8], cs_q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
 #pragma unroll
       for (int ep = 0; ep < EP; ++ep) {
         __builtin_amdgcn_s_barrier();
-        if (wm / (WM / EP) == ep) {
+        if (is_consumer && wm / (WM / EP) == ep) {
 #pragma unroll
           for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -715,6 +744,53 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
               *(u32x4*)((bf16*)p.out + (size_t)m * p.ldo + (n0 >> 1) + 32 * Gg + jj) = pack_bf8(v);
             }
           }
+        } else if (CS && p.colstats) {
+          // statistics wanted: (row lane, octet) item mapping with the octet FIXED per thread (NT / OCP row lanes, a few threads
+          // idle, one partial sweep more) so the column partials accumulate in registers across sweeps and passes
+          constexpr int OCP = BN / 8, RL = NT / OCP, NITB = (RPP + RL - 1) / RL;
+          const bool act_t = t < RL * OCP;
+          const int o = t % OCP, rl = t / OCP;
+#pragma unroll
+          for (int u0 = 0; u0 < NITB; u0 += 3) {
+            f32x4 x0[3], x1[3]; u32x4 rr[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int r = min(rl + RL * (u0 + u), RPP - 1);
+              x0[u] = *(const f32x4*)(tile + r * LDT + o * 8); x1[u] = *(const f32x4*)(tile + r * LDT + o * 8 + 4);
+              if (p.res) {
+                int m = m0 + ep * RPP + r; if (m >= Mlim) m = Mlim - 1;
+                const int n = min(n0 + o * 8, p.N - 8);
+                rr[u] = *(const u32x4*)(p.res + (size_t)m * p.ldres + n);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int r = rl + RL * (u0 + u);
+              const int m = m0 + ep * RPP + r, n = n0 + o * 8;
+              if (u0 + u >= NITB || !act_t || r >= RPP || m >= Mlim || n >= p.N) continue;
+              float mean = 0.f, rstd = 1.f;
+              if (p.ln_stats) { mean = lnst[2 * (ep * RPP + r)]; rstd = lnst[2 * (ep * RPP + r) + 1]; }
+              float v[8];
+              affine(x0[u], x1[u], o * 8, mean, rstd, v);
+              if (p.rowbias) {
+                const float* rb = rb_one ? colv + 2 * BN + o * 8 : p.rowbias + (size_t)(m / p.rows_per_group) * p.ldrb + n;
+                const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+              }
+              if (p.res) {
+                float rf[8]; unpack_bf8(rr[u], rf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rf[e];
+              }
+              const u32x4 pk = pack_bf8(v);
+              *(u32x4*)((bf16*)p.out + out_row(m) * p.ldo + n) = pk;
+              float f[8]; unpack_bf8(pk, f);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { cs_s[e] += f[e]; cs_q[e] += f[e] * f[e]; }
+            }
+          }
+          if (ep == EP - 1) publish_colstats(cs_s, cs_q, o, rl, RL, act_t, tile);
         } else {
           constexpr int OCP = BN / 8;
           constexpr int NIT = RPP * OCP / NT;            // 5 for both instances (64 rows x 20 | 40 octets over 256 | 512 threads)
@@ -823,6 +899,9 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
     // spill reload after the first global store would wait for that store: vmcnt counts stores)
     constexpr bool LATE_COLS = (TN * TM > 4);
     if constexpr (!LATE_COLS) load_cols();
+    float cs_s[8], cs_q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
 #pragma unroll
     for (int ep = 0; ep < EP; ++ep) {
       __builtin_amdgcn_s_barrier();                    // K loop / previous pass is done with this LDS
@@ -908,6 +987,11 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
           }
           const u32x4 pk = pack_bf8(v);
           if (live) *(u32x4*)((bf16*)p.out + out_row(m) * p.ldo + n) = pk;
+          if (CS && p.colstats && live) {
+            float f[8]; unpack_bf8(pk, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cs_s[e] += f[e]; cs_q[e] += f[e] * f[e]; }
+          }
           if (p.rowstats_out) {
             // per-row (sum, sumsq) of the rounded outputs over this n-tile: the OC lanes of a row are adjacent lanes
             float f[8]; unpack_bf8(pk, f);
@@ -936,6 +1020,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : 2
         }
       }
     }
+    if (CS && p.colstats && !geglu) publish_colstats(cs_s, cs_q, o, t / OC, NT / OC, true, tile);
     }   // if constexpr (TN != 5)
   } else {
     // ---- generic epilogue (fp32 output, channel counts that are not multiples of 8): per-lane 4-channel groups
@@ -1169,6 +1254,15 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
   *cfg_out = best_c; *splitk_out = best_sk; *ktps_out = ktps;
 }
 
+bool dmx_gemm_colstats_ok(const GemmArgs& a) {
+  if (a.out_f32 || a.geglu || (a.N & 7) || (a.ldo & 7) || (a.res && (a.ldres & 7)) || a.cs_rows <= 0) return false;
+  int c, sk, ktps;
+  dmx_gemm_plan(a, &c, &sk, &ktps);
+  if (sk > 1 || c == 6) return false;                        // the reduce pass finishes those tiles; the warp-specialised instance has no twin
+  const int rows = a.ups2 ? a.M4 : a.M;
+  return a.cs_rows % kCfg[c].bm == 0 && rows % a.cs_rows == 0;
+}
+
 int dmx_gemm_persist_blocks(const GemmArgs& a) {
   int c, sk, ktps;
   dmx_gemm_plan(a, &c, &sk, &ktps);
@@ -1193,8 +1287,8 @@ size_t dmx_gemm_workspace_bytes(const GemmArgs& a) {
   return sk > 1 ? (size_t)sk * a.M * a.N * sizeof(float) : 0;
 }
 
-template <int WM, int TN, int BKT, int NST, int TM = 2, int NP = 0, int NWN = 2, bool PS = false, int MF = 32>
-static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+template <int WM, int TN, int BKT, int NST, int TM = 2, int NP = 0, int NWN = 2, bool PS = false, int MF = 32, bool CS = false>
+static void launch_cfg_(const GemmArgs& a, dim3 grid, hipStream_t stream) {
   constexpr int BM = MF * TM * WM, BN = MF * TN * NWN;
   size_t lds = (size_t)NST * (BM + BN) * BKT * 2;
   size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);             // fp32 staging tile of the coalesced epilogue
@@ -1205,8 +1299,15 @@ static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
   if (TN == 5) lds += (size_t)3 * BN * sizeof(float);                  // the tile's column vectors (160 / 320-column epilogue)
   static bool attr[64] = {};                          // the dynamic-LDS opt-in is per device
   int dev = 0; (void)hipGetDevice(&dev);
-  if (dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float) > 163840 ? 163840 : lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr[dev] = true; }
-  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF>), grid, dim3(64 * (NWN * WM + NP)), lds, stream, a);
+  if (dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float) > 163840 ? 163840 : lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr[dev] = true; }
+  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, CS>), grid, dim3(64 * (NWN * WM + NP)), lds, stream, a);
+}
+
+// the statistics-emitting twin of an instance is used exactly when GemmArgs.colstats is set (the warp-specialised instance has none)
+template <int WM, int TN, int BKT, int NST, int TM = 2, int NP = 0, int NWN = 2, bool PS = false, int MF = 32>
+static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+  if constexpr (NP == 0) { if (a.colstats) { launch_cfg_<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, true>(a, grid, stream); return; } }
+  launch_cfg_<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, false>(a, grid, stream);
 }
 
 int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -1226,6 +1327,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
     DMX_REQUIRE(!a.res && !a.rowbias && !a.geglu && !a.act && !a.ln_stats && !a.rowstats_out, "gemm: the phase-decomposed upsample conv takes a bias only");
   }
   DMX_REQUIRE(a.force_tn < 4 || a.force_tn > 6, "gemm: tile instance %d was retired", a.force_tn);
+  if (a.colstats) DMX_REQUIRE(dmx_gemm_colstats_ok(a), "gemm: this plan cannot emit column statistics (split-K, fp32 / GEGLU output or tiles straddling samples)");
   if (a.force_tn) DMX_REQUIRE(a.force_tn <= 16 && cfg_applicable(a, force_to_cfg(a.force_tn)), "gemm: tile instance %d cannot run this problem (K-tile alignment / epilogue)", a.force_tn);
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;

@@ -54,6 +54,11 @@ struct GemmArgs {
   // persistent stream-K launch (filled by the launcher): grid = one block per CU walking (tile, K-range) items; `partial` holds
   // one accumulator slab per block, `flags` one int per block, all zero at launch (see the kernel's work-item loop)
   int persist; int* flags;
+  // GroupNorm statistics of the output for its consumer (norm.hip dmx_groupnorm_sums_launch): per (sample, channel) 64-bit fixed-point
+  // (sum * 2^20, sum of squares * 2^32) of the rounded outputs, ADDED into colstats[(sample*N + n)*2 ..] (zero before the launch);
+  // cs_rows = rows per sample (a tile must not straddle samples: cs_rows % tile rows == 0).  Plans without a reduce pass only
+  // (dmx_gemm_colstats_ok); bf16 coalesced epilogues.
+  long long* colstats; int cs_rows;
   const bf16* zeros;                           // filled by the launcher
 };
 int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
@@ -61,6 +66,7 @@ size_t dmx_gemm_workspace_bytes(const GemmArgs& a);
 void dmx_gemm_plan(const GemmArgs& a, int* tn, int* splitk, int* ktps);
 int dmx_zero_page(const bf16** out);
 void dmx_gemm_plan_override_set(int M, int N, int K, int st, int ups, int cfg, int sk);   // tuning aid; cfg < 0 clears all
+bool dmx_gemm_colstats_ok(const GemmArgs& a);    // the plan this problem runs on can emit GemmArgs.colstats (a.cs_rows set)
 int dmx_gemm_persist_blocks(const GemmArgs& a);   // grid of the persistent stream-K plan this problem will run on, 0 for a classic plan
 int dmx_gemm_tiles_n(const GemmArgs& a);       // n-tiles of the plan that dmx_gemm_launch will pick (rowstats_out sizing)
 // W' = bf16(W*gamma) and the c1 / c2 vectors of the folded LayerNorm, from the raw bf16 weights (rows may be GEGLU-packed)
@@ -97,10 +103,14 @@ struct GroupNormArgs {
   float* partial;     // [B][nchunk][groups][2]
   float* stats_out;   // optional [B][groups][2] = (mean, rstd), kept for the backward pass (training)
   float* coef;        // [B][C][2] (filled by the launcher: lives behind partial in the workspace)
+  // statistics from the producers of x0 / x1 (GemmArgs.colstats of the GEMM that wrote each tensor): [B][channels of that
+  // tensor][2] fixed-point (sum * 2^20, sumsq * 2^32); dmx_groupnorm_sums_launch only
+  const long long* st0; const long long* st1;
   int nchunk, rows_per_chunk;
 };
 size_t dmx_gn_workspace_bytes(int B, int HW, int groups);
 int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream);
+int dmx_groupnorm_sums_launch(GroupNormArgs a, hipStream_t stream);   // statistics from the producers (a.st0 / a.st1): one apply-only launch
 bool dmx_gn_single_launch(GroupNormArgs a);   // the register-resident one-launch path applies to this shape
 int dmx_splitk_reduce_launch(const GemmArgs& a, hipStream_t stream);   // gemm.hip: the deferred reduce pass on its own
 int dmx_layernorm_launch(const bf16* x, int ldx, bf16* y, int ldy, const float* gamma, const float* beta,

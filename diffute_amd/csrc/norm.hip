@@ -83,7 +83,29 @@ __global__ __launch_bounds__(1024) void dmx_gn_apply_kernel(const GroupNormArgs 
   const int r = t / oc, co = t - r * oc;
   const int b = blockIdx.y;
   const int G = p.groups;
-  {
+  if (p.st0) {
+    // statistics from the PRODUCER of the tensor(s): per (sample, channel) fixed-point (sum * 2^20, sumsq * 2^32) written by the
+    // epilogue of the GEMM that produced x0 / x1 (gemm.hip publish_colstats) - no statistics pass over the tensor at all
+    extern __shared__ float csum[];                    // [C] sums, [C] sums of squares
+    for (int c = t; c < p.C; c += blockDim.x) {
+      const long long* q = (c < p.c0) ? p.st0 + ((size_t)b * p.c0 + c) * 2 : p.st1 + ((size_t)b * (p.C - p.c0) + (c - p.c0)) * 2;
+      csum[c] = (float)q[0] * (1.0f / 1048576.0f);
+      csum[p.C + c] = (float)((double)q[1] * (1.0 / 4294967296.0));
+    }
+    __syncthreads();
+    const int cpg = p.C / G;
+    if (t < G) {
+      float a = 0.f, q = 0.f;
+      for (int k = 0; k < cpg; ++k) { a += csum[t * cpg + k]; q += csum[p.C + t * cpg + k]; }
+      const float inv_n = 1.0f / ((float)p.HW * (float)cpg);
+      const float mean = a * inv_n;
+      float var = q * inv_n - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      MEAN[t] = mean; RSTD[t] = rsqrtf(var + p.eps);
+      if (p.stats_out && blockIdx.x == 0) { p.stats_out[((size_t)b * G + t) * 2] = mean; p.stats_out[((size_t)b * G + t) * 2 + 1] = RSTD[t]; }
+    }
+    __syncthreads();
+  } else {
     int slices = blockDim.x / G; if (slices > 16) slices = 16;
     const int g = t % G, sl = t / G;
     if (sl < slices) {
@@ -341,12 +363,29 @@ size_t dmx_gn_workspace_bytes(int B, int HW, int groups) {
   return (size_t)B * GN_MAX_CHUNKS * groups * 2 * sizeof(float) + (size_t)B * 2560 * 2 * sizeof(float);
 }
 
+// GroupNorm whose statistics come from the producers of x0 / x1 (GroupNormArgs.st0 / st1): ONE apply-only launch over all CUs
+int dmx_groupnorm_sums_launch(GroupNormArgs a, hipStream_t stream) {
+  DMX_REQUIRE(a.C % 8 == 0 && a.C % a.groups == 0 && a.C <= 2560 && a.groups <= 64, "groupnorm: C=%d / groups=%d unsupported", a.C, a.groups);
+  DMX_REQUIRE(a.c0 % 8 == 0 && a.ldx0 % 8 == 0 && a.ldy % 8 == 0, "groupnorm: strides/splits must be multiples of 8");
+  if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; a.st1 = a.st0; }
+  DMX_REQUIRE(a.st0 != nullptr && a.st1 != nullptr, "groupnorm: producer statistics missing");
+  const int oc = a.C / 8;
+  int R = 1024 / oc; if (R > 16) R = 16; if (R < 1) R = 1;
+  const int threads = oc * R;
+  int rpb = 8 * R;                                                  // up to 8 rows per thread
+  while (rpb > R && (long)cdiv(a.HW, rpb) * a.B < 512) rpb -= R;
+  a.partial = nullptr; a.nchunk = 0;
+  hipLaunchKernelGGL(dmx_gn_apply_kernel, dim3(cdiv(a.HW, rpb), a.B), dim3(threads), (size_t)2 * a.C * sizeof(float), stream, a, rpb);
+  return dmx_check_launch("dmx_gn_apply_kernel");
+}
+
 int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream) {
   DMX_REQUIRE(a.C % 8 == 0 && a.C % a.groups == 0, "groupnorm: C=%d must be a multiple of 8 and of groups=%d", a.C, a.groups);
   DMX_REQUIRE(a.C <= 2560 && a.groups <= 64, "groupnorm: C=%d > 2560 or groups > 64 unsupported", a.C);
   DMX_REQUIRE(a.c0 % 8 == 0 && a.ldx0 % 8 == 0 && a.ldy % 8 == 0, "groupnorm: strides/splits must be multiples of 8");
   DMX_REQUIRE(a.partial != nullptr, "groupnorm: partial workspace is null");
   if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; }
+  a.st0 = a.st1 = nullptr;
   if (!gn_two_pass_forced() && gn_slab_launch(a, stream)) return dmx_check_launch("dmx_gn_slab_kernel");
   // ---- two-launch path (slabs that do not fit the register budget, e.g. 1024-px images)
   // thread = (row lane r < R, channel octet); wide blocks so each thread walks only a few rows

@@ -321,7 +321,7 @@ struct Fwd {
     ex.drop(st3.buf);
     Tn h4 = ex.linear(g, u->at<bf16>(w.wf2), C, u->at<float>(w.bf2), &h3, false);
     ex.drop(g); ex.drop(h3);
-    Tn y = ex.linear(h4, u->at<bf16>(w.wpo), C, u->at<float>(w.bpo), &x, false);
+    Tn y = ex.linear(h4, u->at<bf16>(w.wpo), C, u->at<float>(w.bpo), &x, false, nullptr, nullptr, true);   // (+ GroupNorm statistics for the next block)
     ex.drop(h4);
     return y;
   }
@@ -400,7 +400,7 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
       a.B = B; a.IH = a.OH = H; a.IW = a.OW = W; a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = u->ci_kpad;
       ex.rc = dmx_im2col_small_launch(a, ex.stream);
     }
-    h = ex.linear(col, u->at<bf16>(u->ci_w), boc[0], u->at<float>(u->ci_b), nullptr, false);
+    h = ex.linear(col, u->at<bf16>(u->ci_w), boc[0], u->at<float>(u->ci_b), nullptr, false, nullptr, nullptr, true);
     ex.drop(col);
   }
   ex.tap(h);                                           // "conv_in"
@@ -418,7 +418,7 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
       h = y; skips.push_back(h);                      // previous h stays alive as a skip
     }
     if (i < 3) {
-      ConvOpts o; o.stride = 2; o.pad = 1; o.bias = f.W<float>(u->down_ds[i].b);
+      ConvOpts o; o.stride = 2; o.pad = 1; o.bias = f.W<float>(u->down_ds[i].b); o.stats = 1;
       h = ex.conv(h, nullptr, f.W<bf16>(u->down_ds[i].w), boc[i], o);
       skips.push_back(h);
     }
@@ -439,7 +439,7 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
     if (i < 3) {
       // nearest x2 + conv3x3 as four 2x2 phase convolutions on the source grid (pre-summed taps): 4/9 of the multiply-adds
       const bool direct = ex.f32;                                          // (the phase weights are derived data of the bf16 path)
-      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = f.W<float>(u->up_us[i].b);
+      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = f.W<float>(u->up_us[i].b); o.stats = 1;
       Tn y = ex.conv(h, nullptr, direct ? f.W<bf16>(u->up_us[i].w) : u->at<bf16>(u->up_us[i].wp), boc[3 - i], o);
       ex.drop(h); h = y;
     }

@@ -72,7 +72,7 @@ Tn attn_run(Exec& ex, const dmx_vae* v, const AttnW& w, const Tn& x, int G) {
     ex.rc = dmx_attention_wide_launch(aa, ex.stream);
   }
   ex.drop(qkv);
-  Tn y = ex.linear(a, v->W<bf16>(w.wo), C, v->W<float>(w.bo), &x, false);
+  Tn y = ex.linear(a, v->W<bf16>(w.wo), C, v->W<float>(w.bo), &x, false, nullptr, nullptr, true);
   ex.drop(a);
   return y;
 }
@@ -93,7 +93,7 @@ int vae_encode_run(dmx_vae* v, Exec& ex, const float* x, float* moments, int B, 
       a.ksize = 3; a.stride = 1; a.pad = 1; a.out = col.p; a.Kpad = v->e_in.kpad;
       ex.rc = dmx_im2col_small_launch(a, ex.stream);
     }
-    h = ex.linear(col, v->W<bf16>(v->e_in.w), c.block_out_channels[0], v->W<float>(v->e_in.b), nullptr, false);
+    h = ex.linear(col, v->W<bf16>(v->e_in.w), c.block_out_channels[0], v->W<float>(v->e_in.b), nullptr, false, nullptr, nullptr, true);
     ex.drop(col);
   }
   for (int i = 0; i < 4; ++i) {
@@ -102,7 +102,7 @@ int vae_encode_run(dmx_vae* v, Exec& ex, const float* x, float* moments, int B, 
       ex.drop(h); h = y;
     }
     if (i < 3) {                       // F.pad(h,(0,1,0,1)) + conv s2 p0: the gather's range check is the pad
-      ConvOpts o; o.stride = 2; o.pad = 0; o.bias = v->W<float>(v->e_ds[i].b);
+      ConvOpts o; o.stride = 2; o.pad = 0; o.bias = v->W<float>(v->e_ds[i].b); o.stats = 1;
       Tn y = ex.conv(h, nullptr, v->W<bf16>(v->e_ds[i].w), c.block_out_channels[i], o);
       ex.drop(h); h = y;
     }
@@ -168,7 +168,7 @@ int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, in
     ex.rc = dmx_im2col_small_launch(a, ex.stream);
   }
   ex.drop(z2);
-  h = ex.linear(col, v->W<bf16>(v->d_in.w), c.block_out_channels[3], v->W<float>(v->d_in.b), nullptr, false);
+  h = ex.linear(col, v->W<bf16>(v->d_in.w), c.block_out_channels[3], v->W<float>(v->d_in.b), nullptr, false, nullptr, nullptr, true);
   ex.drop(col);
   }
   { Tn y = resnet_run(ex, v->wbase(), v->d_mid[0], h, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(h);
@@ -182,7 +182,7 @@ int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, in
     if (i < 3) {
       // nearest x2 + conv3x3 as four 2x2 phase convolutions on the source grid (GemmArgs.ups2)
       const bool direct = ex.f32;                                          // (the phase weights are derived data of the bf16 path)
-      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = v->W<float>(v->d_us[i].b);
+      ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = v->W<float>(v->d_us[i].b); o.stats = 1;
       Tn y = ex.conv(h, nullptr, v->W<bf16>(direct ? v->d_us[i].w : v->d_us[i].wp), c.block_out_channels[3 - i], o);
       ex.drop(h); h = y;
     }

@@ -141,8 +141,10 @@ def conv_ups2x(x, wp, N, bias=None, force_tn=0, force_splitk=0):
 
 def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=None, rowbias=None,
               res=None, sc0=None, sc1=None, out_f32=False, geglu=False, direct=None, force_tn=0, force_splitk=0, timing=None, group_m=0, dbg=0, act=0,
-              rowstats=False, ln=None):
+              rowstats=False, ln=None, gn_stats=False):
     """Fused conv / linear.  x0 (and x1) NHWC bf16; w packed bf16 [N][K].  Returns NHWC (bf16 or fp32).
+    gn_stats=True: also returns the [B][N][2] int64 fixed-point (sum * 2^20, sumsq * 2^32) GroupNorm statistics of the output
+    (or None when the plan this problem runs on cannot emit them: split-K / tiles straddling samples).
     rowstats=True: also returns the per-row (sum, sumsq) partials [tiles][M][2] of the rounded output (folded-LayerNorm
     producer); ln=(stats, c1, c2, eps): folded-LayerNorm consumer (w must already be W*diag(gamma))."""
     B, H, W, C0 = x0.shape
@@ -187,9 +189,19 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
     if rowstats:
         stats = torch.empty(lib().dmx_conv_gemm_rowstats_tiles(ctypes.byref(d)), d.M, 2, dtype=torch.float32, device=x0.device)   # (every entry is written)
         d.rowstats_out = stats.data_ptr()
+    cst = None
+    if gn_stats:
+        d.cs_rows = OH * OW
+        if lib().dmx_conv_gemm_colstats_ok(ctypes.byref(d)):
+            cst = torch.zeros(B, N, 2, dtype=torch.int64, device=x0.device)
+            d.colstats = cst.data_ptr()
+        else:
+            d.cs_rows = 0
     wsb = lib().dmx_conv_gemm_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x0.device)
     check(lib().dmx_conv_gemm(ctypes.byref(d), ptr(ws), wsb, current_stream()), "conv_gemm")
+    if gn_stats:
+        return out, cst
     return (out, stats) if rowstats else out
 
 
@@ -258,6 +270,17 @@ def groupnorm(x0, gamma, beta, groups, eps, silu, x1=None):
     ws = torch.empty(wsb, dtype=torch.uint8, device=x0.device)
     check(lib().dmx_groupnorm(ptr(x0), _ld(x0), ptr(x1), _ld(x1) if x1 is not None else 0, C0, C, groups, B, H * W,
                               ptr(gamma), ptr(beta), float(eps), int(silu), ptr(y), C, ptr(ws), wsb, current_stream()), "groupnorm")
+    return y
+
+
+def groupnorm_from_stats(x0, st0, gamma, beta, groups, eps, silu, x1=None, st1=None):
+    """GroupNorm (+SiLU) whose statistics were emitted by the GEMM(s) that produced x0 / x1 (conv_gemm(..., gn_stats=True))"""
+    B, H, W, C0 = x0.shape
+    C = C0 + (x1.shape[-1] if x1 is not None else 0)
+    y = torch.empty(B, H, W, C, dtype=h16(), device=x0.device)
+    check(lib().dmx_groupnorm_from_stats(ptr(x0), _ld(x0), ptr(x1), _ld(x1) if x1 is not None else 0, C0, C, groups, B, H * W,
+                                         ptr(gamma), ptr(beta), float(eps), int(silu), ptr(st0), ptr(st1), ptr(y), C, current_stream()),
+          "groupnorm_from_stats")
     return y
 
 

@@ -88,8 +88,18 @@ typedef struct dmx_gemm_desc {
   float* rowstats_out;              /* producer side, or NULL                                                          */
   const float* ln_stats; int ln_tiles;   /* consumer side: the producer's partials and how many it wrote per row       */
   const float* ln_c1; const float* ln_c2; int ln_C; float ln_eps;   /* ln_C = normalised feature count (= K)           */
+  /* GroupNorm statistics from the producer (ResnetBlock2D norm1 / norm2, Transformer2DModel.norm and conv_norm_out behind
+   * unet(...), app.ipynb:814, and the same norms of AutoencoderKL): the conv / linear that WRITES a tensor also adds, per
+   * (sample, channel), the fixed-point sum * 2^20 and sum of squares * 2^32 of its rounded outputs into
+   * colstats[(sample*N + n)*2 + {0, 1}] (int64, zero before the call; cs_rows = rows per sample, a multiple of the plan's tile
+   * rows - dmx_conv_gemm_colstats_ok(d) says whether the plan this problem gets can do it).  The GroupNorm that READS the
+   * tensor is then dmx_groupnorm_from_stats: one apply-only pass, no statistics pass over the tensor. */
+  long long* colstats; int cs_rows;
 } dmx_gemm_desc;
 size_t dmx_conv_gemm_workspace_bytes(const dmx_gemm_desc* d);
+int dmx_set_gn_producer_stats(int on);                      /* tuning aid: 0 makes the model executors compute GroupNorm statistics in the
+                                                               consumer again (A/B runs inside one process); returns the old setting */
+int dmx_conv_gemm_colstats_ok(const dmx_gemm_desc* d);      /* 1 when dmx_conv_gemm(d) can fill d->colstats (d->cs_rows set)      */
 int dmx_conv_gemm_rowstats_tiles(const dmx_gemm_desc* d);   /* partials per row that dmx_conv_gemm(d) will write to rowstats_out */
 int dmx_conv_gemm(const dmx_gemm_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
@@ -128,6 +138,11 @@ size_t dmx_groupnorm_workspace_bytes(int B, int HW, int groups);
 int dmx_groupnorm(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
                   int B, int HW, const float* gamma, const float* beta, float eps, int silu,
                   void* y, int ldy, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+/* GroupNorm (+SiLU) with the statistics taken from the producers of x0 / x1: st0 = colstats of the GEMM that wrote x0
+ * ([B][c0][2] int64), st1 likewise for x1 ([B][C - c0][2]) or NULL without a second source.  One launch. */
+int dmx_groupnorm_from_stats(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
+                             int B, int HW, const float* gamma, const float* beta, float eps, int silu,
+                             const long long* st0, const long long* st1, void* y, int ldy, dmx_stream_t stream);
 
 /* Training (P5 over K3/K4/K8): forward GroupNorm that also keeps (mean, rstd) per (image, group), and the backward
  * kernels of GroupNorm(+SiLU), LayerNorm and the unfused GEGLU.  All deterministic.  `res*` is an optional gradient

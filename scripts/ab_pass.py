@@ -1,0 +1,45 @@
+"""A/B of a library switch inside ONE process and on one box: alternating timed 50-step passes with the switch on / off.
+    python scripts/ab_pass.py gn_stats [--rounds 4]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import diffute_amd as D  # noqa: E402
+from diffute_amd import _cabi  # noqa: E402
+from diffute_amd.synthetic import synth_inputs  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "gn_stats"
+rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 4
+dev = torch.device("cuda")
+lib = _cabi.lib()
+unet = D.UNet2DConditionModel(device=dev).requires_grad_(False)
+lat, mask, mlat, ctx = synth_inputs(4, 64, 64, 577, 1024, device=dev)
+
+
+def setting(on):
+    if what == "gn_stats":
+        lib.dmx_set_gn_producer_stats(int(on))
+    for sl in unet._slots.values():
+        sl["ws_need"] = None
+
+
+def timed():
+    D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 50)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 50)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 3 * 1e3
+
+
+res = {True: [], False: []}
+for r in range(rounds):
+    for on in (True, False):
+        setting(on)
+        res[on].append(timed())
+    print(f"round {r}: on {res[True][-1]:.1f} ms, off {res[False][-1]:.1f} ms", flush=True)
+print(f"{what}: on  min {min(res[True]):.1f} median {sorted(res[True])[len(res[True]) // 2]:.1f} ms per pass")
+print(f"{what}: off min {min(res[False]):.1f} median {sorted(res[False])[len(res[False]) // 2]:.1f} ms per pass")

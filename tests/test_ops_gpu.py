@@ -223,6 +223,50 @@ def test_groupnorm(cuda, case):
     assert_close(nchw(out), bf(ref), TOL, name)
 
 
+GNSTAT_CASES = [("conv_320_64x64_auto", 2, 64, 64, 320, 320, 0, 0), ("conv_320_64x64_streamk", 4, 64, 64, 320, 320, 13, 0), ("conv_320_64x64_mf16", 4, 64, 64, 320, 320, 16, 0),
+                ("conv_640_32x32_128x128", 2, 32, 32, 320, 640, 9, 1), ("conv_w160_concat", 2, 32, 32, 320, 640, 11, 1), ("conv_1280_16x16", 2, 16, 16, 640, 1280, 10, 1),
+                ("conv_128_32x32_small", 2, 32, 32, 64, 128, 1, 1)]
+
+
+@pytest.mark.parametrize("case", GNSTAT_CASES, ids=[c[0] for c in GNSTAT_CASES])
+def test_groupnorm_statistics_from_the_producer(cuda, case):
+    """K3 fused the way north_star asks: the conv that WRITES a tensor also emits its per-(sample, channel) sum and sum of squares
+    (fixed-point int64 atomics: bit-reproducible), and the GroupNorm + SiLU that READS it is one apply-only pass.  conv + temb
+    row bias + residual -> statistics vs the rounded output's own sums; GroupNorm from them vs F.group_norm(F.conv2d(...)),
+    alone and as the second source of a concat; twice for bit-reproducibility."""
+    from diffute_amd import ops
+    name, B, H, W, Cin, Co, tn, sk = case
+    x = bf(seeded((B, Cin, H, W), 1)); w = bf(seeded((Co, Cin, 3, 3), 2, 1 / math.sqrt(9 * Cin))); b = seeded((Co,), 3, 0.1)
+    temb = seeded((B, Co), 5); r = bf(seeded((B, Co, H, W), 6))
+    conv_ref = bf(F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + r)
+    kw = dict(bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(), res=nhwc(r, cuda), force_tn=tn, force_splitk=sk)
+    y, st = ops.conv_gemm(nhwc(x, cuda), ops.pack_conv_weight(w.to(cuda)), Co, gn_stats=True, **kw)
+    assert st is not None, f"{name}: this plan should be able to emit statistics"
+    assert_close(nchw(y), conv_ref, TOL, f"{name}: conv")
+    yf = nchw(y).double()
+    s_ref = yf.sum((2, 3)); q_ref = (yf * yf).sum((2, 3))                                  # [B][Co] of the ROUNDED output
+    s_hip = st[..., 0].cpu().double() / 2 ** 20; q_hip = st[..., 1].cpu().double() / 2 ** 32
+    assert float(((s_hip - s_ref).abs() / (1e-5 * yf.abs().sum((2, 3)) + 1e-4)).max()) <= 1.0, f"{name}: channel sums"
+    assert float(((q_hip - q_ref).abs() / q_ref).max()) <= 1e-5, f"{name}: channel sums of squares"
+    y2, st2 = ops.conv_gemm(nhwc(x, cuda), ops.pack_conv_weight(w.to(cuda)), Co, gn_stats=True, **kw)
+    assert torch.equal(y, y2) and torch.equal(st, st2), f"{name}: statistics are not bit-reproducible"
+    g = 1 + 0.1 * seeded((Co,), 7); be = 0.1 * seeded((Co,), 8)
+    out = ops.groupnorm_from_stats(y, st, g.to(cuda), be.to(cuda), 32, 1e-5, True)
+    ref = bf(F.silu(F.group_norm(nchw(y).float(), 32, g, be, 1e-5)))
+    assert_close(nchw(out), ref, TOL, f"{name}: GroupNorm + SiLU from the producer's statistics")
+    assert_close(nchw(out), nchw(ops.groupnorm(y, g.to(cuda), be.to(cuda), 32, 1e-5, True)).float(), TOL, f"{name}: vs the GroupNorm kernel with its own statistics")
+    # as the second source of a channel concat (UNet up path): [other | y] with a group that straddles the two tensors
+    C0 = 320 if (320 + Co) % 32 == 0 else Co
+    o_x = bf(seeded((B, C0, H, W), 9))
+    o_w = torch.zeros(C0, C0, 1, 1); o_w[torch.arange(C0), torch.arange(C0), 0, 0] = 1.0      # identity 1x1 conv: a producer for the other source
+    o_y, o_st = ops.conv_gemm(nhwc(o_x, cuda), ops.pack_conv_weight(o_w.to(cuda)), C0, ksize=1, pad=0, gn_stats=True)
+    if o_st is not None:
+        g2 = 1 + 0.1 * seeded((C0 + Co,), 10); b2 = 0.1 * seeded((C0 + Co,), 11)
+        out2 = ops.groupnorm_from_stats(o_y, o_st, g2.to(cuda), b2.to(cuda), 32, 1e-5, True, x1=y, st1=st)
+        ref2 = bf(F.silu(F.group_norm(torch.cat([nchw(o_y).float(), nchw(y).float()], 1), 32, g2, b2, 1e-5)))
+        assert_close(nchw(out2), ref2, TOL, f"{name}: concat GroupNorm from two producers' statistics")
+
+
 @pytest.mark.parametrize("C", [320, 640, 1280])
 def test_layernorm(cuda, C):
     from diffute_amd import ops
