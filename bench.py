@@ -35,7 +35,7 @@ GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2, false, 32>"), ("gemm_12
              ("gemm_128x160x64", "<4, 5, 64, 2, 1, 0, 1, false, 32>"), ("gemm_128x320x64", "<4, 5, 64, 2, 1, 0, 2, false, 32>"),
              ("streamk_256x160x64", "<8, 5, 64, 3, 1, 0, 1, true, 32>"), ("retired_13", ""),
              ("streamk_256x128x64", "<8, 4, 64, 3, 1, 0, 1, true, 32>"), ("streamk_256x160x64_mf16", "<4, 5, 64, 3, 4, 0, 2, true, 16>")]
-KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % t for n, t in GEMM_CFGS}
+KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % (t[:-1] + ", false>" if t else t) for n, t in GEMM_CFGS}      # (+ CS = false: the plain twin)
 KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true, 1, 4>(AttnArgs)"
 PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
                 "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS]

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
         const f32x4* sl = (const f32x4*)p.partial + (size_t)q * SLAB_F4 + t;
         // the block is alone on its CU and the slab comes from L2 / the fabric: what the pass costs is round trips, so all
         // loads of a batch are issued before the first add (SB groups = 4*SB registers in flight)
-        constexpr int NG = TN * TM * NGRP, SB = NG % 5 == 0 ? 5 : 8;
+        constexpr int NG = TN * TM * NGRP, SB = NG % 5 == 0 ? 5 : (NG % 8 == 0 ? 8 : 4);
         static_assert(NG % SB == 0, "slab batches");
 #pragma unroll
         for (int g0 = 0; g0 < NG; g0 += SB) {
@@ -1259,6 +1259,8 @@ bool dmx_gemm_colstats_ok(const GemmArgs& a) {
   int c, sk, ktps;
   dmx_gemm_plan(a, &c, &sk, &ktps);
   if (sk > 1 || c == 6) return false;                        // the reduce pass finishes those tiles; the warp-specialised instance has no twin
+  if (c == 12 || c == 15) return false;                      // persistent 160-column instances: the statistics cost the producer +5 us per launch
+                                                             // (measured in situ: 53.8 -> 59.1 us), as much as the consumer saves
   const int rows = a.ups2 ? a.M4 : a.M;
   return a.cs_rows % kCfg[c].bm == 0 && rows % a.cs_rows == 0;
 }
@@ -1306,7 +1308,7 @@ static void launch_cfg_(const GemmArgs& a, dim3 grid, hipStream_t stream) {
 // the statistics-emitting twin of an instance is used exactly when GemmArgs.colstats is set (the warp-specialised instance has none)
 template <int WM, int TN, int BKT, int NST, int TM = 2, int NP = 0, int NWN = 2, bool PS = false, int MF = 32>
 static void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-  if constexpr (NP == 0) { if (a.colstats) { launch_cfg_<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, true>(a, grid, stream); return; } }
+  if constexpr (NP == 0 && !(PS && TN == 5)) { if (a.colstats) { launch_cfg_<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, true>(a, grid, stream); return; } }
   launch_cfg_<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, false>(a, grid, stream);
 }
 

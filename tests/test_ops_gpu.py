@@ -223,7 +223,7 @@ def test_groupnorm(cuda, case):
     assert_close(nchw(out), bf(ref), TOL, name)
 
 
-GNSTAT_CASES = [("conv_320_64x64_auto", 2, 64, 64, 320, 320, 0, 0), ("conv_320_64x64_streamk", 4, 64, 64, 320, 320, 13, 0), ("conv_320_64x64_mf16", 4, 64, 64, 320, 320, 16, 0),
+GNSTAT_CASES = [("conv_320_64x64_8w", 2, 64, 64, 320, 320, 9, 1), ("conv_320_64x64_streamk_w128", 4, 64, 64, 256, 256, 15, 0),
                 ("conv_640_32x32_128x128", 2, 32, 32, 320, 640, 9, 1), ("conv_w160_concat", 2, 32, 32, 320, 640, 11, 1), ("conv_1280_16x16", 2, 16, 16, 640, 1280, 10, 1),
                 ("conv_128_32x32_small", 2, 32, 32, 64, 128, 1, 1)]
 
