@@ -1,16 +1,16 @@
-# Regenerates profiles/r02_*: rocprofv3 kernel stats of one bench pass + separate PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy),
+# Regenerates profiles/rNN_* (default r03): rocprofv3 kernel stats of one bench pass + separate PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy),
 # plus kernel-stat summaries of the secondary configurations (cfg3 VAE 32 x 512 px, cfg5 768 px loop, cfg4 per-GPU training step).
 # Run on the GPU box from the repo root: bash scripts/profile_round.sh ; outputs land in gpurun_out/ (copy the CSVs to profiles/).
 # Counter passes are separate runs with --pmc only (never combined with trace domains).
 R=$PWD
-P=${1:-r02}
+P=${1:-r03}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write /tmp/rp_mfma /tmp/rp_extra /tmp/rp_train
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o $P -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/rp_stats.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_write.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/rp_mfma -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile > $R/gpurun_out/rp_mfma.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o $P -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/rp_stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile --no-secondary > $R/gpurun_out/rp_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile --no-secondary > $R/gpurun_out/rp_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/rp_mfma -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile --no-secondary > $R/gpurun_out/rp_mfma.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_extra -o $P -- python3 $R/scripts/bench_extra.py --skip-vit > $R/gpurun_out/${P}_cfg3_cfg5.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_train -o $P -- python3 $R/scripts/bench_train.py --steps 2 --warmup 1 > $R/gpurun_out/${P}_train.log 2>&1
 cd $R

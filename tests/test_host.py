@@ -116,10 +116,36 @@ def test_cabi_exports_every_declared_symbol():
     from diffute_amd import _cabi
     hdr = open(os.path.join(ROOT, "include", "diffute_hip.h")).read()
     declared = set(re.findall(r"\b(dmx_[a-z0-9_]+)\s*\(", hdr))
-    lib = _cabi.lib()
-    for sym in declared:
-        assert hasattr(lib, sym), f"{sym} declared in include/diffute_hip.h but not exported"
+    for elem in ("bf16", "fp16"):          # the two builds of the same sources (libdiffute_hip.so, libdiffute_hip_f16.so)
+        lib = _cabi.lib(elem)
+        for sym in declared:
+            assert hasattr(lib, sym), f"{sym} declared in include/diffute_hip.h but not exported by the {elem} build"
+        assert lib.dmx_element_type().decode() == elem
     assert declared == set(_cabi.exported_symbols())
+
+
+def test_dtype_selects_the_build():
+    """`.to(dtype=torch.float16)` (vae.to(device, dtype=weight_dtype), train_diffute_v1.py:789-797) moves a model to the fp16 build;
+    bf16 / fp32 requests stay on the bf16 build; the Parameters (fp32 masters) are untouched by the switch."""
+    import diffute_amd as D
+    u = D.UNet2DConditionModel(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128)
+    before = {k: v.clone() for k, v in u.state_dict().items()}
+    assert u.compute_dtype == torch.bfloat16
+    u.to(dtype=torch.float16)
+    assert u.compute_dtype == torch.float16 and u.dtype == torch.float16 and u._lib is _cabi_lib("fp16")
+    u.to(dtype=torch.float32)
+    assert u.compute_dtype == torch.bfloat16 and u._lib is _cabi_lib("bf16")
+    after = u.state_dict()
+    assert all(torch.equal(before[k], after[k]) and after[k].dtype == torch.float32 for k in before)
+    v = D.AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=1).to("cpu", dtype=torch.float16)
+    assert v.compute_dtype == torch.float16
+    with pytest.raises(NotImplementedError):
+        D.AutoencoderKL(block_out_channels=(64, 128, 128, 192), layers_per_block=1)      # mid-block width outside 128 / 256 / 512
+
+
+def _cabi_lib(elem):
+    from diffute_amd import _cabi
+    return _cabi.lib(elem)
 
 
 def test_error_paths_without_gpu():
