@@ -482,8 +482,8 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
 #undef DMX_CSUB
 #undef DMX_SB
     }
-  } else if constexpr (PS) {
-    // ---- two-group ping-pong (persistent instances).  Waves w and w + NC/2 share a SIMD; group A = waves [0, NC/2), group B the
+  } else if constexpr (PS && BM >= 256) {
+    // ---- two-group ping-pong (persistent big-tile instances).  Waves w and w + NC/2 share a SIMD; group A = waves [0, NC/2), group B the
     // rest.  Per K-tile every wave runs a DMA phase (its share of tile j+1 -> stage (j+1) % NSTAGE), a barrier, an MFMA phase
     // (tile j), a barrier.  Both groups run the SAME instruction stream, but B takes one extra barrier up front (and A one at the
     // end), so B is always one phase behind: on every SIMD one wave is in its MFMA phase while its partner issues LDS-DMA.  (An
@@ -553,7 +553,10 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
   if (kt_begin > 0) {
     helper = true;
     if (is_consumer) {
-      f32x4* sl = (f32x4*)p.partial + (size_t)pos * SLAB_F4 + t;
+      // WRITE-THROUGH (sc1) 16-byte stores: the slab leaves this XCD's L2 as it is written, so publishing it needs no agent-scope
+      // release (buffer_wbl2 walks the whole L2: ~2 us clean, 6+ us with the slab freshly dirty - cdna guide, "publish-large")
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((f32x4*)p.partial + (size_t)pos * SLAB_F4), 0, SLAB_F4 * 16, 0x00020000);
+      int off = t * 16;
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -561,18 +564,15 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
 #pragma unroll
           for (int g = 0; g < NGRP; ++g) {
             const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-            *sl = v; sl += NCT;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 16);
+            off += NCT * 16;
             __builtin_amdgcn_sched_barrier(0);
           }
     }
-    // publish: every wave's stores drained -> block barrier -> one agent-scope release -> the flag (cdna guide, Guideline 16)
+    // publish: every wave's write-through stores drained -> block barrier -> the flag (relaxed, agent scope)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(p.flags + pos, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (t == 0) __hip_atomic_store(p.flags + pos, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else if (kt_end < nkt_total) {
     // owner of a tile whose K tail other blocks computed: positions pos+1 ... while their range starts inside this tile
     const long long tile_end_it = (long long)(tile_id + 1) * nkt_total;
@@ -581,12 +581,13 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
     if (t == 0) {
       for (int q = pos + 1; q < q_end; ++q)
         while (__hip_atomic_load(p.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (is_consumer) {
       for (int q = pos + 1; q < q_end; ++q) {
-        const f32x4* sl = (const f32x4*)p.partial + (size_t)q * SLAB_F4 + t;
+        // the slabs were stored write-through (sc1), so sc1 loads (L1 bypassed, served by L2 / the fabric) see them without an
+        // agent-scope acquire (buffer_inv: ~1.7 us per block) - cdna guide, Guideline 16 R1
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((f32x4*)p.partial + (size_t)q * SLAB_F4), 0, SLAB_F4 * 16, 0x00020000);
         // the block is alone on its CU and the slab comes from L2 / the fabric: what the pass costs is round trips, so all
         // loads of a batch are issued before the first add (SB groups = 4*SB registers in flight)
         constexpr int NG = TN * TM * NGRP, SB = NG % 5 == 0 ? 5 : (NG % 8 == 0 ? 8 : 4);
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
         for (int g0 = 0; g0 < NG; g0 += SB) {
           f32x4 v[SB];
 #pragma unroll
-          for (int u = 0; u < SB; ++u) v[u] = sl[(size_t)(g0 + u) * NCT];
+          for (int u = 0; u < SB; ++u) v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (t + (g0 + u) * NCT) * 16, 0, 16));
 #pragma unroll
           for (int u = 0; u < SB; ++u) {
             const int gi = g0 + u, ab = gi / NGRP, g = gi % NGRP, a = ab / TM, b = ab % TM;
