@@ -38,7 +38,7 @@ GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2, false, 32>"), ("gemm_12
 KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % (t[:-1] + ", false>" if t else t) for n, t in GEMM_CFGS}      # (+ CS = false: the plain twin)
 KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true, 1, 4>(AttnArgs)"
 PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
-                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS]
+                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS] + ["xf_chain"]
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 

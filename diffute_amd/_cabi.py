@@ -16,6 +16,16 @@ _lib = None
 _lib_f16 = None
 
 
+class XfChainDesc(ctypes.Structure):
+    _fields_ = [
+        ("M", c_int), ("C", c_int), ("x", c_void_p), ("ldx", c_int), ("res", c_void_p), ("ldres", c_int),
+        ("w0", c_void_p), ("b0", c_void_p), ("h_out", c_void_p), ("ldh", c_int), ("w1", c_void_p),
+        ("c1", c_void_p), ("c2", c_void_p), ("y", c_void_p), ("ldy", c_int), ("wf1", c_void_p),
+        ("wf2", c_void_p), ("bf2", c_void_p), ("wpo", c_void_p), ("bpo", c_void_p), ("xres", c_void_p), ("ldxres", c_int),
+        ("eps", c_float), ("dbg", c_int), ("timing", c_void_p),
+    ]
+
+
 class GemmDesc(ctypes.Structure):
     _fields_ = [
         ("x0", c_void_p), ("x1", c_void_p), ("ldx0", c_int), ("ldx1", c_int), ("cx0", c_int),
@@ -57,6 +67,9 @@ _PROTOS = {
     "dmx_conv_gemm_rowstats_tiles": (c_int, [POINTER(GemmDesc)]),
     "dmx_conv_gemm_colstats_ok": (c_int, [POINTER(GemmDesc)]),
     "dmx_set_gn_producer_stats": (c_int, [c_int]),
+    "dmx_xf_chain_ok": (c_int, [c_int, c_int]),
+    "dmx_xf_chain": (c_int, [POINTER(XfChainDesc), c_int, _P]),
+    "dmx_set_xf_chain": (c_int, [c_int]),
     "dmx_groupnorm_from_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, _P, _P, c_int, _P]),
     "dmx_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(GemmDesc), c_int]),
     "dmx_conv_wgrad": (c_int, [POINTER(GemmDesc), _P, c_int, _P, c_int, _P, c_size_t, _P]),

@@ -116,6 +116,16 @@ extern "C" int dmx_groupnorm_from_stats(const void* x0, int ldx0, const void* x1
   a.y = (bf16*)y; a.ldy = ldy; a.st0 = st0; a.st1 = x1 ? st1 : st0;
   return dmx_groupnorm_sums_launch(a, (hipStream_t)stream);
 }
+extern "C" int dmx_xf_chain_ok(int M, int C) { return dmx_xf_chain_supported(M, C) ? 1 : 0; }
+extern "C" int dmx_xf_chain(const dmx_xf_chain_desc* d, int mode, dmx_stream_t stream) {
+  DMX_REQUIRE(d != nullptr, "xf_chain: null descriptor");
+  XfChainArgs a{};
+  a.M = d->M; a.C = d->C; a.x = (const bf16*)d->x; a.ldx = d->ldx; a.res = (const bf16*)d->res; a.ldres = d->ldres;
+  a.w0 = (const bf16*)d->w0; a.b0 = d->b0; a.h_out = (bf16*)d->h_out; a.ldh = d->ldh; a.w1 = (const bf16*)d->w1;
+  a.c1 = d->c1; a.c2 = d->c2; a.y = (bf16*)d->y; a.ldy = d->ldy; a.wf1 = (const bf16*)d->wf1; a.wf2 = (const bf16*)d->wf2; a.bf2 = d->bf2;
+  a.wpo = (const bf16*)d->wpo; a.bpo = d->bpo; a.xres = (const bf16*)d->xres; a.ldxres = d->ldxres; a.eps = d->eps; a.dbg = d->dbg; a.timing = d->timing;
+  return dmx_xf_chain_launch(a, mode, (hipStream_t)stream);
+}
 extern "C" int dmx_groupnorm_train(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
                                    int B, int HW, const float* gamma, const float* beta, float eps, int silu,
                                    void* y, int ldy, float* stats, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {

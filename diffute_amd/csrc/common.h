@@ -112,6 +112,25 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + erf_v);
 }
 
+// the same function on two values with gfx950's packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32): 21 instructions for two values
+// against 2 x 18 - for epilogues that are VALU-bound on it (xf_chain.hip's in-kernel GEGLU)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
+  const f32x2 z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  const f32x2 d = __builtin_elementwise_fma((f32x2)(0.3275911f), z, (f32x2)(1.0f));
+  const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2 poly = __builtin_elementwise_fma((f32x2)(1.061405429f), t, (f32x2)(-1.453152027f));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2)(1.421413741f));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2)(-0.284496736f));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2)(0.254829592f));
+  poly = poly * t;
+  const f32x2 a = z * z * -1.4426950408889634f;
+  const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  const f32x2 erf_abs = __builtin_elementwise_fma(-poly, e, (f32x2)(1.0f));
+  const f32x2 erf_v = __builtin_elementwise_copysign(erf_abs, x);
+  return x * 0.5f * (erf_v + 1.0f);
+}
+
 // dynamic-LDS opt-in above 64 KB: a per-DEVICE function attribute, so it is set once per (kernel, device), result checked
 #define DMX_LDS_OPT_IN(kernel, bytes)                                                                        \
   do {                                                                                                       \

@@ -156,6 +156,10 @@ class Exec {
   void gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N, int K, const float* bias,
                 void* out, int ldo, int out_f32);
   Tn layernorm(const Tn& x, const float* gamma, const float* beta, float eps);
+  // xf_chain.hip: the row-local chains of a transformer block as one launch each (mode 0 / 1); chain_ok = this shape and mode of
+  // operation take them (C = 320, rows % 64 == 0, bf16 path, dmx_set_xf_chain(1))
+  bool chain_ok(const Tn& x) const;
+  void xf_chain(int mode, XfChainArgs& a);
   // fused attention core; V row-major (LDS transpose-read path)
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                  bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale);

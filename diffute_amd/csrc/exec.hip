@@ -335,6 +335,14 @@ Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps
   return y;
 }
 
+static int g_xf_chain = 1;
+extern "C" int dmx_set_xf_chain(int on) { const int old = g_xf_chain; g_xf_chain = on; return old; }
+bool Exec::chain_ok(const Tn& x) const { return g_xf_chain && !f32 && x.ld == x.C && dmx_xf_chain_supported(x.rows(), x.C); }
+void Exec::xf_chain(int mode, XfChainArgs& a) {
+  if (dry || rc) return;
+  rc = dmx_xf_chain_launch(a, mode, stream);
+}
+
 void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                      bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale) {
   if (dry || rc) return;

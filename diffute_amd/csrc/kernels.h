@@ -7,7 +7,7 @@
 // Optional per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg).
 enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN = 3, PROF_GNORM = 4, PROF_LNORM = 5,
                  PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_WGRAD = 8, PROF_GEMM256WS = 9,
-                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_NCLASS = 26 };
+                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_NCLASS = 27 };
 struct ProfScope {
   ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag = nullptr);
   ~ProfScope();
@@ -140,6 +140,26 @@ int dmx_geglu_fwd_launch(const bf16* h, int ldh, bf16* y, int ldy, int rows, int
 int dmx_geglu_bwd_launch(const bf16* h, int ldh, const bf16* dy, int lddy, bf16* dh, int lddh, int rows, int C2, int packed, hipStream_t stream);
 
 int dmx_softmax_rows_launch(const float* s, int lds_, bf16* p, int ldp, int rows, int n, float scale, hipStream_t stream);
+
+// ------------------------------------------------------------------ xf_chain.hip (row-local chains of the transformer block, C = 320)
+struct XfChainArgs {
+  int M, C;                              // rows (multiple of 64), channels (320)
+  const bf16* x; int ldx;                // operand of the first GEMM: mode 0 attn1's output, mode 1 attn2's output
+  const bf16* res; int ldres;            // residual of the first GEMM (the stream before that attention)
+  const bf16* w0; const float* b0;       // to_out.0 of that attention [C][C] + bias
+  bf16* h_out; int ldh;                  // the first GEMM's output (mode 0: the residual stream for mode 1; mode 1: a scratch copy the kernel reads back)
+  const bf16* w1;                        // mode 0: attn2.to_q with norm2's gamma folded in [C][C]
+  const float* c1; const float* c2;      // folded-LayerNorm vectors of the GEMM that consumes h: mode 0 to_q's [C], mode 1 FF1's [8C] (packed GEGLU order)
+  bf16* y; int ldy;                      // mode 0: q2; mode 1: the block's output
+  const bf16* wf1;                       // mode 1: ff.net.0.proj folded with norm3, packed GEGLU groups [8C][C]
+  const bf16* wf2; const float* bf2;     //         ff.net.2 [C][4C] + bias
+  const bf16* wpo; const float* bpo;     //         proj_out [C][C] + bias
+  const bf16* xres; int ldxres;          //         the Transformer2DModel residual
+  float eps;
+  int dbg; long long* timing;            // measurement aids (0 / null in the product path): bit 0 no MFMA phase, bit 1 no DMA refills; [blocks][8] phase timestamps
+};
+bool dmx_xf_chain_supported(int M, int C);
+int dmx_xf_chain_launch(const XfChainArgs& a, int mode, hipStream_t stream);
 
 // ------------------------------------------------------------------ attention.hip
 struct AttnArgs {

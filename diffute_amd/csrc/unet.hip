@@ -302,14 +302,40 @@ struct Fwd {
     Tn a = ex.make(x.B, x.H, x.W, C);
     ex.attention(qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, S, a.p, C, x.B, w.heads, S, S, 0.125f);
     ex.drop(qkv);
+    const int sp = ctx_pad(ctx_len);
+    const bf16* kvc = ctx_slot_ptr(u, cache, x.B, ctx_len, w.ctx_slot);
+    if (ex.chain_ok(x)) {
+      // C = 320 levels: everything after the self-attention core is per query row - two chained kernels around the cross-attention
+      // (xf_chain.hip): [to_out + res -> LN2 -> to_q] and [to_out + res -> LN3 -> FF1 / GEGLU -> FF2 + res -> proj_out + res]
+      XfChainArgs c{};
+      c.M = x.rows(); c.C = C; c.eps = 1e-5f;
+      Tn h2 = ex.make(x.B, x.H, x.W, C), q = ex.make(x.B, x.H, x.W, C);
+      c.x = a.p; c.ldx = a.ld; c.res = h.p; c.ldres = h.ld; c.w0 = u->at<bf16>(w.wo1); c.b0 = u->at<float>(w.bo1);
+      c.h_out = h2.p; c.ldh = h2.ld; c.w1 = u->at<bf16>(w.wq2); c.c1 = u->at<float>(w.c1_q2); c.c2 = u->at<float>(w.c2_q2);
+      c.y = q.p; c.ldy = q.ld;
+      ex.xf_chain(0, c);
+      ex.drop(a); ex.drop(h);
+      a = ex.make(x.B, x.H, x.W, C);
+      ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
+      ex.drop(q);
+      Tn h3 = ex.make(x.B, x.H, x.W, C), y = ex.make(x.B, x.H, x.W, C);
+      XfChainArgs d{};
+      d.M = x.rows(); d.C = C; d.eps = 1e-5f;
+      d.x = a.p; d.ldx = a.ld; d.res = h2.p; d.ldres = h2.ld; d.w0 = u->at<bf16>(w.wo2); d.b0 = u->at<float>(w.bo2);
+      d.h_out = h3.p; d.ldh = h3.ld; d.c1 = u->at<float>(w.c1_f1); d.c2 = u->at<float>(w.c2_f1);
+      d.wf1 = u->at<bf16>(w.wf1); d.wf2 = u->at<bf16>(w.wf2); d.bf2 = u->at<float>(w.bf2);
+      d.wpo = u->at<bf16>(w.wpo); d.bpo = u->at<float>(w.bpo); d.xres = x.p; d.ldxres = x.ld;
+      d.y = y.p; d.ldy = y.ld;
+      ex.xf_chain(1, d);
+      ex.drop(a); ex.drop(h2); ex.drop(h3);
+      return y;
+    }
     Tn h2 = ex.linear(a, u->at<bf16>(w.wo1), C, u->at<float>(w.bo1), &h, false, &st2);
     ex.drop(a); ex.drop(h);
     // ---- cross attention over the cached glyph-context K / V
     Exec::LnIn ln2; ln2.stats = st2.buf; ln2.tiles = st2.tiles; ln2.c1 = u->at<float>(w.c1_q2); ln2.c2 = u->at<float>(w.c2_q2);
     Tn q = ex.linear(h2, u->at<bf16>(w.wq2), C, nullptr, nullptr, false, nullptr, &ln2);
     ex.drop(st2.buf);
-    const int sp = ctx_pad(ctx_len);
-    const bf16* kvc = ctx_slot_ptr(u, cache, x.B, ctx_len, w.ctx_slot);
     a = ex.make(x.B, x.H, x.W, C);
     ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
     ex.drop(q);

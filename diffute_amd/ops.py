@@ -262,6 +262,29 @@ def linear(x, w, bias=None, res=None, geglu=False, out_f32=False, act=0, force_t
     return y.reshape(*x.shape[:-1], y.shape[-1])
 
 
+def xf_chain(mode, x, res, w0, b0, c1, c2, w1=None, wf1=None, wf2=None, bf2=None, wpo=None, bpo=None, xres=None, eps=1e-5, dbg=0, timing=None):
+    """The row-local chains of a transformer block at the C = 320 levels, one launch each (include/diffute_hip.h dmx_xf_chain).
+    x / res / xres [M][C]; returns (h_out, y)."""
+    M, C = x.shape
+    d = _cabi.XfChainDesc()
+    h = torch.empty(M, C, dtype=h16(), device=x.device)
+    y = torch.empty(M, C, dtype=h16(), device=x.device)
+    d.M, d.C, d.eps, d.dbg = M, C, float(eps), int(dbg)
+    if timing is not None:
+        d.timing = timing.data_ptr()
+    d.x, d.ldx, d.res, d.ldres = ptr(x), _ld(x), ptr(res), _ld(res)
+    d.w0, d.b0, d.h_out, d.ldh, d.y, d.ldy = ptr(w0), ptr(b0), ptr(h), C, ptr(y), C
+    d.c1, d.c2 = ptr(c1), ptr(c2)
+    keep = [x, res, w0, b0, c1, c2, w1, wf1, wf2, bf2, wpo, bpo, xres]
+    if mode == 0:
+        d.w1 = ptr(w1)
+    else:
+        d.wf1, d.wf2, d.bf2, d.wpo, d.bpo, d.xres, d.ldxres = ptr(wf1), ptr(wf2), ptr(bf2), ptr(wpo), ptr(bpo), ptr(xres), _ld(xres)
+    check(lib().dmx_xf_chain(ctypes.byref(d), int(mode), current_stream()), "xf_chain")
+    del keep
+    return h, y
+
+
 def groupnorm(x0, gamma, beta, groups, eps, silu, x1=None):
     B, H, W, C0 = x0.shape
     C = C0 + (x1.shape[-1] if x1 is not None else 0)

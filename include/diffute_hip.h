@@ -144,6 +144,35 @@ int dmx_groupnorm_from_stats(const void* x0, int ldx0, const void* x1, int ldx1,
                              int B, int HW, const float* gamma, const float* beta, float eps, int silu,
                              const long long* st0, const long long* st1, void* y, int ldy, dmx_stream_t stream);
 
+/* The row-local chains of diffusers' BasicTransformerBlock + Transformer2DModel.proj_out (the unet(...) call at
+ * /root/reference/app.ipynb:814) at the C = 320 levels, ONE launch each (xf_chain.hip); rows M % 64 == 0:
+ *   mode 0:  h_out = x w0^T + b0 + res ;  y = LayerNorm(h_out) folded into w1:  rstd * (h_out w1^T - mean * c1) + c2
+ *            (attn1.to_out.0 + residual, then attn2.to_q behind norm2; w1 / c1 / c2 as dmx_pack_ln_fold writes them)
+ *   mode 1:  h_out = x w0^T + b0 + res ;  h3 = h_out + wf2 GEGLU(LayerNorm(h_out) folded into wf1) + bf2 ;
+ *            y = h3 wpo^T + bpo + xres     (attn2.to_out.0 + residual, ff.net, proj_out + the block residual; wf1 [8C][C] in
+ *            the packed GEGLU order of dmx_pack_geglu_weight with c1 / c2 [8C] in the same order; wf2 [C][4C])
+ * All 16-bit operands in the build's element type, biases / c1 / c2 fp32.  dmx_xf_chain_supported: 1 for (M, C) it takes.
+ * dmx_set_xf_chain(0) makes the UNet executor use the separate GEMMs again (A/B runs in one process); returns the old setting. */
+typedef struct {
+  int M, C;
+  const void* x; int ldx;
+  const void* res; int ldres;
+  const void* w0; const float* b0;
+  void* h_out; int ldh;
+  const void* w1;
+  const float* c1; const float* c2;
+  void* y; int ldy;
+  const void* wf1;
+  const void* wf2; const float* bf2;
+  const void* wpo; const float* bpo;
+  const void* xres; int ldxres;
+  float eps;
+  int dbg; long long* timing;   /* measurement aids, 0 / NULL: ablation bits (results invalid), [M/64][8] phase timestamps in 10 ns ticks */
+} dmx_xf_chain_desc;
+int dmx_xf_chain_ok(int M, int C);
+int dmx_xf_chain(const dmx_xf_chain_desc* d, int mode, dmx_stream_t stream);
+int dmx_set_xf_chain(int on);
+
 /* Training (P5 over K3/K4/K8): forward GroupNorm that also keeps (mean, rstd) per (image, group), and the backward
  * kernels of GroupNorm(+SiLU), LayerNorm and the unfused GEGLU.  All deterministic.  `res*` is an optional gradient
  * added into dx (the tensor's other consumer, e.g. the residual branch); dgamma/dbeta fp32, `accumulate` adds.

@@ -1,5 +1,5 @@
 """A/B of a library switch inside ONE process and on one box: alternating timed 50-step passes with the switch on / off.
-    python scripts/ab_pass.py gn_stats [--rounds 4]"""
+    python scripts/ab_pass.py gn_stats|xf_chain [--rounds 4]"""
 import sys
 import time
 
@@ -21,8 +21,13 @@ lat, mask, mlat, ctx = synth_inputs(4, 64, 64, 577, 1024, device=dev)
 def setting(on):
     if what == "gn_stats":
         lib.dmx_set_gn_producer_stats(int(on))
+    elif what == "xf_chain":
+        lib.dmx_set_xf_chain(int(on))
     for sl in unet._slots.values():
         sl["ws_need"] = None
+    unet._ensure_packed()
+    _cabi.check(lib.dmx_unet_refresh_derived(unet._h, None), "refresh")     # drops the captured graphs (they embed the old setting)
+    torch.cuda.synchronize()
 
 
 def timed():

@@ -462,3 +462,67 @@ def test_fp16_build_operators(cuda):
         refw = h16r((torch.softmax(q @ k.transpose(-1, -2) * Dw ** -0.5, -1) @ v).reshape(Bw * Sw, Dw))
         qkv = torch.cat([q, k, v], dim=-1).reshape(Bw * Sw, 3 * Dw).to(cuda).to(H16)
         assert_close(ops.attention_wide(qkv[:, :Dw], qkv[:, Dw:2 * Dw], qkv[:, 2 * Dw:], Bw, Sw, Sw, Dw, Dw ** -0.5), refw, 2e-3, "fp16 wide attention")
+
+
+def _ln_fold(w, gamma, beta, bias=None):
+    """what dmx_ln_fold writes: W' = bf16(W * gamma), c1 = row sums of W' (as the MFMA sees them), c2 = W beta (+ bias)"""
+    wf = bf(w * gamma[None, :])
+    c2 = (w * beta[None, :]).sum(1)
+    return wf, wf.sum(1), c2 if bias is None else c2 + bias
+
+
+def _row_stats(h, eps=1e-5):
+    mean = h.mean(1, keepdim=True)
+    var = ((h * h).mean(1, keepdim=True) - mean * mean).clamp_min(0)
+    return mean, torch.rsqrt(var + eps)
+
+
+@pytest.mark.parametrize("M", [64, 4096 + 192])
+def test_xf_chain_out_proj_ln_query(cuda, M):
+    """xf_chain mode 0: attn1.to_out.0 + residual, then attn2.to_q behind the folded norm2, one launch (C = 320)"""
+    from diffute_amd import ops
+    C = 320
+    a = bf(seeded((M, C), 1)); h0 = bf(seeded((M, C), 2)); wo = bf(seeded((C, C), 3, 1 / math.sqrt(C))); bo = seeded((C,), 4, 0.1)
+    wq = bf(seeded((C, C), 5, 1 / math.sqrt(C))); gamma = 1 + seeded((C,), 6, 0.2); beta = seeded((C,), 7, 0.2)
+    wqf, c1, c2 = _ln_fold(wq, gamma, beta)
+    h1 = bf(F.linear(a, wo, bo) + h0)
+    mean, rstd = _row_stats(h1)
+    q_ref = bf(rstd * (h1 @ wqf.t() - mean * c1[None, :]) + c2[None, :])
+    dv = lambda v, dt=torch.bfloat16: v.to(cuda).to(dt).contiguous()
+    f32 = lambda v: v.to(cuda).float().contiguous()
+    assert ops.lib().dmx_xf_chain_ok(M, C) == 1 and ops.lib().dmx_xf_chain_ok(M, 640) == 0 and ops.lib().dmx_xf_chain_ok(M + 8, C) == 0
+    h, q = ops.xf_chain(0, dv(a), dv(h0), dv(wo), f32(bo), f32(c1), f32(c2), w1=dv(wqf))
+    assert_close(h, h1, TOL, "xf_chain mode 0: residual stream")
+    assert_close(q, q_ref, 2e-3, "xf_chain mode 0: query")
+    h_b, q_b = ops.xf_chain(0, dv(a), dv(h0), dv(wo), f32(bo), f32(c1), f32(c2), w1=dv(wqf))
+    assert torch.equal(h, h_b) and torch.equal(q, q_b), "xf_chain mode 0 is not bit-stable"
+
+
+@pytest.mark.parametrize("M", [64, 4096 + 192])
+def test_xf_chain_feed_forward_tail(cuda, M):
+    """xf_chain mode 1: attn2.to_out.0 + residual -> norm3 -> GEGLU feed-forward + residual -> proj_out + residual, one launch"""
+    from diffute_amd import ops
+    C = 320
+    a = bf(seeded((M, C), 11)); h1 = bf(seeded((M, C), 12)); xres = bf(seeded((M, C), 13))
+    wo = bf(seeded((C, C), 14, 1 / math.sqrt(C))); bo = seeded((C,), 15, 0.1)
+    w1 = bf(seeded((8 * C, C), 16, 1 / math.sqrt(C))); b1 = seeded((8 * C,), 17, 0.1)
+    gamma = 1 + seeded((C,), 18, 0.2); beta = seeded((C,), 19, 0.2)
+    w2 = bf(seeded((C, 4 * C), 20, 1 / math.sqrt(4 * C))); b2 = seeded((C,), 21, 0.1)
+    wp = bf(seeded((C, C), 22, 1 / math.sqrt(C))); bp = seeded((C,), 23, 0.1)
+    w1f, c1, c2 = _ln_fold(w1, gamma, beta, b1)                                  # torch order: [value 4C | gate 4C]
+    h2 = bf(F.linear(a, wo, bo) + h1)
+    mean, rstd = _row_stats(h2)
+    u = rstd * (h2 @ w1f.t() - mean * c1[None, :]) + c2[None, :]
+    val, gate = u.chunk(2, dim=-1)
+    t = bf(val * F.gelu(gate))
+    h3 = bf(F.linear(t, w2, b2) + h2)
+    y_ref = bf(F.linear(h3, wp, bp) + xres)
+    dv = lambda v, dt=torch.bfloat16: v.to(cuda).to(dt).contiguous()
+    f32 = lambda v: v.to(cuda).float().contiguous()
+    w1p = ops.pack_linear_weight(dv(w1f).float(), geglu=True)                    # packed GEGLU groups, as the arena holds FF1
+    c1p, c2p = ops.pack_geglu_bias(f32(c1)), ops.pack_geglu_bias(f32(c2))
+    h, y = ops.xf_chain(1, dv(a), dv(h1), dv(wo), f32(bo), c1p, c2p, wf1=w1p, wf2=dv(w2), bf2=f32(b2), wpo=dv(wp), bpo=f32(bp), xres=dv(xres))
+    assert_close(h, h2, TOL, "xf_chain mode 1: residual stream")
+    assert_close(y, y_ref, 3e-3, "xf_chain mode 1: block output")
+    h_b, y_b = ops.xf_chain(1, dv(a), dv(h1), dv(wo), f32(bo), c1p, c2p, wf1=w1p, wf2=dv(w2), bf2=f32(b2), wpo=dv(wp), bpo=f32(bp), xres=dv(xres))
+    assert torch.equal(y, y_b), "xf_chain mode 1 is not bit-stable"
