@@ -146,6 +146,11 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
   auto mma_tile = [&](const char* st, const int J, f32x4 (&c)[5][2], const bool rn = false) {
     if constexpr (ABL & 1) { dma_all(); return; }
     if (rn) dma_all();
+    // the five loads are STAGGERED by wave: wave w issues load i behind MFMA 4 i + (w & 3) of the tile's twenty, so that at any
+    // moment only the two waves of one SIMD (which alternate on its matrix pipe anyway) reach for the address path - issued at
+    // the same program point by all eight waves every LDS-DMA instruction queued behind seven others (~200 cycles each).
+    // (mode 1; in mode 0's short loops the pinned static order measured better: 2.6 vs 3.1 us per five tiles)
+    const int wq = w & 3;
     if constexpr (MODE == 0) {
       bf16x8 wf[2][5];
 #pragma unroll
@@ -178,20 +183,12 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
         for (int a = 0; a < 5; ++a) wf[a] = *(const bf16x8*)(st + wad[kk] + a * 2048);
 #pragma unroll
         for (int a = 0; a < 5; ++a) {
-          c[a][0] = DMX_MFMA_16x16x32(wf[a], xf[0][2 * J + kk], c[a][0]);
-          c[a][1] = DMX_MFMA_16x16x32(wf[a], xf[1][2 * J + kk], c[a][1]);
-          if (!rn && ((kk * 5 + a) & 1)) dma((kk * 5 + a) >> 1);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-        if (rn) __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
-        else if (kk == 0) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            c[a][b] = DMX_MFMA_16x16x32(wf[a], xf[b][2 * J + kk], c[a][b]);
+            const int m = kk * 10 + 2 * a + b;
+            if (!rn && (m & 3) == wq) dma(m >> 2);
+          }
         }
       }
     }
@@ -337,6 +334,7 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
     auto ff2_tile = [&](const char* st, const int JJ, const int NKK, const bool rn = false) {
       if constexpr (ABL & 1) { dma_all(); return; }
       if (rn) dma_all();
+      const int wq = w & 3;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
         bf16x8 wf[5], tf[2];
@@ -345,27 +343,15 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
 #pragma unroll
         for (int b = 0; b < 2; ++b) tf[b] = *(const bf16x8*)(FB + ml[b] * XFF_LD + (xsw(4 * (2 * JJ + kk) + lh, ml[b]) << 4));
 #pragma unroll
-        for (int a = 0; a < 5; ++a) {
-          accf[a][0] = DMX_MFMA_16x16x32(wf[a], tf[0], accf[a][0]);
-          accf[a][1] = DMX_MFMA_16x16x32(wf[a], tf[1], accf[a][1]);
-          if (rn) continue;
-          if (NKK == 2) { if ((kk * 5 + a) & 1) dma((kk * 5 + a) >> 1); }
-          else dma(a);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-        if (rn) __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
-        else if (NKK == 1) {
+        for (int a = 0; a < 5; ++a)
 #pragma unroll
-          for (int q = 0; q < 5; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
-        } else if (kk == 0) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        }
+          for (int b = 0; b < 2; ++b) {
+            accf[a][b] = DMX_MFMA_16x16x32(wf[a], tf[b], accf[a][b]);
+            const int m = kk * 10 + 2 * a + b;
+            if (rn) continue;
+            if (NKK == 2) { if ((m & 3) == wq) dma(m >> 2); }       // staggered by wave like mma_tile
+            else if ((m & 1) == (wq & 1)) dma(m >> 1);
+          }
       }
     };
 #pragma unroll 1

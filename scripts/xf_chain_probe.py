@@ -43,12 +43,12 @@ t1 = graph_time(lambda: ops.xf_chain(1, a, h0, wo, bo, c1f, c2f, wf1=w1, wf2=w2,
 
 def separate0():
     h, st = ops.linear(a, wo, bias=bo, res=h0, rowstats=True)
-    return ops.linear(h, wq, ln=(st, c1, c2))
+    return ops.linear(h, wq, ln=(st, c1, c2, 1e-5))
 
 
 def separate1():
     h, st = ops.linear(a, wo, bias=bo, res=h0, rowstats=True)
-    gg = ops.linear(h, w1, geglu=True, ln=(st, c1f, c2f))
+    gg = ops.linear(h, w1, geglu=True, ln=(st, c1f, c2f, 1e-5))
     h3 = ops.linear(gg, w2, bias=b2, res=h)
     return ops.linear(h3, wp, bias=bp, res=xres)
 
