@@ -293,20 +293,32 @@ struct Fwd {
     // LayerNorms are folded: each residual-stream producer also emits per-row (sum, sumsq) partials and the
     // consuming GEMM multiplies the raw rows by W*gamma and normalises in its epilogue - no LN kernels, no LN tensors.
     Exec::RowStats st1, st2, st3;
-    Tn h = ex.linear(t, u->at<bf16>(w.wpi), C, u->at<float>(w.bpi), nullptr, false, &st1);
-    ex.drop(t);
-    // ---- self attention
-    Exec::LnIn ln1; ln1.stats = st1.buf; ln1.tiles = st1.tiles; ln1.c1 = u->at<float>(w.c1_qkv); ln1.c2 = u->at<float>(w.c2_qkv);
-    Tn qkv = ex.linear(h, u->at<bf16>(w.wqkv), 3 * C, nullptr, nullptr, false, nullptr, &ln1);
-    ex.drop(st1.buf);
+    const bool chain = ex.chain_ok(x);     // C = 320 levels: the per-row GEMM chains around the two attention cores are three kernels (xf_chain.hip)
+    Tn h, qkv;
+    if (chain) {
+      // [proj_in -> LN1 -> to_q | to_k | to_v]
+      h = ex.make(x.B, x.H, x.W, C); qkv = ex.make(x.B, x.H, x.W, 3 * C);
+      XfChainArgs c{};
+      c.M = x.rows(); c.C = C; c.eps = 1e-5f;
+      c.x = t.p; c.ldx = t.ld; c.w0 = u->at<bf16>(w.wpi); c.b0 = u->at<float>(w.bpi); c.h_out = h.p; c.ldh = h.ld;
+      c.w1 = u->at<bf16>(w.wqkv); c.c1 = u->at<float>(w.c1_qkv); c.c2 = u->at<float>(w.c2_qkv); c.y = qkv.p; c.ldy = qkv.ld;
+      ex.xf_chain(2, c);
+      ex.drop(t);
+    } else {
+      h = ex.linear(t, u->at<bf16>(w.wpi), C, u->at<float>(w.bpi), nullptr, false, &st1);
+      ex.drop(t);
+      // ---- self attention
+      Exec::LnIn ln1; ln1.stats = st1.buf; ln1.tiles = st1.tiles; ln1.c1 = u->at<float>(w.c1_qkv); ln1.c2 = u->at<float>(w.c2_qkv);
+      qkv = ex.linear(h, u->at<bf16>(w.wqkv), 3 * C, nullptr, nullptr, false, nullptr, &ln1);
+      ex.drop(st1.buf);
+    }
     Tn a = ex.make(x.B, x.H, x.W, C);
     ex.attention(qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, S, a.p, C, x.B, w.heads, S, S, 0.125f);
     ex.drop(qkv);
     const int sp = ctx_pad(ctx_len);
     const bf16* kvc = ctx_slot_ptr(u, cache, x.B, ctx_len, w.ctx_slot);
-    if (ex.chain_ok(x)) {
-      // C = 320 levels: everything after the self-attention core is per query row - two chained kernels around the cross-attention
-      // (xf_chain.hip): [to_out + res -> LN2 -> to_q] and [to_out + res -> LN3 -> FF1 / GEGLU -> FF2 + res -> proj_out + res]
+    if (chain) {
+      // [to_out + res -> LN2 -> to_q] and [to_out + res -> LN3 -> FF1 / GEGLU -> FF2 + res -> proj_out + res] around the cross-attention
       XfChainArgs c{};
       c.M = x.rows(); c.C = C; c.eps = 1e-5f;
       Tn h2 = ex.make(x.B, x.H, x.W, C), q = ex.make(x.B, x.H, x.W, C);

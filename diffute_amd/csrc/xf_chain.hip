@@ -3,6 +3,8 @@
 //
 //   MODE 0   h1 = a1 Wo1^T + bo1 + h0                      (attn1.to_out + residual)
 //            q2 = LN2(h1) Wq2^T                            (attn2.to_q, LayerNorm folded: raw rows x W*gamma, normalised in the epilogue)
+//   MODE 2   h0 = n Wpi^T + bpi                           (proj_in on the GroupNorm output)
+//            qkv = LN1(h0) [Wq | Wk | Wv]^T                (attn1's stacked projections, LayerNorm folded; three 320-wide GEMMs on the same fragments)
 //   MODE 1   h2 = a2 Wo2^T + bo2 + h1                      (attn2.to_out + residual)
 //            h3 = h2 + FF2(GEGLU(LN3(h2) W1^T))            (ff.net, hidden 4C never leaves the CU)
 //            y  = h3 Wpo^T + bpo + x                       (proj_out + the Transformer2DModel residual)
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
   // tile stream: five [320][64] weight tiles per 320-wide GEMM, then one RESIDUAL tile (this block's 64 rows of the tensor the
   // epilogue adds, fetched in the exchange-image layout: the epilogue reads it from LDS at the address it then writes its output to)
   constexpr int FF0 = 6;                                             // first feed-forward tile (mode 1)
-  constexpr int NTILES = MODE == 0 ? 11 : FF0 + NCH * 8 + 1 + 6;
+  constexpr int NTILES = MODE == 0 ? 11 : MODE == 2 ? 20 : FF0 + NCH * 8 + 1 + 6;
 
   // ---- thread t fills LDS chunk positions t + 512 i; weight tiles: row t/8 + 64 i, physical chunk t & 7
   const int d_row = t >> 3;
@@ -72,6 +74,10 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
       else if (gi == 5) { base = p.res; ldb = (unsigned)p.ldres * 2; resid = 1; }
       else if (gi < NTILES) base = p.w1 + 64 * (gi - 6);
       else base = p.w0;                                              // past the end: dummy tile (keeps the counted waits uniform)
+    } else if constexpr (MODE == 2) {
+      if (gi < 5) base = p.w0 + 64 * gi;
+      else if (gi < NTILES) { const int gg = gi - 5, sl = gg / 5, j = gg - sl * 5; base = p.w1 + (size_t)sl * XC * XC + 64 * j; }   // rows 320 sl .. of [3C][C]
+      else base = p.w0;
     } else {
       if (gi < 5) base = p.w0 + 64 * gi;
       else if (gi == 5) { base = p.res; ldb = (unsigned)p.ldres * 2; resid = 1; }
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
     // the same program point by all eight waves every LDS-DMA instruction queued behind seven others (~200 cycles each).
     // (mode 1; in mode 0's short loops the pinned static order measured better: 2.6 vs 3.1 us per five tiles)
     const int wq = w & 3;
-    if constexpr (MODE == 0) {
+    if constexpr (MODE != 1) {
       bf16x8 wf[2][5];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
   auto finish = [&](const f32x4 (&c)[5][2], const int vbias, const int vc1, const bool res, const bool stats) {
     float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f};
     const char* X = smem + (sc == 0 ? 2 : sc - 1) * XSLOT;           // the residual tile (the slot computed last), in the exchange layout
-    const float* vec = (const float*)(smem + XVEC_OFF);
+    const float* vec = (const float*)(smem + (MODE == 2 ? XFF_OFF : XVEC_OFF));
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
       const int n = 80 * wn + 16 * a + 4 * lh;
@@ -296,7 +302,13 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) xf[b][ks] = *(const bf16x8*)(xp + 32 * ks);
   }
-  if (t < 240) {                                                     // the three column vectors of the 320-wide epilogues -> LDS
+  if constexpr (MODE == 2) {                                         // b0 | c1[3C] | c2[3C] -> the (otherwise unused) GEGLU chunk buffer
+    for (int e = t; e < 7 * 80; e += 512) {
+      const int v = e / 80, q4 = e - v * 80;
+      const float* vsrc = v == 0 ? p.b0 : v < 4 ? p.c1 + (v - 1) * XC : p.c2 + (v - 4) * XC;
+      *(f32x4*)(smem + XFF_OFF + (v * XC + 4 * q4) * 4) = *(const f32x4*)(vsrc + 4 * q4);
+    }
+  } else if (t < 240) {                                              // the three column vectors of the 320-wide epilogues -> LDS
     const int v = t / 80, q4 = t - v * 80;
     const float* vsrc = MODE == 0 ? (v == 0 ? p.b0 : v == 1 ? p.c1 : p.c2) : (v == 0 ? p.b0 : v == 1 ? p.bf2 : p.bpo);
     *(f32x4*)(smem + XVEC_OFF + (v * XC + 4 * q4) * 4) = *(const f32x4*)(vsrc + 4 * q4);
@@ -310,10 +322,16 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
   stamp(1);
   // ---- phase 1: h = x W0^T + b0 + res
   clear(acc);
-  XSTEP(mma_tile(st, 0, acc)) XSTEP(mma_tile(st, 1, acc)) XSTEP(mma_tile(st, 2, acc)) XSTEP(mma_tile(st, 3, acc, true)) XSTEP(mma_tile(st, 4, acc))
-  XSTEP(dma_all())                                         // the residual tile
-  stamp(2);
-  finish(acc, 0, -1, true, true);
+  if constexpr (MODE == 2) {
+    XSTEP(mma_tile(st, 0, acc)) XSTEP(mma_tile(st, 1, acc)) XSTEP(mma_tile(st, 2, acc)) XSTEP(mma_tile(st, 3, acc)) XSTEP(mma_tile(st, 4, acc))
+    stamp(2);
+    finish(acc, 0, -1, false, true);
+  } else {
+    XSTEP(mma_tile(st, 0, acc)) XSTEP(mma_tile(st, 1, acc)) XSTEP(mma_tile(st, 2, acc)) XSTEP(mma_tile(st, 3, acc, true)) XSTEP(mma_tile(st, 4, acc))
+    XSTEP(dma_all())                                       // the residual tile
+    stamp(2);
+    finish(acc, 0, -1, true, true);
+  }
   exchange(p.h_out, p.ldh, true, true);
   stamp(3);
 
@@ -324,6 +342,16 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
     stamp(4);
     finish(acc, 2, 1, false, false);
     exchange(p.y, p.ldy, false, false);
+  } else if constexpr (MODE == 2) {
+    // ---- q | k | v = LN(h) W1'^T, 320 output columns at a time on the same register fragments
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      clear(acc);
+      XSTEP(mma_tile(st, 0, acc)) XSTEP(mma_tile(st, 1, acc)) XSTEP(mma_tile(st, 2, acc)) XSTEP(mma_tile(st, 3, acc)) XSTEP(mma_tile(st, 4, acc))
+      if (sl == 0) stamp(4);
+      finish(acc, 4 + sl, 1 + sl, false, false);
+      exchange(p.y + sl * XC, p.ldy, false, false);
+    }
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the copy of h (the residual of the feed-forward, read back below) has left this wave
     // ---- feed-forward over 8 chunks of 160 hidden columns: FF1 chunk -> GEGLU -> LDS -> partial FF2 into accf
@@ -402,15 +430,15 @@ size_t dmx_xf_chain_lds_bytes() { return XLDS; }
 bool dmx_xf_chain_supported(int M, int C) { return C == XC && M > 0 && M % XBM == 0; }
 
 int dmx_xf_chain_launch(const XfChainArgs& a, int mode, hipStream_t stream) {
-  DMX_REQUIRE(mode == 0 || mode == 1, "xf_chain: mode %d", mode);
+  DMX_REQUIRE(mode >= 0 && mode <= 2, "xf_chain: mode %d", mode);
   DMX_REQUIRE(dmx_xf_chain_supported(a.M, a.C), "xf_chain: M=%d C=%d unsupported (C = 320, M %% 64 == 0)", a.M, a.C);
-  DMX_REQUIRE(a.x && a.res && a.w0 && a.b0 && a.h_out && a.y && a.c1 && a.c2, "xf_chain: null operand");
+  DMX_REQUIRE(a.x && (a.res || mode == 2) && a.w0 && a.b0 && a.h_out && a.y && a.c1 && a.c2, "xf_chain: null operand");
   DMX_REQUIRE(a.ldx % 8 == 0 && a.ldres % 4 == 0 && a.ldh % 8 == 0 && a.ldy % 8 == 0, "xf_chain: row strides must be multiples of 8 elements");
-  if (mode == 0) DMX_REQUIRE(a.w1 != nullptr, "xf_chain: null operand");
+  if (mode != 1) DMX_REQUIRE(a.w1 != nullptr, "xf_chain: null operand");
   else DMX_REQUIRE(a.wf1 && a.wf2 && a.bf2 && a.wpo && a.bpo && a.xres && a.ldxres % 4 == 0, "xf_chain: null operand");
   const double M = a.M, C = a.C;
-  const double flops = mode == 0 ? 2.0 * M * C * C * 2 : 2.0 * M * C * C * 2 + 2.0 * M * C * (8 * C) + 2.0 * M * (4 * C) * C;
-  const double bytes = mode == 0 ? 2.0 * (4 * M * C + 2 * C * C) : 2.0 * (4 * M * C + 2 * C * C + 12 * C * C);
+  const double flops = mode == 0 ? 2.0 * M * C * C * 2 : mode == 2 ? 2.0 * M * C * C * 4 : 2.0 * M * C * C * 2 + 2.0 * M * C * (8 * C) + 2.0 * M * (4 * C) * C;
+  const double bytes = mode == 0 ? 2.0 * (4 * M * C + 2 * C * C) : mode == 2 ? 2.0 * (5 * M * C + 4 * C * C) : 2.0 * (4 * M * C + 2 * C * C + 12 * C * C);
   char tag[64]; snprintf(tag, sizeof(tag), "M=%d C=%d mode=%d", a.M, a.C, mode);
   ProfScope ps(PROF_XFCHAIN, stream, flops, bytes, tag);
   const dim3 grid(a.M / XBM), block(512);
@@ -423,13 +451,14 @@ int dmx_xf_chain_launch(const XfChainArgs& a, int mode, hipStream_t stream) {
   if (a.dbg & 3) {
     const int k = a.dbg & 3;
     if (mode == 0) { if (k == 1) XLAUNCH(0, 1) else if (k == 2) XLAUNCH(0, 2) else XLAUNCH(0, 3) }
+    else if (mode == 2) { if (k == 1) XLAUNCH(2, 1) else if (k == 2) XLAUNCH(2, 2) else XLAUNCH(2, 3) }
     else { if (k == 1) XLAUNCH(1, 1) else if (k == 2) XLAUNCH(1, 2) else XLAUNCH(1, 3) }
     return dmx_check_launch("dmx_xf_chain_kernel");
   }
 #else
   DMX_REQUIRE(a.dbg == 0, "xf_chain: the ablation switches exist in -DDMX_PROBES builds only");
 #endif
-  if (mode == 0) XLAUNCH(0, 0) else XLAUNCH(1, 0)
+  if (mode == 0) XLAUNCH(0, 0) else if (mode == 2) XLAUNCH(2, 0) else XLAUNCH(1, 0)
 #undef XLAUNCH
   return dmx_check_launch("dmx_xf_chain_kernel");
 }

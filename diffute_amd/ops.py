@@ -268,15 +268,15 @@ def xf_chain(mode, x, res, w0, b0, c1, c2, w1=None, wf1=None, wf2=None, bf2=None
     M, C = x.shape
     d = _cabi.XfChainDesc()
     h = torch.empty(M, C, dtype=h16(), device=x.device)
-    y = torch.empty(M, C, dtype=h16(), device=x.device)
+    y = torch.empty(M, 3 * C if mode == 2 else C, dtype=h16(), device=x.device)
     d.M, d.C, d.eps, d.dbg = M, C, float(eps), int(dbg)
     if timing is not None:
         d.timing = timing.data_ptr()
-    d.x, d.ldx, d.res, d.ldres = ptr(x), _ld(x), ptr(res), _ld(res)
-    d.w0, d.b0, d.h_out, d.ldh, d.y, d.ldy = ptr(w0), ptr(b0), ptr(h), C, ptr(y), C
+    d.x, d.ldx, d.res, d.ldres = ptr(x), _ld(x), ptr(res), (_ld(res) if res is not None else 0)
+    d.w0, d.b0, d.h_out, d.ldh, d.y, d.ldy = ptr(w0), ptr(b0), ptr(h), C, ptr(y), y.shape[1]
     d.c1, d.c2 = ptr(c1), ptr(c2)
     keep = [x, res, w0, b0, c1, c2, w1, wf1, wf2, bf2, wpo, bpo, xres]
-    if mode == 0:
+    if mode != 1:
         d.w1 = ptr(w1)
     else:
         d.wf1, d.wf2, d.bf2, d.wpo, d.bpo, d.xres, d.ldxres = ptr(wf1), ptr(wf2), ptr(bf2), ptr(wpo), ptr(bpo), ptr(xres), _ld(xres)

@@ -148,6 +148,8 @@ int dmx_groupnorm_from_stats(const void* x0, int ldx0, const void* x1, int ldx1,
  * /root/reference/app.ipynb:814) at the C = 320 levels, ONE launch each (xf_chain.hip); rows M % 64 == 0:
  *   mode 0:  h_out = x w0^T + b0 + res ;  y = LayerNorm(h_out) folded into w1:  rstd * (h_out w1^T - mean * c1) + c2
  *            (attn1.to_out.0 + residual, then attn2.to_q behind norm2; w1 / c1 / c2 as dmx_pack_ln_fold writes them)
+ *   mode 2:  h_out = x w0^T + b0 (res unused) ;  y[M][3C] = LayerNorm(h_out) folded into w1 [3C][C] with c1 / c2 [3C]
+ *            (proj_in on the GroupNorm output, then attn1's stacked to_q | to_k | to_v behind norm1; ldy >= 3C)
  *   mode 1:  h_out = x w0^T + b0 + res ;  h3 = h_out + wf2 GEGLU(LayerNorm(h_out) folded into wf1) + bf2 ;
  *            y = h3 wpo^T + bpo + xres     (attn2.to_out.0 + residual, ff.net, proj_out + the block residual; wf1 [8C][C] in
  *            the packed GEGLU order of dmx_pack_geglu_weight with c1 / c2 [8C] in the same order; wf2 [C][4C])

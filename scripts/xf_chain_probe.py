@@ -37,6 +37,16 @@ def graph_time(fn, reps=20):
     return e0.elapsed_time(e1) * 1e3 / (5 * reps)
 
 
+wqkv = bfl(rn(3 * C, C, sc=1 / math.sqrt(C))); c1q, c2q = rn(3 * C, sc=0.1), rn(3 * C, sc=0.1)
+t2 = graph_time(lambda: ops.xf_chain(2, a, None, wo, bo, c1q, c2q, w1=wqkv))
+
+
+def separate2():
+    h, st = ops.linear(a, wo, bias=bo, rowstats=True)
+    return ops.linear(h, wqkv, ln=(st, c1q, c2q, 1e-5))
+
+
+print(f"M={M}: chain mode 2 (proj_in -> LN -> qkv) {t2:.1f} us (separate {graph_time(separate2):.1f})")
 t0 = graph_time(lambda: ops.xf_chain(0, a, h0, wo, bo, c1, c2, w1=wq))
 t1 = graph_time(lambda: ops.xf_chain(1, a, h0, wo, bo, c1f, c2f, wf1=w1, wf2=w2, bf2=b2, wpo=wp, bpo=bp, xres=xres))
 

@@ -526,3 +526,23 @@ def test_xf_chain_feed_forward_tail(cuda, M):
     assert_close(y, y_ref, 3e-3, "xf_chain mode 1: block output")
     h_b, y_b = ops.xf_chain(1, dv(a), dv(h1), dv(wo), f32(bo), c1p, c2p, wf1=w1p, wf2=dv(w2), bf2=f32(b2), wpo=dv(wp), bpo=f32(bp), xres=dv(xres))
     assert torch.equal(y, y_b), "xf_chain mode 1 is not bit-stable"
+
+
+@pytest.mark.parametrize("M", [64, 4096 + 192])
+def test_xf_chain_proj_in_ln_qkv(cuda, M):
+    """xf_chain mode 2: proj_in, then attn1's stacked to_q | to_k | to_v behind the folded norm1, one launch (C = 320)"""
+    from diffute_amd import ops
+    C = 320
+    x = bf(seeded((M, C), 31)); wpi = bf(seeded((C, C), 32, 1 / math.sqrt(C))); bpi = seeded((C,), 33, 0.1)
+    wqkv = bf(seeded((3 * C, C), 34, 1 / math.sqrt(C))); gamma = 1 + seeded((C,), 35, 0.2); beta = seeded((C,), 36, 0.2)
+    wf, c1, c2 = _ln_fold(wqkv, gamma, beta)
+    h0 = bf(F.linear(x, wpi, bpi))
+    mean, rstd = _row_stats(h0)
+    qkv_ref = bf(rstd * (h0 @ wf.t() - mean * c1[None, :]) + c2[None, :])
+    dv = lambda v, dt=torch.bfloat16: v.to(cuda).to(dt).contiguous()
+    f32 = lambda v: v.to(cuda).float().contiguous()
+    h, qkv = ops.xf_chain(2, dv(x), None, dv(wpi), f32(bpi), f32(c1), f32(c2), w1=dv(wf))
+    assert_close(h, h0, TOL, "xf_chain mode 2: proj_in")
+    assert_close(qkv, qkv_ref, 2e-3, "xf_chain mode 2: q | k | v")
+    h_b, qkv_b = ops.xf_chain(2, dv(x), None, dv(wpi), f32(bpi), f32(c1), f32(c2), w1=dv(wf))
+    assert torch.equal(h, h_b) and torch.equal(qkv, qkv_b), "xf_chain mode 2 is not bit-stable"
