@@ -59,12 +59,12 @@ def main():
         del enc
         torch.cuda.empty_cache()
     if not args.skip_768:
-        unet = D.UNet2DConditionModel(device=dev).requires_grad_(False)
+        unet = D.UNet2DConditionModel(device=dev).requires_grad_(False).to(dtype=torch.float16)      # the fp16 build of the library (BASELINE configs[4])
         lat, mask, mlat, ctx = synth_inputs(2, 96, 96, 577, 1024, device=dev)
         t, out = timed(lambda: D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 50), 2)
         assert torch.isfinite(out).all()
         fl = 50 * unet_flops(unet.config, 2, 96, 96, 577, True)
-        print(json.dumps({"config": "cfg5: 768x768 denoise loop, 50 DDIM steps, batch 2, bf16 (north_star names fp16; this build computes bf16)",
+        print(json.dumps({"config": "cfg5: 768x768 denoise loop, 50 DDIM steps, batch 2, fp16 (libdiffute_hip_f16.so)",
                           "ms_per_batch": round(t * 1e3, 1), "images_per_s": round(2 / t, 3), "loop_tflops": round(fl / t / 1e12, 1)}))
 
 
