@@ -98,21 +98,26 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
       __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(smem + XFFV_OFF + (w < 3 ? w : 3) * 1024), 16, 0, 0);
     }
     dres = resid;
+    {   // the tile base is wave-uniform: pinned into SGPRs so that the loads take the (SGPR base + 32-bit VGPR offset) form - no
+        // 64-bit address arithmetic per load
+      const unsigned long long bq = (unsigned long long)(resid ? (const char*)base + (size_t)m0 * ldb : (const char*)base);
+      const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bq), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bq >> 32));
+      dbase = (const char*)(((unsigned long long)bhi << 32) | blo);
+    }
     if (resid) {
-      dbase = (const char*)base + (size_t)m0 * ldb; dstep = ldb;
+      dstep = __builtin_amdgcn_readfirstlane(ldb);
     } else {
-      dbase = (const char*)base;
       // (arithmetic selects: a ?: between the captured per-thread constants becomes a select of their stack ADDRESSES - two
       //  dependent scratch / flat loads with vmcnt(0) in the hot loop, which also drained the DMA queue every step)
       const unsigned row = (unsigned)d_row + (unsigned)perm * (unsigned)(d_prow - d_row);
       const unsigned cs = (unsigned)d_csrc & (half ? 3u : 7u);       // half tile (32 valid k): both halves fetch the valid one
-      doff = row * ldb + cs * 16; dstep = 64 * ldb;
+      doff = row * ldb + cs * 16; dstep = __builtin_amdgcn_readfirstlane(64 * ldb);
     }
     ++gi; si = (si == 2) ? 0 : si + 1;
   };
   auto dma = [&](const int i) {
     if constexpr (ABL & 2) { if (gi > 2) return; }
-    __builtin_amdgcn_global_load_lds((gptr_t)(dbase + (doff + (unsigned)i * dstep)), (lptr_t)(ddst + i * 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)((dbase + (size_t)i * dstep) + doff), (lptr_t)(ddst + i * 8192), 16, 0, 0);   // (SGPR base + i * SGPR step) + 32-bit VGPR offset
   };
   auto dma_all = [&]() {                                             // (the only way residual tiles are issued: their steps have no MFMA phase)
     if constexpr (ABL & 2) { if (gi > 2) return; }
