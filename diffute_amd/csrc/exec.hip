@@ -337,7 +337,7 @@ Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps
 
 static int g_xf_chain = 1;
 extern "C" int dmx_set_xf_chain(int on) { const int old = g_xf_chain; g_xf_chain = on; return old; }
-bool Exec::chain_ok(const Tn& x) const { return g_xf_chain && !f32 && x.ld == x.C && dmx_xf_chain_supported(x.rows(), x.C); }
+bool Exec::chain_ok(const Tn& x) const { return g_xf_chain && !f32 && x.ld == x.C && (g_xf_chain > 1 ? dmx_xf_chain_supported(x.rows(), x.C) : dmx_xf_chain_pays(x.rows(), x.C)); }
 void Exec::xf_chain(int mode, XfChainArgs& a) {
   if (dry || rc) return;
   rc = dmx_xf_chain_launch(a, mode, stream);

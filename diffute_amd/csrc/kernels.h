@@ -159,6 +159,7 @@ struct XfChainArgs {
   int dbg; long long* timing;            // measurement aids (0 / null in the product path): bit 0 no MFMA phase, bit 1 no DMA refills; [blocks][8] phase timestamps
 };
 bool dmx_xf_chain_supported(int M, int C);
+bool dmx_xf_chain_pays(int M, int C);      // what the model executors use: enough 64-row blocks to fill the chip
 int dmx_xf_chain_launch(const XfChainArgs& a, int mode, hipStream_t stream);
 
 // ------------------------------------------------------------------ attention.hip

@@ -12,17 +12,22 @@ from diffute_amd.synthetic import synth_inputs  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "gn_stats"
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 4
+batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 4
+latent = int(sys.argv[sys.argv.index("--latent") + 1]) if "--latent" in sys.argv else 64
 dev = torch.device("cuda")
 lib = _cabi.lib()
 unet = D.UNet2DConditionModel(device=dev).requires_grad_(False)
-lat, mask, mlat, ctx = synth_inputs(4, 64, 64, 577, 1024, device=dev)
+if "--fp16" in sys.argv:
+    unet.to(dtype=torch.float16)
+    lib = unet._lib
+lat, mask, mlat, ctx = synth_inputs(batch, latent, latent, 577, 1024, device=dev)
 
 
 def setting(on):
     if what == "gn_stats":
         lib.dmx_set_gn_producer_stats(int(on))
     elif what == "xf_chain":
-        lib.dmx_set_xf_chain(int(on))
+        lib.dmx_set_xf_chain(2 if on else 0)          # 2: at every supported size (the executor's own rule needs >= 192 row blocks)
     for sl in unet._slots.values():
         sl["ws_need"] = None
     unet._ensure_packed()

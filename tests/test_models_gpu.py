@@ -263,10 +263,14 @@ def test_cfg2_headline_workload_vs_golden(cuda):
         assert torch.isfinite(out).all()
 
 
-def test_cfg1_full_size_block_taps(cuda):
+@pytest.mark.parametrize("chains", [False, True], ids=["separate_gemms", "transformer_chains"])
+def test_cfg1_full_size_block_taps(cuda, chains):
     """per-block checks at FULL size (SD2-inpaint config, cfg1's first UNet call): L2 norm, sum and a strided slice of every
-    block output - conv_in, down0..3, mid, up0..3 - against the committed oracle values (tests/golden/cfg1_taps.npz)."""
+    block output - conv_in, down0..3, mid, up0..3 - against the committed oracle values (tests/golden/cfg1_taps.npz).
+    Run on both forms of the C = 320 transformer blocks: the separate GEMMs (what the executor picks at this size) and the
+    chained kernels of xf_chain.hip forced on (what it picks from 192 row blocks up, e.g. the batch-4 512-px bench)."""
     import diffute_amd as D
+    from diffute_amd import _cabi
     from diffute_amd.synthetic import synth_inputs
     path = os.path.join(GOLD, "cfg1_taps.npz")
     if not os.path.exists(path):
@@ -274,7 +278,11 @@ def test_cfg1_full_size_block_taps(cuda):
     g = np.load(path)
     unet = D.UNet2DConditionModel(device=cuda).requires_grad_(False)
     lat, mask, mlat, ctx = synth_inputs(1, 32, 32, 577, 1024, device=cuda)
-    y, taps = unet.forward_taps(torch.cat([lat, mask, mlat], 1), torch.tensor(int(g["timestep"])), ctx)
+    old = _cabi.lib().dmx_set_xf_chain(2 if chains else 0)
+    try:
+        y, taps = unet.forward_taps(torch.cat([lat, mask, mlat], 1), torch.tensor(int(g["timestep"])), ctx)
+    finally:
+        _cabi.lib().dmx_set_xf_chain(old)
     rep = []
     for k, v in taps.items():
         v = v.float().cpu()
