@@ -6,7 +6,7 @@
 // block streams 64-key K / V tiles through LDS, double buffered.  Row-major V (the UNet path): both tiles go L2 -> LDS by
 // LDS-DMA (global_load_lds, 16 B per lane, no staging registers and no address VALU in the loop: a wave-uniform tile
 // base plus two per-lane constant offsets), unpadded 128-byte rows made conflict-free by XOR swizzles applied on the DMA
-// SOURCE address (K: 16-byte chunk ^ (key & 7) for the ds_read_b128 fragment reads; V: 64-byte half ^ (key & 1) for
+// SOURCE address (K: 16-byte chunk ^ ((key >> 1) & 7) for the ds_read_b128 fragment reads; V: 64-byte half ^ ((key >> 1) & 1) for
 // the transpose reads).  4 % faster than staging through registers (147.7 -> 141.4 us at S = 4096, B*H = 20) and 16
 // VGPRs / 11 KB of LDS lighter.  scripts/attn_pieces.py (probe build) prices the pieces of the loop: exp 19 %, QK MFMAs
 // 17 %, PV MFMAs 10 %, row sum 9 %, row max 5 %, and 34 % for the skeleton (24 LDS fragment reads = 16 KB per wave per
@@ -118,8 +118,15 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   // (row drow, physical 16-byte chunk dchk) of that 1-KB slab and fetches the source chunk the swizzle assigns to it
   const int drow = lane >> 3, dchk = lane & 7;
   const unsigned ldkb = (unsigned)p.ldk * 2u, ldvb = (unsigned)p.ldv * 2u;
-  const unsigned kcb = (unsigned)((dchk ^ drow) << 4);                                             // K: chunk ^ (row & 7)
-  const unsigned vcb = (unsigned)((((((dchk >> 2) ^ (drow & 1)) << 2) | (dchk & 3))) << 4);        // V: 64-byte half ^ (row & 1)
+  // K: chunk ^ ((row >> 1) & 7) - the key that makes the 32-row ds_read_b128 fragment reads conflict-free with 128-byte rows
+  // (row & 7, rounds 1-2, left rows r and r + 8 of a lane group in one bank quad).  Slab rows are 8 (wave + NW i) + drow and
+  // NW is even, so the key is a per-thread constant
+  static_assert(NW % 2 == 0, "K swizzle key assumes an even number of waves");
+  const unsigned kcb = (unsigned)((dchk ^ (((drow >> 1) + 4 * (wave & 1)) & 7)) << 4);
+  // V: 64-byte half ^ ((row >> 1) & 1): a 16-lane group of a transpose read touches 32 bytes of four consecutive rows (128-byte
+  // stride = 32 banks), so rows r and r + 2 must sit in different halves; keyed on row & 1 (rounds 1-2) rows 0 / 2 and 1 / 3 collided:
+  // SQ_LDS_BANK_CONFLICT was 2.7x the LDS instruction cycles of the kernel
+  const unsigned vcb = (unsigned)((((((dchk >> 2) ^ ((drow >> 1) & 1)) << 2) | (dchk & 3))) << 4);
   const unsigned koff = (unsigned)drow * ldkb + kcb, voff = (unsigned)drow * ldvb + vcb;
   const char* kdma = (const char*)(p.k + (size_t)b * p.kv_rows * p.ldk + h * 64);
   const char* vdma = DMA ? (const char*)(p.v + (size_t)b * p.kv_rows * p.ldv + h * 64) : nullptr;
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
       }
     }
   };
-  const int ksw = (lh ^ (lr & 7)) << 4;               // K fragment: row lr (mod 8), chunk (2kk + lh) ^ (lr & 7) == (2kk << 4) ^ ksw
+  const int ksw = (lh ^ ((lr >> 1) & 7)) << 4;        // K fragment: row lr, chunk (2kk + lh) ^ ((lr >> 1) & 7) == (2kk << 4) ^ ksw
 
   f32x16 o[R][2];
   float m_run[R], l_run[R];
@@ -263,10 +270,10 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
     if (VROWMAJOR) {
       // V tile is [key][d]; the MFMA A operand (rows d, k-slots = keys) comes from LDS transpose reads:
       // group g = lane>>4 covers d = 32dt + 16(g&1) + 0..15 and key-half lh = g>>1; two reads per operand.
-      // (all of a lane's rows have row & 1 == (p16 >> 2) & 1: the swizzled half of d-tile dt is a per-lane constant)
+      // (all of a lane's rows have (row >> 1) & 1 == (p16 >> 3) & 1: the swizzled half of d-tile dt is a per-lane constant)
       const int p16 = lane & 15, g = lane >> 4;
       const char* va = vs + (4 * (g >> 1) + (p16 >> 2)) * 128 + (16 * (g & 1) + 4 * (p16 & 3)) * 2;
-      const int vsw = (p16 >> 2) & 1;
+      const int vsw = (p16 >> 3) & 1;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
