@@ -546,3 +546,52 @@ def test_xf_chain_proj_in_ln_qkv(cuda, M):
     assert_close(qkv, qkv_ref, 2e-3, "xf_chain mode 2: q | k | v")
     h_b, qkv_b = ops.xf_chain(2, dv(x), None, dv(wpi), f32(bpi), f32(c1), f32(c2), w1=dv(wf))
     assert torch.equal(h, h_b) and torch.equal(qkv, qkv_b), "xf_chain mode 2 is not bit-stable"
+
+
+def test_xf_chain_two_rounds_and_fp16_build(cuda):
+    """xf_chain on more 64-row blocks than CUs (300: two rounds of the one-block-per-CU grid), bf16 build, and all three modes on
+    the fp16 build of the library (same sources, -DDMX_F16) against fp32 math on fp16-rounded operands."""
+    from diffute_amd import ops
+    C = 320
+    mk = lambda M, seed: (seeded((M, C), seed), seeded((M, C), seed + 1), seeded((M, C), seed + 2))   # noqa: E731
+    wo = seeded((C, C), 41, 1 / math.sqrt(C)); bo = seeded((C,), 42, 0.1)
+    wq = seeded((C, C), 43, 1 / math.sqrt(C)); w3 = seeded((3 * C, C), 44, 1 / math.sqrt(C))
+    w1 = seeded((8 * C, C), 45, 1 / math.sqrt(C)); b1 = seeded((8 * C,), 46, 0.1)
+    w2 = seeded((C, 4 * C), 47, 1 / math.sqrt(4 * C)); b2 = seeded((C,), 48, 0.1)
+    wp = seeded((C, C), 49, 1 / math.sqrt(C)); bp = seeded((C,), 50, 0.1)
+    gamma = 1 + seeded((C,), 51, 0.2); beta = seeded((C,), 52, 0.2)
+
+    def run(elem, M, tols):
+        rnd = bf if elem == "bf16" else h16r
+        dt = torch.bfloat16 if elem == "bf16" else torch.float16
+        dv = lambda v: v.to(cuda).to(dt).contiguous()                     # noqa: E731
+        f32 = lambda v: v.to(cuda).float().contiguous()                   # noqa: E731
+        a, h0, xr = (rnd(v) for v in mk(M, 60))
+        Wo, Wq, W3, W1, W2, Wp = (rnd(v) for v in (wo, wq, w3, w1, w2, wp))
+
+        def fold(w, bias=None):
+            wf = rnd(w * gamma[None, :]); c2 = (w * beta[None, :]).sum(1)
+            return wf, wf.sum(1), c2 if bias is None else c2 + bias
+        with ops.element_type(elem):
+            # mode 2
+            wf, c1, c2 = fold(W3)
+            hp = rnd(F.linear(a, Wo, bo)); mean, rstd = _row_stats(hp)
+            h, y = ops.xf_chain(2, dv(a), None, dv(Wo), f32(bo), f32(c1), f32(c2), w1=dv(wf))
+            assert_close(h, hp, tols[0], f"{elem} mode 2 proj_in"); assert_close(y, rnd(rstd * (hp @ wf.t() - mean * c1) + c2), tols[1], f"{elem} mode 2 qkv")
+            # mode 0
+            wf, c1, c2 = fold(Wq)
+            h1 = rnd(F.linear(a, Wo, bo) + h0); mean, rstd = _row_stats(h1)
+            h, y = ops.xf_chain(0, dv(a), dv(h0), dv(Wo), f32(bo), f32(c1), f32(c2), w1=dv(wf))
+            assert_close(h, h1, tols[0], f"{elem} mode 0 h"); assert_close(y, rnd(rstd * (h1 @ wf.t() - mean * c1) + c2), tols[1], f"{elem} mode 0 q")
+            # mode 1
+            wf, c1, c2 = fold(W1, b1)
+            u = rstd * (h1 @ wf.t() - mean * c1) + c2
+            val, gate = u.chunk(2, dim=-1)
+            h3 = rnd(F.linear(rnd(val * F.gelu(gate)), W2, b2) + h1)
+            yr = rnd(F.linear(h3, Wp, bp) + xr)
+            h, y = ops.xf_chain(1, dv(a), dv(h0), dv(Wo), f32(bo), ops.pack_geglu_bias(f32(c1)), ops.pack_geglu_bias(f32(c2)),
+                                wf1=ops.pack_linear_weight(dv(wf).float(), geglu=True), wf2=dv(W2), bf2=f32(b2), wpo=dv(Wp), bpo=f32(bp), xres=dv(xr))
+            assert_close(h, h1, tols[0], f"{elem} mode 1 h"); assert_close(y, yr, tols[2], f"{elem} mode 1 y")
+
+    run("bf16", 64 * 300, (TOL, 2e-3, 3e-3))
+    run("fp16", 64 * 5, (TOL, TOL, TOL))
