@@ -9,7 +9,7 @@
 //            h3 = h2 + FF2(GEGLU(LN3(h2) W1^T))            (ff.net, hidden 4C never leaves the CU)
 //            y  = h3 Wpo^T + bpo + x                       (proj_out + the Transformer2DModel residual)
 //
-// After self-attention every one of these ops is per query row.  As separate GEMMs they are 6 launches of 12-30 us whose
+// Outside the two attention cores every op of the block is per query row.  As separate GEMMs they are 9 launches of 12-60 us whose
 // K = 320 loops are 70 % prologue + epilogue (scripts/linear_timeline.py), and the 4C-wide hidden tensor makes an 84 MB round
 // trip.  Here a block owns 64 rows: the activation operand of the running GEMM lives in REGISTERS (each wave keeps its 32
 // rows x 320 k as twenty 16x32 fragments), the weights stream through a three-slot LDS ring of [320 n][64 k] tiles by
@@ -20,6 +20,10 @@
 // Eight waves = 2 (rows) x 4 (80 output columns each), v_mfma_f32_16x16x32 with the weight tile as the A operand, so a lane
 // ends up with 4 consecutive output channels of one row (8-byte LDS writes, and a value / gate pair of GEGLU in one lane:
 // FF1's rows are fetched in the order [v0 v1 g0 g1] per lane quad straight from the packed 64-row groups of the arena).
+// Residual tensors arrive as DMA tiles in the exchange layout (the epilogue reads the residual at the LDS address it then writes
+// its output to); the column vectors of the epilogues are staged in LDS once per block.  The LDS-DMA instructions ride between
+// the MFMAs, staggered by wave (mode 1) - the address path takes one 1-KB instruction per ~25 cycles per CU, and eight waves
+// issuing at one program point queue behind each other with the matrix pipes idle (EXPERIMENTS.md, round 3 item 0).
 // Deterministic: no atomics, fixed summation order.
 #include "common.h"
 #include "kernels.h"
@@ -151,7 +155,6 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
 #pragma unroll
     for (int a = 0; a < 5; ++a) { c[a][0] = zero4; c[a][1] = zero4; }
   };
-  // one [320][64] weight tile against k-steps 2J, 2J+1 of the register operand
   // one [320][64] weight tile against k-steps 2J, 2J+1 of the register operand, with the five loads of the prepared tile between the MFMAs
   // rn: the prepared tile is a residual tile (its loads are not affine in i: issued as a burst up front, not between the MFMAs)
   auto mma_tile = [&](const char* st, const int J, f32x4 (&c)[5][2], const bool rn = false) {
