@@ -173,6 +173,10 @@ _PROTOS = {
     "dmx_vae_decode_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "dmx_unet_adamw_step": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P, c_size_t, _P, c_float, _P]),
     "dmx_unet_refresh_derived": (c_int, [_P, _P]),
+    "dmx_unet_temb_table_floats": (c_size_t, [_P, c_int]),
+    "dmx_unet_temb_table_workspace_bytes": (c_size_t, [_P, c_int]),
+    "dmx_unet_temb_table": (c_int, [_P, _P, c_int, _P, _P, c_size_t, _P]),
+    "dmx_unet_use_temb_table": (c_int, [_P, _P, _P]),
     "dmx_mask_rasterize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dmx_preprocess_crop": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "dmx_postprocess_paste": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

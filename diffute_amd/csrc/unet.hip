@@ -365,6 +365,48 @@ struct Fwd {
   }
 };
 
+// row *step of the precomputed time-embedding projection table -> the buffer every resnet's conv1 reads its row bias from
+__global__ __launch_bounds__(256) void dmx_temb_row_kernel(const float* table, const int* step, float* out, int n) {
+  const float* src = table + (size_t)(*step) * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = src[i];
+}
+
+// the time-embedding MLP + the stacked time_emb_proj of every resnet for `rows` timesteps (product path: fp32 math, bf16 weights;
+// each row is computed exactly as the per-step path computes its single row)
+static int temb_rows(dmx_unet* u, Exec& ex, const long long* timesteps, int rows, float* tproj) {
+  const int c0 = u->cfg.block_out_channels[0], temb = u->temb_dim;
+  float* sinus = (float*)ex.raw((size_t)rows * c0 * 4);
+  float* e1 = (float*)ex.raw((size_t)rows * temb * 4);
+  float* emb = (float*)ex.raw((size_t)rows * temb * 4);
+  if (!ex.dry && !ex.rc) {
+    ex.rc = dmx_timestep_embedding_launch(timesteps, rows, u->at<float>(u->freq), rows, c0, sinus, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(sinus, c0, u->at<bf16>(u->te_w1), c0, u->at<float>(u->te_b1), e1, temb, rows, temb, c0, 0, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(e1, temb, u->at<bf16>(u->te_w2), temb, u->at<float>(u->te_b2), emb, temb, rows, temb, temb, 1, ex.stream);
+    if (!ex.rc) ex.rc = dmx_linear_small_launch(emb, temb, u->at<bf16>(u->tp_w), temb, u->at<float>(u->tp_b), tproj, u->tproj_total, rows, u->tproj_total, temb, 1, ex.stream);
+  }
+  ex.drop(sinus); ex.drop(e1); ex.drop(emb);
+  return ex.rc;
+}
+extern "C" size_t dmx_unet_temb_table_floats(dmx_unet* u, int T) { return u ? (size_t)T * u->tproj_total : 0; }
+extern "C" size_t dmx_unet_temb_table_workspace_bytes(dmx_unet* u, int T) {
+  if (!u) return 0;
+  Exec ex; ex.dry = true; ex.ws.reset(nullptr, 0, true);
+  temb_rows(u, ex, nullptr, T, nullptr);
+  return ex.ws.peak() + 4096;
+}
+extern "C" int dmx_unet_temb_table(dmx_unet* u, const int64_t* timesteps, int T, float* table, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(u && u->finalized, "unet_temb_table: weights not finalized");
+  DMX_REQUIRE(timesteps && table && workspace && T > 0, "unet_temb_table: null argument");
+  Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
+  return temb_rows(u, ex, (const long long*)timesteps, T, table);
+}
+extern "C" int dmx_unet_use_temb_table(dmx_unet* u, const float* table, const int* step_index) {
+  DMX_REQUIRE(u != nullptr, "unet_use_temb_table: null handle");
+  DMX_REQUIRE((table == nullptr) == (step_index == nullptr), "unet_use_temb_table: table and step index go together");
+  u->temb_table = table; u->temb_step = step_index;
+  return DMX_OK;
+}
+
 int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
              const long long* timesteps, int t_count, const void* cache, int ctx_len, float* out, int B, int H, int W) {
   const dmx_unet_config& cfg = u->cfg;
@@ -425,10 +467,16 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
     ex.drop(x9);
   } else {
     if (!ex.dry && !ex.rc) {
-      ex.rc = dmx_timestep_embedding_launch(timesteps, t_count, u->at<float>(u->freq), Bt, boc[0], sinus, ex.stream);
-      if (!ex.rc) ex.rc = dmx_linear_small_launch(sinus, boc[0], u->at<bf16>(u->te_w1), boc[0], u->at<float>(u->te_b1), e1, temb, Bt, temb, boc[0], 0, ex.stream);
-      if (!ex.rc) ex.rc = dmx_linear_small_launch(e1, temb, u->at<bf16>(u->te_w2), temb, u->at<float>(u->te_b2), emb, temb, Bt, temb, temb, 1, ex.stream);
-      if (!ex.rc) ex.rc = dmx_linear_small_launch(emb, temb, u->at<bf16>(u->tp_w), temb, u->at<float>(u->tp_b), tproj, u->tproj_total, Bt, u->tproj_total, temb, 1, ex.stream);
+      if (u->temb_table && t_count == 1) {
+        // the loop computed the projections of all its timesteps in one batched pass (dmx_unet_temb_table): fetch this step's row
+        hipLaunchKernelGGL(dmx_temb_row_kernel, dim3(cdiv(u->tproj_total, 1024)), dim3(256), 0, ex.stream, u->temb_table, u->temb_step, tproj, u->tproj_total);
+        ex.rc = dmx_check_launch("dmx_temb_row_kernel");
+      } else {
+        ex.rc = dmx_timestep_embedding_launch(timesteps, t_count, u->at<float>(u->freq), Bt, boc[0], sinus, ex.stream);
+        if (!ex.rc) ex.rc = dmx_linear_small_launch(sinus, boc[0], u->at<bf16>(u->te_w1), boc[0], u->at<float>(u->te_b1), e1, temb, Bt, temb, boc[0], 0, ex.stream);
+        if (!ex.rc) ex.rc = dmx_linear_small_launch(e1, temb, u->at<bf16>(u->te_w2), temb, u->at<float>(u->te_b2), emb, temb, Bt, temb, temb, 1, ex.stream);
+        if (!ex.rc) ex.rc = dmx_linear_small_launch(emb, temb, u->at<bf16>(u->tp_w), temb, u->at<float>(u->tp_b), tproj, u->tproj_total, Bt, u->tproj_total, temb, 1, ex.stream);
+      }
     }
     ex.drop(sinus); ex.drop(e1); ex.drop(emb);
     // ---- conv_in: cat + layout + im2col, then GEMM
@@ -575,7 +623,7 @@ extern "C" int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, cons
   DMX_REQUIRE(u && u->finalized, "unet_forward_graph: weights not finalized");
   if (stream == nullptr || dmx_profile_active())
     return dmx_unet_forward(u, f0, c0, f1, c1, f2, c2, timesteps, t_count, cache, ctx_len, out, B, H, W, workspace, workspace_bytes, stream);
-  dmx_unet::GraphKey key(f0, f1, f2, timesteps, cache, out, workspace, c0, c1, c2, t_count, ctx_len, B, H, W);
+  dmx_unet::GraphKey key(f0, f1, f2, timesteps, cache, out, workspace, c0, c1, c2, t_count, ctx_len, B, H, W, u->temb_table, u->temb_step);
   dmx_unet::GraphEntry& e = u->graphs[key];
   hipStream_t s = (hipStream_t)stream;
   if (e.exec) { DMX_HIP(hipGraphLaunch(e.exec, s)); return DMX_OK; }

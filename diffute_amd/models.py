@@ -384,11 +384,25 @@ class UNet2DConditionModel(_HipModel):
         sl["ctx_key"] = (encoder_hidden_states, encoder_hidden_states._version)
         sl["ctx_shape"] = (B, S)
 
-    def forward_parts(self, parts, timesteps_dev, out=None, graph=False, slot=0):
+    def temb_table(self, timesteps_dev):
+        """[T][sum of resnet widths] fp32: the time-embedding MLP + every resnet's time_emb_proj for ALL the (scalar) timesteps of a
+        denoise loop in one batched pass (include/diffute_hip.h dmx_unet_temb_table); forward_parts(..., temb=(table, step_index))
+        then fetches row *step_index instead of recomputing four small layers per step.  Rows are bit-identical to the per-step path."""
+        self._ensure_packed()
+        lib = self._lib
+        T = int(timesteps_dev.numel())
+        table = torch.empty(int(lib.dmx_unet_temb_table_floats(self._h, T)), dtype=torch.float32, device=timesteps_dev.device)
+        ws = torch.empty(int(lib.dmx_unet_temb_table_workspace_bytes(self._h, T)), dtype=torch.uint8, device=timesteps_dev.device)
+        _cabi.check(lib.dmx_unet_temb_table(self._h, _cabi.ptr(timesteps_dev), T, _cabi.ptr(table), _cabi.ptr(ws), ws.numel(),
+                                            _cabi.current_stream()), "unet_temb_table")
+        return table.view(T, -1)
+
+    def forward_parts(self, parts, timesteps_dev, out=None, graph=False, slot=0, temb=None):
         """Hot-loop entry: `parts` = list of (NCHW fp32 cuda tensor) whose channels sum to in_channels
         (fuses the torch.cat of app.ipynb:811); timesteps_dev = int64 cuda tensor [1] or [B];
         context must have been set with set_context() on the same slot.  graph=True replays a captured hipGraph
-        when the same buffers are passed again (needs a non-default current stream)."""
+        when the same buffers are passed again (needs a non-default current stream).  temb = (temb_table(...), int32 cuda
+        tensor [1] holding the step's row): the time-embedding projections come from the table (scalar timestep only)."""
         lib = self._lib
         sl = self._slot(slot)
         x0 = parts[0]
@@ -403,10 +417,16 @@ class UNet2DConditionModel(_HipModel):
             sl["ws_need"] = (key, lib.dmx_unet_workspace_bytes(self._h, B, H, W, sl["ctx_shape"][1]))
         ws = self._slot_workspace(sl, sl["ws_need"][1])
         fwd = lib.dmx_unet_forward_graph if graph else lib.dmx_unet_forward
-        _cabi.check(fwd(self._h, _cabi.ptr(ps[0][0]), ps[0][1], _cabi.ptr(ps[1][0]), ps[1][1],
-                        _cabi.ptr(ps[2][0]), ps[2][1], _cabi.ptr(timesteps_dev), timesteps_dev.numel(),
-                        _cabi.ptr(sl["ctx_cache"]), sl["ctx_shape"][1], _cabi.ptr(out), B, H, W,
-                        _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_forward")
+        if temb is not None:
+            _cabi.check(lib.dmx_unet_use_temb_table(self._h, _cabi.ptr(temb[0]), _cabi.ptr(temb[1])), "unet_use_temb_table")
+        try:
+            _cabi.check(fwd(self._h, _cabi.ptr(ps[0][0]), ps[0][1], _cabi.ptr(ps[1][0]), ps[1][1],
+                            _cabi.ptr(ps[2][0]), ps[2][1], _cabi.ptr(timesteps_dev), timesteps_dev.numel(),
+                            _cabi.ptr(sl["ctx_cache"]), sl["ctx_shape"][1], _cabi.ptr(out), B, H, W,
+                            _cabi.ptr(ws), ws.numel(), _cabi.current_stream()), "unet_forward")
+        finally:
+            if temb is not None:
+                lib.dmx_unet_use_temb_table(self._h, None, None)
         return out
 
     # ---- validation / debugging (tests only): per-block taps of the product path, and the fp32 instantiation of the graph

@@ -12,6 +12,7 @@ from .schedulers import DDIMScheduler, DDPMScheduler
 
 
 _SIDE = {}
+TEMB_TABLE = True      # denoise(): time-embedding projections of all steps in one batched pass (False: four small launches per step; A/B aid)
 
 
 def _side_streams(device, n):
@@ -31,14 +32,16 @@ def mask_to_latent(mask, vae_scale_factor=8):
 class _Run:
     """One micro-batch of the denoise loop: its own stream, UNet execution slot and fixed-address buffers."""
 
-    def __init__(self, unet, scheduler, latents, mask, mlat, ctx, slot, stream, use_graph):
+    def __init__(self, unet, scheduler, latents, mask, mlat, ctx, slot, stream, use_graph, temb_table=None):
         self.unet, self.sched, self.slot, self.stream, self.use_graph = unet, scheduler, slot, stream, use_graph
+        self.temb_table = temb_table
         with torch.cuda.stream(stream):
             self.x = (latents.to(torch.float32) * scheduler.init_noise_sigma).contiguous()      # app.ipynb:800
             self.m = mask.to(torch.float32).contiguous()
             self.ml = mlat.to(torch.float32).contiguous()
             self.eps = torch.empty_like(self.x)
             self.t_cur = torch.empty(1, dtype=torch.int64, device=self.x.device)   # fixed address: the captured graph reads it
+            self.step_idx = torch.zeros(1, dtype=torch.int32, device=self.x.device)   # likewise: the row of temb_table this step fetches
             unet.set_context(ctx, slot=slot)
 
     def step(self, i, t, ts_dev, coefs, noise, is_ddim, vpred):
@@ -46,8 +49,13 @@ class _Run:
         x, eps = self.x, self.eps
         with torch.cuda.stream(self.stream):
             st = _cabi.current_stream()
-            self.t_cur.copy_(ts_dev[i:i + 1], non_blocking=True)
-            self.unet.forward_parts([x, self.m, self.ml], self.t_cur, out=eps, graph=self.use_graph, slot=self.slot)
+            if self.temb_table is not None:
+                self.step_idx.copy_(ts_dev[1][i:i + 1], non_blocking=True)
+                self.unet.forward_parts([x, self.m, self.ml], self.t_cur, out=eps, graph=self.use_graph, slot=self.slot,
+                                        temb=(self.temb_table, self.step_idx))
+            else:
+                self.t_cur.copy_(ts_dev[0][i:i + 1], non_blocking=True)
+                self.unet.forward_parts([x, self.m, self.ml], self.t_cur, out=eps, graph=self.use_graph, slot=self.slot)
             # the update is elementwise, so prev_sample overwrites the sample in place (stable pointers for the graph)
             if is_ddim:
                 sbt, sat, sap, dirc, std = coefs
@@ -81,12 +89,16 @@ def denoise(unet, scheduler, latents, mask, masked_image_latents, encoder_hidden
     n = max(1, min(int(micro_batches), B))
     bounds = [(B * j // n, B * (j + 1) // n) for j in range(n)]
     main = torch.cuda.current_stream(dev)
+    # the time-embedding MLP + every resnet's time_emb_proj depend on the timestep only: all steps' rows in one batched pass up
+    # front (bit-identical rows), each step then fetches its row with one tiny launch instead of recomputing four small layers
+    temb_table = unet.temb_table(ts_dev) if (ts_host and TEMB_TABLE) else None
+    ts_dev = (ts_dev, torch.arange(len(ts_host), dtype=torch.int32, device=dev))
     streams = _side_streams(dev, n)             # the loop runs on side streams: graph capture needs a non-default stream
     runs = []
     for j, (lo, hi) in enumerate(bounds):
         streams[j].wait_stream(main)
         runs.append(_Run(unet, scheduler, latents[lo:hi], mask[lo:hi], masked_image_latents[lo:hi],
-                         encoder_hidden_states[lo:hi].contiguous(), j, streams[j], use_graph))
+                         encoder_hidden_states[lo:hi].contiguous(), j, streams[j], use_graph, temb_table))
     for i, t in enumerate(ts_host):
         coefs = scheduler.step_coefficients(t, eta) if is_ddim else scheduler.step_coefficients(t)
         need_noise = (eta > 0) if is_ddim else (t > 0)

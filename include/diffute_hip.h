@@ -324,6 +324,16 @@ int dmx_unet_forward(dmx_unet* u, const float* f0, int c0, const float* f1, int 
                      const int64_t* timesteps, int t_count, const void* context_cache, int ctx_len,
                      float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 
+/* The time-embedding MLP and the stacked time_emb_proj of every resnet depend on the timestep only: a denoise loop
+ * (/root/reference/app.ipynb:806-816) can compute them for ALL its timesteps in one batched pass and let each step fetch its row
+ * - one tiny launch instead of four per step, and the 49 MB of projection weights are streamed once per loop instead of once
+ * per step.  Rows are bit-identical to what the per-step path computes.  dmx_unet_temb_table fills table[T][tproj] (fp32;
+ * dmx_unet_temb_table_floats(T) elements); dmx_unet_use_temb_table(u, table, step_index) makes the following scalar-timestep
+ * forwards read row *step_index (an int on the device, updated by the caller between steps); (NULL, NULL) switches back. */
+size_t dmx_unet_temb_table_floats(dmx_unet* u, int T);
+size_t dmx_unet_temb_table_workspace_bytes(dmx_unet* u, int T);
+int dmx_unet_temb_table(dmx_unet* u, const int64_t* timesteps, int T, float* table, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+int dmx_unet_use_temb_table(dmx_unet* u, const float* table, const int* step_index);
 /* Same as dmx_unet_forward; the launch sequence is captured into a hipGraph the second time an identical argument
  * tuple is seen and replayed afterwards.  Requires a non-NULL stream (falls back to eager launches otherwise). */
 int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,

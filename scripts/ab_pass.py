@@ -26,6 +26,9 @@ lat, mask, mlat, ctx = synth_inputs(batch, latent, latent, 577, 1024, device=dev
 def setting(on):
     if what == "gn_stats":
         lib.dmx_set_gn_producer_stats(int(on))
+    elif what == "temb_table":
+        import diffute_amd.pipeline as P
+        P.TEMB_TABLE = bool(on)
     elif what == "xf_chain":
         lib.dmx_set_xf_chain(2 if on else 0)          # 2: at every supported size (the executor's own rule needs >= 192 row blocks)
     for sl in unet._slots.values():
