@@ -203,6 +203,9 @@ def test_tiny_denoise_loops(cuda, tiny_unet):
             eps = tiny_unet(inp, t, ctx).sample
             x = sch.step(eps, t, x).prev_sample
     assert torch.equal(x, out)
+    # two independent chains of the batch on two streams (each with its own graph, step index and slot of the context cache)
+    out_mb = D.denoise(tiny_unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 4, micro_batches=2)
+    assert_close(out_mb, out.cpu(), 1e-2, "micro-batched DDIM loop vs the single chain")
 
 
 def test_cfg1_full_golden(cuda):
