@@ -135,7 +135,22 @@ class _SchedulerBase:
 
 
 class DDPMScheduler(_SchedulerBase):
-    """The scheduler the reference instantiates (app.ipynb:545, train_diffute_v1.py:628)."""
+    """The scheduler the reference instantiates (app.ipynb:545, train_diffute_v1.py:628).
+
+    `steps_offset`: implemented is the behaviour of the diffusers release the reference was written against (0.15-era,
+    SURVEY Appendix A.3): DDPMScheduler.set_timesteps does NOT add `steps_offset` to the leading-spaced grid (the inference
+    grid ends at timestep 0), while DDIMScheduler does.  Later diffusers releases apply the offset to DDPM as well.  The SD2
+    `scheduler_config.json` carries `steps_offset: 1`; the key is kept in `.config` (round trip through save_pretrained) and a
+    warning says once per process that the DDPM grid ignores it."""
+    _warned_offset = False
+
+    def __init__(self, **config):
+        super().__init__(**config)
+        if int(self.config.steps_offset) != 0 and not DDPMScheduler._warned_offset:
+            DDPMScheduler._warned_offset = True
+            import warnings
+            warnings.warn(f"DDPMScheduler: steps_offset={self.config.steps_offset} is kept in the config but NOT applied to the "
+                          "inference grid (the behaviour of the diffusers release the reference uses; later releases add it)", stacklevel=2)
 
     def set_timesteps(self, num_inference_steps, device=None):
         self.num_inference_steps = int(num_inference_steps)
