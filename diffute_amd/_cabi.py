@@ -41,6 +41,18 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class HaloConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("x0", c_void_p), ("x1", c_void_p), ("ldx0", c_int), ("ldx1", c_int), ("cx0", c_int), ("Cin", c_int),
+        ("B", c_int), ("H", c_int), ("W", c_int), ("gn", c_int), ("silu", c_int), ("groups", c_int), ("eps", c_float),
+        ("st0", c_void_p), ("st1", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+        ("s0", c_void_p), ("s1", c_void_p), ("lds0", c_int), ("lds1", c_int), ("cs0", c_int), ("Csc", c_int),
+        ("w", c_void_p), ("ldw", c_int), ("N", c_int), ("bias", c_void_p), ("rowbias", c_void_p), ("ldrb", c_int),
+        ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("colstats", c_void_p),
+        ("force_split", c_int), ("dbg", c_int), ("timing", c_void_p),
+    ]
+
+
 class ViTConfig(ctypes.Structure):
     _fields_ = [("image_size", c_int), ("patch_size", c_int), ("num_channels", c_int), ("hidden_size", c_int), ("num_layers", c_int),
                 ("num_heads", c_int), ("intermediate_size", c_int), ("qkv_bias", c_int), ("layer_norm_eps", c_float)]
@@ -67,6 +79,11 @@ _PROTOS = {
     "dmx_conv_gemm_rowstats_tiles": (c_int, [POINTER(GemmDesc)]),
     "dmx_conv_gemm_colstats_ok": (c_int, [POINTER(GemmDesc)]),
     "dmx_set_gn_producer_stats": (c_int, [c_int]),
+    "dmx_conv3x3_gn_supported": (c_int, [POINTER(HaloConvDesc)]),
+    "dmx_conv3x3_gn_workspace_bytes": (c_size_t, [POINTER(HaloConvDesc)]),
+    "dmx_conv3x3_gn": (c_int, [POINTER(HaloConvDesc), _P, c_size_t, _P]),
+    "dmx_colstats": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "dmx_set_halo_conv": (c_int, [c_int]),
     "dmx_xf_chain_ok": (c_int, [c_int, c_int]),
     "dmx_xf_chain": (c_int, [POINTER(XfChainDesc), c_int, _P]),
     "dmx_set_xf_chain": (c_int, [c_int]),

@@ -116,6 +116,27 @@ extern "C" int dmx_groupnorm_from_stats(const void* x0, int ldx0, const void* x1
   a.y = (bf16*)y; a.ldy = ldy; a.st0 = st0; a.st1 = x1 ? st1 : st0;
   return dmx_groupnorm_sums_launch(a, (hipStream_t)stream);
 }
+static HaloConvArgs halo_args(const dmx_halo_conv_desc* d) {
+  HaloConvArgs a{};
+  a.x0 = (const bf16*)d->x0; a.x1 = (const bf16*)d->x1; a.ldx0 = d->ldx0; a.ldx1 = d->ldx1; a.cx0 = d->x1 ? d->cx0 : d->Cin; a.Cin = d->Cin;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.gn = d->gn; a.silu = d->silu; a.groups = d->groups; a.eps = d->eps;
+  a.st0 = d->st0; a.st1 = d->st1; a.gamma = d->gamma; a.beta = d->beta;
+  a.s0 = (const bf16*)d->s0; a.s1 = (const bf16*)d->s1; a.lds0 = d->lds0; a.lds1 = d->lds1; a.cs0 = d->s1 ? d->cs0 : d->Csc; a.Csc = d->s0 ? d->Csc : 0;
+  a.w = (const bf16*)d->w; a.ldw = d->ldw; a.N = d->N; a.bias = d->bias; a.rowbias = d->rowbias; a.ldrb = d->ldrb;
+  a.res = (const bf16*)d->res; a.ldres = d->ldres; a.out = (bf16*)d->out; a.ldo = d->ldo; a.colstats = d->colstats;
+  a.force_split = d->force_split; a.dbg = d->dbg; a.timing = d->timing;
+  return a;
+}
+extern "C" int dmx_conv3x3_gn_supported(const dmx_halo_conv_desc* d) { return d && dmx_conv_halo_supported(halo_args(d)) ? 1 : 0; }
+extern "C" size_t dmx_conv3x3_gn_workspace_bytes(const dmx_halo_conv_desc* d) { return d ? dmx_conv_halo_workspace_bytes(halo_args(d)) : 0; }
+extern "C" int dmx_conv3x3_gn(const dmx_halo_conv_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(d && d->x0 && d->w && d->out, "conv3x3_gn: null argument");
+  return dmx_conv_halo_launch(halo_args(d), workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int dmx_colstats(const void* x, int ldx, int B, int HW, int C, long long* st, dmx_stream_t stream) {
+  DMX_REQUIRE(x && st, "colstats: null argument");
+  return dmx_colstats_launch((const bf16*)x, ldx, B, HW, C, st, (hipStream_t)stream);
+}
 extern "C" int dmx_xf_chain_ok(int M, int C) { return dmx_xf_chain_supported(M, C) ? 1 : 0; }
 extern "C" int dmx_xf_chain(const dmx_xf_chain_desc* d, int mode, dmx_stream_t stream) {
   DMX_REQUIRE(d != nullptr, "xf_chain: null descriptor");

@@ -131,6 +131,22 @@ __device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
   return x * 0.5f * (erf_v + 1.0f);
 }
 
+// ---- GroupNorm statistics records ("DmxStat"): per (sample, channel) FOUR 64-bit integers {sum * 2^20, floor(sumsq * 2^8),
+// (sumsq - that) * 2^40, 0}, accumulated with integer atomics: integer addition is associative, so the totals are bit-reproducible
+// whatever order the tiles finish in.  The two-word sum of squares is exact to 2^-40 per addend and cannot wrap below 2^55 = 3.6e16
+// (512 x 512 pixels at an RMS of 3.7e5) - the single word scaled by 2^32 of round 3 wrapped at 2^31 (RMS ~90 at 512 x 512).
+#define DMX_STAT_WORDS 4
+__device__ __forceinline__ void dmx_stat_add(long long* dst, float sum, float sumsq) {
+  const double s = fmin(fmax((double)sum, -4.0e12), 4.0e12), q = fmin(fmax((double)sumsq, 0.0), 3.0e16);
+  const long long qh = (long long)(q * 256.0);
+  const long long ql = (long long)__builtin_rint((q - (double)qh * (1.0 / 256.0)) * 1099511627776.0);
+  __hip_atomic_fetch_add(dst, (long long)__builtin_rint(s * 1048576.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(dst + 1, qh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(dst + 2, ql, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double dmx_stat_sum(long long s) { return (double)s * (1.0 / 1048576.0); }
+__device__ __forceinline__ double dmx_stat_sumsq(long long qh, long long ql) { return (double)qh * (1.0 / 256.0) + (double)ql * (1.0 / 1099511627776.0); }
+
 // dynamic-LDS opt-in above 64 KB: a per-DEVICE function attribute, so it is set once per (kernel, device), result checked
 #define DMX_LDS_OPT_IN(kernel, bytes)                                                                        \
   do {                                                                                                       \

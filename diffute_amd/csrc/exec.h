@@ -79,8 +79,8 @@ int dmx_master_import(const ParamTable& pt, void* masters, const char* name, con
 
 struct Tn {                 // NHWC bf16 activation [B*H*W][C] with row stride ld
   bf16* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0;
-  // GroupNorm statistics of this tensor, written by the epilogue of the GEMM that produced it (GemmArgs.colstats): [B][C][2]
-  // fixed-point (sum, sum of squares); null when the producer could not emit them (split-K plans, fp32 mode, ...)
+  // GroupNorm statistics of this tensor, written by the epilogue of the GEMM that produced it (GemmArgs.colstats / HaloConvArgs.colstats): [B][C][4]
+  // DmxStat records (common.h); null when the producer could not emit them (split-K plans, fp32 mode, ...)
   const long long* cst = nullptr;
   int rows() const { return B * H * W; }
 };
@@ -136,6 +136,7 @@ class Exec {
   // Statistics slices (Tn::cst) come from a pool zeroed once per forward as well (the producers ADD into them).
   long long* cs_pool = nullptr; size_t cs_cap = 0, cs_used = 0;
   void want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B);
+  long long* stat_slice(int B, int C);
   void drop(const void* p) { ws.release(p); }
   void drop(const Tn& t) { drop((const void*)t.p); }
 

@@ -126,18 +126,30 @@ void Workspace::release(const void* p) {
 static int g_gn_producer_stats = 1;
 extern "C" int dmx_set_gn_producer_stats(int on) { const int old = g_gn_producer_stats; g_gn_producer_stats = on; return old; }
 
+static int g_halo_conv = 1;
+extern "C" int dmx_set_halo_conv(int on) { const int old = g_halo_conv; g_halo_conv = on; return old; }
+bool dmx_halo_conv_enabled() { return g_halo_conv != 0; }
+
+// a zeroed slice of DmxStat records [B][C][4] from the per-forward pool (null when it is exhausted)
+long long* Exec::stat_slice(int B, int C) {
+  if (rc) return nullptr;
+  if (!cs_pool) {
+    cs_cap = (size_t)B * 64 * 1024;                    // 64 k channels per sample over the forward (SD2 UNet: ~42 k)
+    cs_pool = (long long*)raw(cs_cap * DMX_STAT_WORDS * sizeof(long long)); cs_used = 0;
+    if (!dry && !rc && hipMemsetAsync(cs_pool, 0, cs_cap * DMX_STAT_WORDS * sizeof(long long), stream) != hipSuccess) { dmx_set_error("statistics pool memset failed"); rc = DMX_ERR_HIP; return nullptr; }
+  }
+  const size_t n = (size_t)B * C;
+  if (cs_used + n > cs_cap) return nullptr;
+  long long* s = cs_pool + DMX_STAT_WORDS * cs_used; cs_used += n;
+  return s;
+}
+
 void Exec::want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B) {
   if (rc || f32 || !g_gn_producer_stats) return;
   a.cs_rows = rows_per_sample;
   if (!dmx_gemm_colstats_ok(a)) { a.cs_rows = 0; return; }
-  if (!cs_pool) {
-    cs_cap = (size_t)B * 64 * 1024;                    // 64 k channels per sample over the forward (SD2 UNet: ~42 k) x 2 values
-    cs_pool = (long long*)raw(cs_cap * 2 * sizeof(long long)); cs_used = 0;
-    if (!dry && !rc && hipMemsetAsync(cs_pool, 0, cs_cap * 2 * sizeof(long long), stream) != hipSuccess) { dmx_set_error("statistics pool memset failed"); rc = DMX_ERR_HIP; return; }
-  }
-  const size_t n = (size_t)B * a.N;
-  if (cs_used + n > cs_cap) { a.cs_rows = 0; return; }        // pool exhausted: the consumer computes its own statistics
-  a.colstats = cs_pool + 2 * cs_used; cs_used += n;
+  a.colstats = stat_slice(B, a.N);
+  if (!a.colstats) { a.cs_rows = 0; return; }                 // pool exhausted: the consumer computes its own statistics
   y.cst = a.colstats;
 }
 

@@ -627,10 +627,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
       float sa = 0.f, sq = 0.f;
       for (int k = 0; k < nrl; ++k) { sa += red[(k * BN + c) * 2]; sq += red[(k * BN + c) * 2 + 1]; }
       const int smp = m0 / p.cs_rows;
-      long long* dst = p.colstats + ((size_t)smp * p.N + n0 + c) * 2;
-      const float sc = fminf(fmaxf(sa, -4.0e12f), 4.0e12f), qc = fminf(sq, 2.0e9f);
-      __hip_atomic_fetch_add(dst, (long long)(sc * 1048576.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(dst + 1, (long long)(qc * 4294967296.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dmx_stat_add(p.colstats + ((size_t)smp * p.N + n0 + c) * DMX_STAT_WORDS, sa, sq);
     }
   };
   // ---------------------------------------------------------------- epilogue

@@ -7,7 +7,7 @@
 // Optional per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg).
 enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN = 3, PROF_GNORM = 4, PROF_LNORM = 5,
                  PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_WGRAD = 8, PROF_GEMM256WS = 9,
-                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_NCLASS = 27 };
+                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_HALO = 27 /* conv_halo.hip */, PROF_NCLASS = 28 };
 struct ProfScope {
   ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag = nullptr);
   ~ProfScope();
@@ -54,8 +54,8 @@ struct GemmArgs {
   // persistent stream-K launch (filled by the launcher): grid = one block per CU walking (tile, K-range) items; `partial` holds
   // one accumulator slab per block, `flags` one int per block, all zero at launch (see the kernel's work-item loop)
   int persist; int* flags;
-  // GroupNorm statistics of the output for its consumer (norm.hip dmx_groupnorm_sums_launch): per (sample, channel) 64-bit fixed-point
-  // (sum * 2^20, sum of squares * 2^32) of the rounded outputs, ADDED into colstats[(sample*N + n)*2 ..] (zero before the launch);
+  // GroupNorm statistics of the output for its consumer (norm.hip dmx_groupnorm_sums_launch, conv_halo.hip): per (sample, channel) a
+  // DmxStat record (common.h; 4 x int64 fixed point) of the rounded outputs, ADDED into colstats[(sample*N + n)*4 ..] (zero before the launch);
   // cs_rows = rows per sample (a tile must not straddle samples: cs_rows % tile rows == 0).  Plans without a reduce pass only
   // (dmx_gemm_colstats_ok); bf16 coalesced epilogues.
   long long* colstats; int cs_rows;
@@ -74,6 +74,36 @@ int dmx_gemm_tiles_n(const GemmArgs& a);       // n-tiles of the plan that dmx_g
 int dmx_ups_phase_weights_launch(const bf16* w3, int ldw3, bf16* wp, int N, int Cin, hipStream_t stream);
 int dmx_ln_fold_launch(const bf16* w_raw, bf16* w_out, const float* gamma, const float* beta, const float* bias,
                        float* c1, float* c2, int N, int K, hipStream_t stream);
+
+// ------------------------------------------------------------------ conv_halo.hip
+// 3x3 stride-1 pad-1 convolution with a HALO input tile staged once per 64-channel chunk in LDS (the nine taps are shifted LDS
+// fragment reads; only the weight tiles stream) and the preceding GroupNorm(+SiLU) applied to the staged tile in place, from the
+// per-(sample, channel) statistics its producer(s) emitted (DmxStat below).  ResnetBlock2D = [GN -> SiLU -> conv3x3] x 2 becomes two launches.
+struct HaloConvArgs {
+  const bf16* x0; const bf16* x1; int ldx0, ldx1;   // NHWC input, two-source channel concat (x1 may be null)
+  int cx0, Cin;                                      // channels [0, cx0) from x0, [cx0, Cin) from x1; both multiples of 64
+  int B, H, W;                                       // input grid = output grid
+  int gn, silu, groups; float eps;                   // gn = 1: y = GroupNorm(x)[SiLU] is what the conv sees (zero padding applies to y)
+  const long long* st0; const long long* st1;        // DmxStat records [B][channels of x0 | x1][4]
+  const float* gamma; const float* beta;             // [Cin]
+  const bf16* s0; const bf16* s1; int lds0, lds1, cs0, Csc;   // fused 1x1 shortcut K segment on RAW tensors of the output grid (Csc = 0: none)
+  const bf16* w; int ldw;                            // [N][9*Cin + Csc]: k = tap*Cin + c, then the shortcut channels
+  int N;                                             // multiple of 160 or of 128
+  const float* bias; const float* rowbias; int ldrb; // rowbias[b*ldrb + n] (time-embedding projection) or null
+  const bf16* res; int ldres;                        // residual (output grid) or null
+  bf16* out; int ldo;
+  long long* colstats;                               // DmxStat records of the OUTPUT [B][N][4], added to (zero before the launch), or null
+  int force_split;                                   // 0 = automatic K split (1 / 2 / 4 / 8 blocks per tile)
+  int dbg; long long* timing;                        // measurement aids (0 / null in the product path)
+  // filled by the launcher
+  int TH, TW, splits; float* slabs; int* flags; const bf16* zeros;
+};
+bool dmx_conv_halo_supported(const HaloConvArgs& a);
+size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a);
+int dmx_conv_halo_flag_count(const HaloConvArgs& a);   // ints of zeroed flags the launch needs (0: none)
+int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
+// statistics of a tensor nobody emitted them for: one streaming pass, DmxStat records [B][C][4] (zero before the launch)
+int dmx_colstats_launch(const bf16* x, int ldx, int B, int HW, int C, long long* st, hipStream_t stream);
 
 // ------------------------------------------------------------------ wgrad.hip (training)
 struct WgradArgs {
@@ -104,7 +134,7 @@ struct GroupNormArgs {
   float* stats_out;   // optional [B][groups][2] = (mean, rstd), kept for the backward pass (training)
   float* coef;        // [B][C][2] (filled by the launcher: lives behind partial in the workspace)
   // statistics from the producers of x0 / x1 (GemmArgs.colstats of the GEMM that wrote each tensor): [B][channels of that
-  // tensor][2] fixed-point (sum * 2^20, sumsq * 2^32); dmx_groupnorm_sums_launch only
+  // tensor][4] DmxStat records (common.h); dmx_groupnorm_sums_launch only
   const long long* st0; const long long* st1;
   int nchunk, rows_per_chunk;
 };

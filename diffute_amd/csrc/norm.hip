@@ -86,23 +86,25 @@ __global__ __launch_bounds__(1024) void dmx_gn_apply_kernel(const GroupNormArgs 
   if (p.st0) {
     // statistics from the PRODUCER of the tensor(s): per (sample, channel) fixed-point (sum * 2^20, sumsq * 2^32) written by the
     // epilogue of the GEMM that produced x0 / x1 (gemm.hip publish_colstats) - no statistics pass over the tensor at all
-    extern __shared__ float csum[];                    // [C] sums, [C] sums of squares
+    // (DmxStat records, common.h).  The group reduction and the variance run in double: the integer records are exact, and
+    // E[x^2] - mean^2 in fp32 loses the variance of channels with a large DC offset (advisor, round 3)
+    extern __shared__ double csum[];                   // [C] sums, [C] sums of squares
     for (int c = t; c < p.C; c += blockDim.x) {
-      const long long* q = (c < p.c0) ? p.st0 + ((size_t)b * p.c0 + c) * 2 : p.st1 + ((size_t)b * (p.C - p.c0) + (c - p.c0)) * 2;
-      csum[c] = (float)q[0] * (1.0f / 1048576.0f);
-      csum[p.C + c] = (float)((double)q[1] * (1.0 / 4294967296.0));
+      const long long* q = (c < p.c0) ? p.st0 + ((size_t)b * p.c0 + c) * DMX_STAT_WORDS : p.st1 + ((size_t)b * (p.C - p.c0) + (c - p.c0)) * DMX_STAT_WORDS;
+      csum[c] = dmx_stat_sum(q[0]);
+      csum[p.C + c] = dmx_stat_sumsq(q[1], q[2]);
     }
     __syncthreads();
     const int cpg = p.C / G;
     if (t < G) {
-      float a = 0.f, q = 0.f;
+      double a = 0.0, q = 0.0;
       for (int k = 0; k < cpg; ++k) { a += csum[t * cpg + k]; q += csum[p.C + t * cpg + k]; }
-      const float inv_n = 1.0f / ((float)p.HW * (float)cpg);
-      const float mean = a * inv_n;
-      float var = q * inv_n - mean * mean;
-      var = var < 0.f ? 0.f : var;
-      MEAN[t] = mean; RSTD[t] = rsqrtf(var + p.eps);
-      if (p.stats_out && blockIdx.x == 0) { p.stats_out[((size_t)b * G + t) * 2] = mean; p.stats_out[((size_t)b * G + t) * 2 + 1] = RSTD[t]; }
+      const double inv_n = 1.0 / ((double)p.HW * (double)cpg);
+      const double mean = a * inv_n;
+      double var = q * inv_n - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      MEAN[t] = (float)mean; RSTD[t] = (float)(1.0 / __builtin_sqrt(var + (double)p.eps));
+      if (p.stats_out && blockIdx.x == 0) { p.stats_out[((size_t)b * G + t) * 2] = MEAN[t]; p.stats_out[((size_t)b * G + t) * 2 + 1] = RSTD[t]; }
     }
     __syncthreads();
   } else {
@@ -375,7 +377,7 @@ int dmx_groupnorm_sums_launch(GroupNormArgs a, hipStream_t stream) {
   int rpb = 8 * R;                                                  // up to 8 rows per thread
   while (rpb > R && (long)cdiv(a.HW, rpb) * a.B < 512) rpb -= R;
   a.partial = nullptr; a.nchunk = 0;
-  hipLaunchKernelGGL(dmx_gn_apply_kernel, dim3(cdiv(a.HW, rpb), a.B), dim3(threads), (size_t)2 * a.C * sizeof(float), stream, a, rpb);
+  hipLaunchKernelGGL(dmx_gn_apply_kernel, dim3(cdiv(a.HW, rpb), a.B), dim3(threads), (size_t)2 * a.C * sizeof(double), stream, a, rpb);
   return dmx_check_launch("dmx_gn_apply_kernel");
 }
 

@@ -11,7 +11,7 @@ import torch
 import contextlib
 
 from . import _cabi
-from ._cabi import GemmDesc, check, current_stream, ptr
+from ._cabi import GemmDesc, HaloConvDesc, check, current_stream, ptr
 
 _ELEM = "bf16"
 
@@ -193,7 +193,7 @@ def conv_gemm(x0, w, N, *, x1=None, ksize=3, stride=1, pad=1, ups=False, bias=No
     if gn_stats:
         d.cs_rows = OH * OW
         if lib().dmx_conv_gemm_colstats_ok(ctypes.byref(d)):
-            cst = torch.zeros(B, N, 2, dtype=torch.int64, device=x0.device)
+            cst = torch.zeros(B, N, 4, dtype=torch.int64, device=x0.device)
             d.colstats = cst.data_ptr()
         else:
             d.cs_rows = 0
@@ -294,6 +294,65 @@ def groupnorm(x0, gamma, beta, groups, eps, silu, x1=None):
     check(lib().dmx_groupnorm(ptr(x0), _ld(x0), ptr(x1), _ld(x1) if x1 is not None else 0, C0, C, groups, B, H * W,
                               ptr(gamma), ptr(beta), float(eps), int(silu), ptr(y), C, ptr(ws), wsb, current_stream()), "groupnorm")
     return y
+
+
+def stat_sums(st):
+    """statistics records [B][C][4] int64 -> (sum, sum of squares) as float64 tensors [B][C]"""
+    s = st.cpu().double()
+    return s[..., 0] / 2 ** 20, s[..., 1] / 2 ** 8 + s[..., 2] / 2 ** 40
+
+
+def colstats(x):
+    """statistics records [B][C][4] of an NHWC tensor (dmx_colstats: for tensors whose producer emitted none)"""
+    B, H, W, C = x.shape
+    st = torch.zeros(B, C, 4, dtype=torch.int64, device=x.device)
+    check(lib().dmx_colstats(ptr(x), _ld(x), B, H * W, C, ptr(st), current_stream()), "colstats")
+    return st
+
+
+def conv3x3_gn(x0, w, N, *, x1=None, gn=None, st0=None, st1=None, sc0=None, sc1=None, bias=None, rowbias=None, res=None,
+               out_stats=False, force_split=0, timing=None, dbg=0):
+    """conv3x3 (stride 1, pad 1) over a halo tile staged in LDS, with GroupNorm(+SiLU) applied to the staged tile in place
+    (dmx_conv3x3_gn).  gn = (gamma, beta, groups, eps, silu) with st0 / st1 the statistics records of x0 / x1, or None for a plain
+    conv.  Returns out, or (out, records of out) with out_stats."""
+    B, H, W, C0 = x0.shape
+    d = HaloConvDesc()
+    d.x0 = x0.data_ptr(); d.ldx0 = _ld(x0); d.cx0 = C0; d.Cin = C0
+    if x1 is not None:
+        d.x1 = x1.data_ptr(); d.ldx1 = _ld(x1); d.Cin = C0 + x1.shape[-1]
+    d.B, d.H, d.W = B, H, W
+    if gn is not None:
+        gamma, beta, groups, eps, silu = gn
+        d.gn = 1; d.silu = int(silu); d.groups = groups; d.eps = float(eps); d.gamma = gamma.data_ptr(); d.beta = beta.data_ptr()
+        d.st0 = st0.data_ptr()
+        if st1 is not None:
+            d.st1 = st1.data_ptr()
+    if sc0 is not None:
+        d.s0 = sc0.data_ptr(); d.lds0 = _ld(sc0); d.cs0 = sc0.shape[-1]; d.Csc = sc0.shape[-1]
+        if sc1 is not None:
+            d.s1 = sc1.data_ptr(); d.lds1 = _ld(sc1); d.Csc += sc1.shape[-1]
+    d.w = w.data_ptr(); d.ldw = w.stride(0); d.N = N
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    if rowbias is not None:
+        d.rowbias = rowbias.data_ptr(); d.ldrb = rowbias.stride(0)
+    if res is not None:
+        d.res = res.data_ptr(); d.ldres = _ld(res)
+    out = torch.empty(B, H, W, N, dtype=h16(), device=x0.device)
+    d.out = out.data_ptr(); d.ldo = N
+    cst = None
+    if out_stats:
+        cst = torch.zeros(B, N, 4, dtype=torch.int64, device=x0.device)
+        d.colstats = cst.data_ptr()
+    d.force_split = force_split; d.dbg = dbg
+    if timing is not None:
+        d.timing = timing.data_ptr()
+    if not lib().dmx_conv3x3_gn_supported(ctypes.byref(d)):
+        raise RuntimeError("conv3x3_gn: the halo kernel does not take this problem")
+    wsb = lib().dmx_conv3x3_gn_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x0.device)
+    check(lib().dmx_conv3x3_gn(ctypes.byref(d), ptr(ws), wsb, current_stream()), "conv3x3_gn")
+    return (out, cst) if out_stats else out
 
 
 def groupnorm_from_stats(x0, st0, gamma, beta, groups, eps, silu, x1=None, st1=None):

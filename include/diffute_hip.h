@@ -90,8 +90,9 @@ typedef struct dmx_gemm_desc {
   const float* ln_c1; const float* ln_c2; int ln_C; float ln_eps;   /* ln_C = normalised feature count (= K)           */
   /* GroupNorm statistics from the producer (ResnetBlock2D norm1 / norm2, Transformer2DModel.norm and conv_norm_out behind
    * unet(...), app.ipynb:814, and the same norms of AutoencoderKL): the conv / linear that WRITES a tensor also adds, per
-   * (sample, channel), the fixed-point sum * 2^20 and sum of squares * 2^32 of its rounded outputs into
-   * colstats[(sample*N + n)*2 + {0, 1}] (int64, zero before the call; cs_rows = rows per sample, a multiple of the plan's tile
+   * (sample, channel), a statistics record of its rounded outputs - four int64 words {sum * 2^20, floor(sumsq * 2^8),
+   * (sumsq - that) * 2^40, 0}, exact integer accumulation, no wrap below sumsq = 3.6e16 - into
+   * colstats[(sample*N + n)*4 ..] (zero before the call; cs_rows = rows per sample, a multiple of the plan's tile
    * rows - dmx_conv_gemm_colstats_ok(d) says whether the plan this problem gets can do it).  The GroupNorm that READS the
    * tensor is then dmx_groupnorm_from_stats: one apply-only pass, no statistics pass over the tensor. */
   long long* colstats; int cs_rows;
@@ -139,10 +140,44 @@ int dmx_groupnorm(const void* x0, int ldx0, const void* x1, int ldx1, int c0, in
                   int B, int HW, const float* gamma, const float* beta, float eps, int silu,
                   void* y, int ldy, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 /* GroupNorm (+SiLU) with the statistics taken from the producers of x0 / x1: st0 = colstats of the GEMM that wrote x0
- * ([B][c0][2] int64), st1 likewise for x1 ([B][C - c0][2]) or NULL without a second source.  One launch. */
+ * ([B][c0][4] int64 records), st1 likewise for x1 ([B][C - c0][4]) or NULL without a second source.  One launch. */
 int dmx_groupnorm_from_stats(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,
                              int B, int HW, const float* gamma, const float* beta, float eps, int silu,
                              const long long* st0, const long long* st1, void* y, int ldy, dmx_stream_t stream);
+
+/* K1 + K3 as ONE launch (north_star: "NHWC conv2d with LDS-staged input tiles ... GroupNorm/SiLU fused per-channel in LDS"):
+ * conv3x3 (stride 1, pad 1) over a halo tile that is staged ONCE per 64-channel chunk in LDS - the nine taps are shifted LDS
+ * fragment reads - with the GroupNorm(32 groups)[+SiLU] in front of it applied to the staged tile in place, from the statistics
+ * records of the tensor's producer(s).  Replaces `conv1(nonlinearity(norm1(x)))` / `conv2(nonlinearity(norm2(h)))` (+ conv_shortcut,
+ * + the time-embedding add, + the residual add) of every diffusers ResnetBlock2D behind unet(...) /root/reference/app.ipynb:814,
+ * train_diffute_v1.py:913 and vae.encode / vae.decode app.ipynb:793,819.
+ *   x0 | x1: NHWC input (virtual channel concat; x1 NULL without one), cx0 / Cin multiples of 64; H x W a multiple of 8 x 32 or 16 x 16
+ *   gn = 1: y = GroupNorm(x)[SiLU] feeds the conv (padding pixels are zeros of y); st0 / st1 = records [B][channels][4] of x0 / x1
+ *   s0 | s1: optional 1x1 shortcut K segment on RAW tensors of the output grid (Csc channels, multiples of 64; 0 = none)
+ *   w: [N][ldw] with k = tap*Cin + c, then the shortcut channels (dmx_pack_conv_weight); N a multiple of 160 or of 128
+ *   out = conv + bias[n] + rowbias[b*ldrb + n] + res, NHWC; colstats: records of the OUTPUT [B][N][4], added to, or NULL
+ * dmx_conv3x3_gn_supported: 1 when the kernel takes the problem (otherwise use dmx_groupnorm + dmx_conv_gemm).
+ * dmx_colstats: the statistics records of a tensor whose producer emitted none (one streaming pass; st zero before the call). */
+typedef struct dmx_halo_conv_desc {
+  const void* x0; const void* x1; int ldx0, ldx1, cx0, Cin;
+  int B, H, W;
+  int gn, silu, groups; float eps;
+  const long long* st0; const long long* st1;
+  const float* gamma; const float* beta;
+  const void* s0; const void* s1; int lds0, lds1, cs0, Csc;
+  const void* w; int ldw; int N;
+  const float* bias; const float* rowbias; int ldrb;
+  const void* res; int ldres;
+  void* out; int ldo;
+  long long* colstats;
+  int force_split;                  /* 0 = automatic; 1 / 2 / 4 / 8 blocks share the K range of a tile (tests, tuning) */
+  int dbg; long long* timing;       /* measurement aids, 0 / NULL */
+} dmx_halo_conv_desc;
+int dmx_conv3x3_gn_supported(const dmx_halo_conv_desc* d);
+size_t dmx_conv3x3_gn_workspace_bytes(const dmx_halo_conv_desc* d);
+int dmx_conv3x3_gn(const dmx_halo_conv_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+int dmx_colstats(const void* x, int ldx, int B, int HW, int C, long long* st, dmx_stream_t stream);
+int dmx_set_halo_conv(int on);      /* tuning aid: 0 makes the model executors use GroupNorm + dmx_conv_gemm everywhere; returns the old setting */
 
 /* The row-local chains of diffusers' BasicTransformerBlock + Transformer2DModel.proj_out (the unet(...) call at
  * /root/reference/app.ipynb:814) at the C = 320 levels, ONE launch each (xf_chain.hip); rows M % 64 == 0:

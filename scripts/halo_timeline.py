@@ -1,0 +1,38 @@
+"""Per-block phase timeline of the halo conv (HaloConvArgs.timing): prologue / K loop / publish / wait / epilogue, in us.
+    python scripts/halo_timeline.py [B H W C0 C1 N Csc] [--split S] [--dbg D]"""
+import argparse, math, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffute_amd import ops
+ap = argparse.ArgumentParser(); ap.add_argument("shape", nargs="*", type=int, default=[4, 64, 64, 320, 0, 320, 0])
+ap.add_argument("--split", type=int, default=0); ap.add_argument("--dbg", type=int, default=0); ap.add_argument("--nogn", action="store_true")
+a = ap.parse_args()
+B, H, W, C0, C1, N, Csc = a.shape
+dev = torch.device("cuda:0")
+Cin = C0 + C1; K = 9 * Cin + Csc
+x0 = torch.randn(B, H, W, C0, device=dev).to(torch.bfloat16)
+x1 = torch.randn(B, H, W, C1, device=dev).to(torch.bfloat16) if C1 else None
+sc = torch.randn(B, H, W, Csc, device=dev).to(torch.bfloat16) if Csc else None
+w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+b = torch.randn(N, device=dev); te = torch.randn(B, N, device=dev)
+r = None if Csc else torch.randn(B, H, W, N, device=dev).to(torch.bfloat16)
+g = torch.ones(Cin, device=dev); be = torch.zeros(Cin, device=dev)
+st0 = ops.colstats(x0); st1 = ops.colstats(x1) if C1 else None
+tm = torch.zeros(4096, 8, dtype=torch.int64, device=dev)
+kw = dict(x1=x1, sc0=sc, bias=b, rowbias=te, res=r, out_stats=True, force_split=a.split, dbg=a.dbg)
+if not a.nogn: kw.update(gn=(g, be, 32, 1e-5, True), st0=st0, st1=st1)
+for i in range(3): ops.conv3x3_gn(x0, w, N, **kw)
+ops.conv3x3_gn(x0, w, N, timing=tm, **kw)
+torch.cuda.synchronize()
+t = tm.cpu()
+t = t[t[:, 0] > 0]
+t0 = t[:, 0].min()
+us = (t[:, :6] - t0).double() / 100.0
+print(f"{len(t)} blocks; steps per block {sorted(set(t[:, 7].tolist()))}")
+names = ["start", "prologue done", "K loop done", "published", "peers arrived", "end"]
+for i, n in enumerate(names):
+    print(f"  {n:15s}: mean {us[:, i].mean():7.2f}  min {us[:, i].min():7.2f}  max {us[:, i].max():7.2f} us")
+d = us[:, 1:] - us[:, :-1]
+print("  phase durations (mean): prologue %.2f  K loop %.2f  publish %.2f  wait+stage %.2f  epilogue %.2f" % tuple(d.mean(0).tolist()))
+steps = t[:, 7].double()
+print("  K loop per step: mean %.3f us (min %.3f, max %.3f)" % (float((d[:, 1] / steps).mean()), float((d[:, 1] / steps).min()), float((d[:, 1] / steps).max())))

@@ -245,7 +245,7 @@ def test_groupnorm_statistics_from_the_producer(cuda, case):
     assert_close(nchw(y), conv_ref, TOL, f"{name}: conv")
     yf = nchw(y).double()
     s_ref = yf.sum((2, 3)); q_ref = (yf * yf).sum((2, 3))                                  # [B][Co] of the ROUNDED output
-    s_hip = st[..., 0].cpu().double() / 2 ** 20; q_hip = st[..., 1].cpu().double() / 2 ** 32
+    s_hip, q_hip = ops.stat_sums(st)
     assert float(((s_hip - s_ref).abs() / (1e-5 * yf.abs().sum((2, 3)) + 1e-4)).max()) <= 1.0, f"{name}: channel sums"
     assert float(((q_hip - q_ref).abs() / q_ref).max()) <= 1e-5, f"{name}: channel sums of squares"
     y2, st2 = ops.conv_gemm(nhwc(x, cuda), ops.pack_conv_weight(w.to(cuda)), Co, gn_stats=True, **kw)
@@ -595,3 +595,113 @@ def test_xf_chain_two_rounds_and_fp16_build(cuda):
 
     run("bf16", 64 * 300, (TOL, 2e-3, 3e-3))
     run("fp16", 64 * 5, (TOL, TOL, TOL))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# conv_halo.hip: conv3x3 over a halo tile staged in LDS + GroupNorm(+SiLU) applied to the staged tile (K1 + K3 as one launch)
+def _halo_ref(x, w, b, *, gn=None, sc=None, wsc=None, temb=None, res=None):
+    """fp32 torch reference on the bf16-rounded inputs; the normalised tensor is rounded once where the kernel materialises its element"""
+    h = x
+    if gn is not None:
+        g, be, eps, silu = gn
+        h = F.group_norm(x, 32, g, be, eps)
+        if silu:
+            h = F.silu(h)
+        h = bf(h)
+    y = F.conv2d(h, w, b, padding=1)
+    if sc is not None:
+        y = y + F.conv2d(sc, wsc)
+    if temb is not None:
+        y = y + temb[:, :, None, None]
+    if res is not None:
+        y = y + res
+    return bf(y)
+
+
+HALO_CASES = [
+    # name, B, H, W, C0, C1, N, Csc0, Csc1, gn, split
+    ("plain_64x64_320", 2, 64, 64, 320, 0, 320, 0, 0, False, 0),
+    ("gn_64x64_320", 2, 64, 64, 320, 0, 320, 0, 0, True, 0),
+    ("gn_32x32_concat_sc", 2, 32, 32, 640, 320, 640, 640, 320, True, 0),
+    ("gn_16x16_1280", 2, 16, 16, 640, 0, 1280, 0, 0, True, 0),
+    ("gn_16x16_concat_sc_split8", 1, 16, 16, 640, 640, 640, 640, 640, True, 8),
+    ("gn_n128_vae", 1, 64, 64, 128, 0, 128, 0, 0, True, 0),
+    ("gn_n256_sc_vae", 1, 32, 32, 128, 0, 256, 128, 0, True, 0),
+    ("gn_split1_two_passes", 1, 32, 32, 320, 0, 320, 0, 0, True, 1),
+    ("gn_split2", 1, 32, 32, 320, 0, 320, 320, 0, True, 2),
+    ("gn_split4_tap_rows", 1, 32, 32, 320, 0, 160, 0, 0, True, 4),
+    ("gn_8x32_strip", 1, 8, 32, 64, 0, 160, 0, 0, True, 1),
+    ("plain_sc_only_split", 1, 16, 32, 64, 64, 160, 64, 64, False, 2),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
+def test_conv3x3_gn_halo(cuda, case):
+    """conv_halo.hip against F.conv2d(F.silu(F.group_norm(x))) + shortcut + time embedding + residual: every tile geometry (8 x 32,
+    16 x 16), both column widths (160 / 128), two-source concat with groups that straddle the sources, the fused 1x1 shortcut, every
+    K split (1 = two epilogue passes, 2 / 4 / 8 = reduce-scatter between co-resident blocks, slices cut inside a chunk), the output
+    statistics records, and twice for bit-reproducibility.  The input statistics come from dmx_colstats (what a producer would emit)."""
+    from diffute_amd import ops
+    name, B, H, W, C0, C1, N, S0, S1, gn, split = case
+    x0 = bf(seeded((B, C0, H, W), 1) * 1.5 + 0.3)
+    x1 = bf(seeded((B, C1, H, W), 2) * 0.5 - 1.0) if C1 else None
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    Cin = C0 + C1
+    w = bf(seeded((N, Cin, 3, 3), 3, 1 / math.sqrt(9 * Cin))); b = seeded((N,), 4, 0.1)
+    temb = seeded((B, N), 5); r = bf(seeded((B, N, H, W), 6))
+    s0 = bf(seeded((B, S0, H, W), 7)) if S0 else None
+    s1 = bf(seeded((B, S1, H, W), 8)) if S1 else None
+    sc = None if s0 is None else (s0 if s1 is None else torch.cat([s0, s1], 1))
+    wsc = bf(seeded((N, S0 + S1, 1, 1), 9, 1 / math.sqrt(S0 + S1))) if S0 else None
+    g = 1 + 0.1 * seeded((Cin,), 10); be = 0.1 * seeded((Cin,), 11)
+    ref = _halo_ref(x, w, b, gn=(g, be, 1e-5, True) if gn else None, sc=sc, wsc=wsc, temb=temb, res=None if S0 else r)
+    X0 = nhwc(x0, cuda); X1 = None if x1 is None else nhwc(x1, cuda)
+    kw = dict(x1=X1, bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(), force_split=split, out_stats=True)
+    if gn:
+        kw.update(gn=(g.to(cuda), be.to(cuda), 32, 1e-5, True), st0=ops.colstats(X0), st1=None if X1 is None else ops.colstats(X1))
+    if S0:
+        kw.update(sc0=nhwc(s0, cuda), sc1=None if s1 is None else nhwc(s1, cuda))
+    else:
+        kw.update(res=nhwc(r, cuda))
+    W_ = ops.pack_conv_weight(w.to(cuda), shortcut_w=None if wsc is None else wsc.to(cuda))
+    out, st = ops.conv3x3_gn(X0, W_, N, **kw)
+    assert_close(nchw(out), ref, 2e-3 if gn else TOL, name)
+    yf = nchw(out).double()
+    s_hip, q_hip = ops.stat_sums(st)
+    s_ref = yf.sum((2, 3)); q_ref = (yf * yf).sum((2, 3))
+    assert float(((s_hip - s_ref).abs() / (1e-5 * yf.abs().sum((2, 3)) + 1e-4)).max()) <= 1.0, f"{name}: channel sums of the output"
+    assert float(((q_hip - q_ref).abs() / q_ref).max()) <= 1e-5, f"{name}: channel sums of squares of the output"
+    out2, st2 = ops.conv3x3_gn(X0, W_, N, **kw)
+    assert torch.equal(out, out2) and torch.equal(st, st2), f"{name}: not bit-reproducible"
+    if gn:
+        # against the unfused HIP path: GroupNorm kernel, then the implicit-GEMM conv
+        t = ops.groupnorm(X0, g.to(cuda), be.to(cuda), 32, 1e-5, True, x1=X1)
+        old = ops.conv_gemm(t, W_, N, bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(), res=None if S0 else nhwc(r, cuda),
+                            sc0=kw.get("sc0"), sc1=kw.get("sc1"))
+        assert_close(nchw(out), nchw(old).float(), 2e-3, f"{name}: vs GroupNorm + implicit-GEMM conv")
+
+
+def test_statistics_records_large_magnitudes(cuda):
+    """the round-3 records (sumsq * 2^32 in one int64) wrapped at a channel RMS of ~90 at 512 x 512.  Activations
+    around 1e3 over 256 x 256 pixels with a DC offset of 50 standard deviations: the records and the GroupNorm from them must match
+    the GroupNorm kernel that reads the tensor (two-pass statistics)."""
+    from diffute_amd import ops
+    B, H, W, C = 1, 256, 256, 64
+    x = bf(seeded((B, C, H, W), 1) * 20.0 + 1000.0)
+    X = nhwc(x, cuda)
+    st = ops.colstats(X)
+    s_hip, q_hip = ops.stat_sums(st)
+    xd = nchw(X).double()
+    assert float(((s_hip - xd.sum((2, 3))).abs() / xd.abs().sum((2, 3))).max()) <= 1e-6
+    assert float(((q_hip - (xd * xd).sum((2, 3))).abs() / (xd * xd).sum((2, 3))).max()) <= 1e-6
+    g = 1 + 0.1 * seeded((C,), 2); be = 0.1 * seeded((C,), 3)
+    out = ops.groupnorm_from_stats(X, st, g.to(cuda), be.to(cuda), 32, 1e-5, True)
+    ref = bf(F.silu(F.group_norm(nchw(X).float().double(), 32, g.double(), be.double(), 1e-5)).float())
+    # (mean / std = 50: the float tile sums behind the records carry ~1e-7 relative error each, the variance ~2.5e-4 of that)
+    assert_close(nchw(out), ref, 5e-3, "GroupNorm from records at |x| ~ 1e3")
+    # the same through a producer: identity 1x1 conv emitting records
+    w = torch.zeros(C, C, 1, 1); w[torch.arange(C), torch.arange(C), 0, 0] = 1.0
+    y, st2 = ops.conv_gemm(X, ops.pack_conv_weight(w.to(cuda)), C, ksize=1, pad=0, gn_stats=True)
+    if st2 is not None:
+        s2, q2 = ops.stat_sums(st2)
+        assert float(((q2 - (xd * xd).sum((2, 3))).abs() / (xd * xd).sum((2, 3))).max()) <= 1e-5
