@@ -39,15 +39,22 @@ namespace {
 constexpr int HB_NT = 512;                 // threads
 constexpr int HB_PATCH = 44032;            // patch buffer: 2752 pieces of 16 B (340 rows of 128 B, rounded up to whole 1-KB DMA instructions)
 
-template <int NF> struct HaloLds {
-  static constexpr int BN = 32 * NF;
+// WMW = waves along the pixel axis: 4 -> 4 x 2 waves of 64-pixel x 16 NF-channel tiles (BN = 32 NF = 160 / 128 columns),
+//                                   8 -> 8 x 1 waves of 32-pixel x 16 NF-channel tiles (BN = 16 NF = 80 / 64 columns: twice the tiles - levels
+//                                        where the wider tile would need a K split, i.e. an exchange of fp32 slabs through memory)
+template <int NF, int WMW> struct HaloLds {
+  static constexpr int BN = (8 / WMW) * 16 * NF;
+  static constexpr int MFR = 16 / WMW;                // 16-pixel fragments per wave
   static constexpr int WSTAGE = BN * 128;
-  static constexpr int PATCH0 = 3 * WSTAGE, PATCH1 = PATCH0 + HB_PATCH;
+  // weight ring: 3 stages = prefetch distance 1 under the two-group ping-pong (stage (s - 1) % 3 is the partner's, s % 3 this wave's next).
+  // A 4-stage ring / distance 2 with a counted vmcnt was built for the tiles that have the LDS for it and measured SLOWER (64x64x320,
+  // 80 columns: 72 vs 62 us): what bounds a step is each wave's serial non-MFMA work, not the landing time of the tile (EXPERIMENTS.md)
+  static constexpr int NSTG = 3;
+  static constexpr int PATCH0 = NSTG * WSTAGE, PATCH1 = PATCH0 + HB_PATCH;
   static constexpr int GB = PATCH1 + HB_PATCH;        // gamma | beta of a chunk, two 1-KB slots (lanes 32..63 of the DMA land in the second half)
   static constexpr int COEF = GB + 2048;              // (a, s) of the 64 channels of a chunk, 512 B
   static constexpr int GST = COEF + 512;              // (mean, rstd) of the 32 groups, 256 B (+ 256 spare)
-  static constexpr int JUNK = GST + 512;              // destination of the dummy DMA instructions that keep the vmcnt arithmetic static, 1 KB
-  static constexpr int TOTAL = JUNK + 1024;
+  static constexpr int TOTAL = GST + 512;
   // epilogue: fp32 staging of 128 rows + the statistics fold
   static constexpr int LDT = BN + 4;
   static constexpr int EPI_FOLD = 128 * LDT * 4;
@@ -56,22 +63,43 @@ template <int NF> struct HaloLds {
   static_assert(EPI_TOTAL <= TOTAL && TOTAL <= 163840, "LDS budget");
 };
 
-template <int NF>
+// lgkmcnt of the wait in front of MFMA group g of the hand-scheduled tap (see mma_post): reads issued so far minus the position of
+// the last read the group needs.  Issue order: X0[0 .. MFR), W[0], W[1], then in front of group g: X1[g] (g < MFR), W[g + 2].
+constexpr int hb_wait(int NF, int MFR, int g) {
+  int pos = MFR + 2, posW[16] = {}, posX1[4] = {};
+  posW[0] = MFR; posW[1] = MFR + 1;
+  int issued_at_wait = 0;
+  for (int q = 0; q < 2 * NF; ++q) {
+    if (q == g) issued_at_wait = pos;
+    if (q < MFR) posX1[q] = pos++;
+    if (q + 2 < 2 * NF) posW[q + 2] = pos++;
+  }
+  int need = posW[g];
+  if (g == 0 && MFR - 1 > need) need = MFR - 1;
+  if (g == NF && posX1[MFR - 1] > need) need = posX1[MFR - 1];
+  return issued_at_wait - 1 - need;
+}
+
+template <int NF, int WMW>
 __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvArgs p) {
-  typedef HaloLds<NF> L;
-  constexpr int BN = L::BN, WSTAGE = L::WSTAGE;
+  typedef HaloLds<NF, WMW> L;
+  constexpr int BN = L::BN, WSTAGE = L::WSTAGE, MFR = L::MFR, NSTG = L::NSTG, PD = L::NSTG - 2;   // PD = prefetch distance of the weight tiles (taps)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % WMW, wn = wave / WMW;
   const int lr = lane & 15, lq = lane >> 4;
   // measurement aids, probe builds only (-DDMX_PROBES; they cost registers in the K loop): HaloConvArgs.dbg ablation switches (results
   // invalid: 1 no MFMA phase, 2 no weight DMA, 4 no normalisation, 8 no patch DMA, 16 no barriers) and .timing phase timestamps
-#ifdef DMX_PROBES
-  const int DBG = p.dbg; long long* const TIMING = p.timing;
-#else
-  constexpr int DBG = 0; constexpr long long* TIMING = nullptr;
+#ifndef DMX_HALO_DBG
+#define DMX_HALO_DBG 0                                 // (compile-time ablation builds: scripts/halo_ablate_build.sh)
 #endif
-  long long tm[6] = {0, 0, 0, 0, 0, 0};                // 100 MHz ticks at the phase boundaries
+  constexpr int DBG = DMX_HALO_DBG;
+#ifdef DMX_PROBES
+  long long* const TIMING = p.timing;
+#else
+  constexpr long long* TIMING = nullptr;
+#endif
+  long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // 100 MHz ticks at the phase boundaries
   if (TIMING) tm[0] = __builtin_amdgcn_s_memrealtime();
 
   // ---- work item: (n-tile, K slice) combos are dealt XCD-contiguously, pixel tiles inside a combo: the blocks resident on one XCD
@@ -81,7 +109,9 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
   const int tiles_m = p.B * tiles_img, S = p.splits;
   const int nb = gridDim.x;
   const int Lb = ((nb & 7) == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const int combo = Lb / tiles_m, tile_m = Lb - combo * tiles_m;
+  const int ncombo = (p.N / BN) * S;
+  // (xcd_tile_major: pixel tiles XCD-contiguous, their column tiles / K slices inside - the blocks of an XCD share the ACTIVATION tiles)
+  const int combo = p.xcd_tile_major ? Lb % ncombo : Lb / tiles_m, tile_m = p.xcd_tile_major ? Lb / ncombo : Lb - combo * tiles_m;
   const int tile_n = combo / S, r = combo - tile_n * S;
   const int b = tile_m / tiles_img, ti = tile_m - b * tiles_img;
   const int ty0 = (ti / tiles_x) * TH, tx0 = (ti % tiles_x) * TW;
@@ -89,8 +119,8 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
   const int twsh = (TW == 32) ? 5 : 4;                 // TW is 16 or 32
   const int nprow = (TH + 2) * PW, npiece = nprow * 8;
 
-  // ---- K steps: main chunk c = steps [9c, 9c + 9) (tap = step % 9), then one step per 64 shortcut channels.  Slice r = steps [sb, se),
-  // boundaries inside the main part on whole tap rows.
+  // ---- K steps: main chunk c = steps [9c, 9c + 9) (tap = step % 9), then one step per 64 shortcut channels.  Slice r = steps [sb, se):
+  // a chunk cut by a boundary runs its nine pipeline steps in both blocks, each with the MFMA phases of its own taps only.
   const int nc = p.Cin >> 6, nsc = p.Csc >> 6, T = 9 * nc + nsc;
   auto bnd = [&](int q) { int v = (int)((long long)T * q / S); if (v < 9 * nc) v = (v + 1) / 3 * 3; return v; };
   const int sb = bnd(r), se = bnd(r + 1);
@@ -109,7 +139,7 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
   }
   const int pslot = ((t & 7) ^ ((t >> 3) & 7)) * 8;    // source channel octet of every piece of this thread ((q >> 3) & 7 = (t >> 3) & 7)
   // weight pieces: instruction j = wave + 8 i covers tile rows 8 j .. 8 j + 7
-  constexpr int WI = (BN * 8 + HB_NT - 1) / HB_NT;     // DMA instructions per thread and weight tile (3 for 160 columns, the last round half dummy)
+  constexpr int WI = (BN * 8 + HB_NT - 1) / HB_NT;     // rounds of DMA instructions per weight tile (BN / 8 instructions over 8 waves)
   // (byte offset of this thread's piece of instruction 0 inside the [BN][ldw] weight slab; instruction i is 64 rows further)
   const char* const wslab = (const char*)(p.w + (size_t)n0 * p.ldw);
   const unsigned woff0 = (unsigned)(((t >> 3) * p.ldw + (((t & 7) ^ ((t >> 3) & 7)) * 8)) * 2);
@@ -119,15 +149,25 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
   auto dma = [&](const char* src, int lds_off) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + lds_off), 16, 0, 0);
   };
-  // weight tile at K offset `koff` (elements; < 0: a dummy that keeps the vmcnt arithmetic static) -> ring stage `st`
-  auto issue_w = [&](long koff, int st) {
+  // weight tile at K offset `koff` (elements) -> ring stage `st`
+  auto issue_w = [&](long koff, int st) -> int {
+    int n = 0;
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      const bool ok = koff >= 0 && (wave + 8 * i) * 64 < BN * 8;       // wave-uniform
+      if ((wave + 8 * i) * 64 >= BN * 8) continue;     // wave-uniform (BN / 8 instructions over 8 waves: the last round is the low waves only)
       unsigned off = woff0 + wstep * i;
       asm volatile("" : "+v"(off));
-      dma(ok ? wslab + koff * 2 + off : zp, ok ? st * WSTAGE + (wave * 64 + HB_NT * i) * 16 : L::JUNK);
+      dma(wslab + koff * 2 + off, st * WSTAGE + (wave * 64 + HB_NT * i) * 16);
+      ++n;
     }
+    return n;
+  };
+  // wait until at most n of this wave's DMA instructions are outstanding (n is wave-uniform, 0 .. 3)
+  auto wait_vm = [&](int n) {
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   };
   // K offset of the weight tile of pipeline step g (-1 outside this block's slice)
   auto koff_of = [&](int g) -> long {
@@ -135,8 +175,8 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     if (g < 9 * nc) { const int c = g / 9, tap = g - 9 * c; return (long)tap * p.Cin + c * 64; }
     return (long)9 * p.Cin + (g - 9 * nc) * 64;
   };
-  // what a chunk's P instructions fetch: mode 1 = main chunk (gamma | beta + six pieces of the halo patch), 2 = shortcut chunk (four
-  // pieces: the 256 centre pixels, row = tile pixel index), 0 = nothing (dummies)
+  // what a chunk's patch instructions fetch: mode 1 = main chunk (gamma | beta + six pieces of the halo patch), 2 = shortcut chunk (four
+  // pieces: the 256 centre pixels, row = tile pixel index), 0 = nothing
   struct PDesc { const bf16* base; int ld; int mode; int ch; };
   auto pdesc = [&](int ch) -> PDesc {
     if (ch < 0) return PDesc{p.x0, 0, 0, 0};
@@ -148,77 +188,104 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     const int pp = (tt + HB_NT * i) >> 3; return (b * p.H + ty0 + (pp >> twsh)) * p.W + tx0 + (pp & (TW - 1));
   };
   auto issue_coef = [&](const PDesc& d) {
-    const bool on = d.mode == 1 && p.gn;
+    if (d.mode != 1 || !p.gn) return;
     const float* g = ((lane & 16) ? p.beta : p.gamma) + d.ch * 64 + (lane & 15) * 4;
-    dma(on ? (const char*)g : zp, on ? L::GB + (d.ch & 1) * 1024 : L::JUNK);
+    dma((const char*)g, L::GB + (d.ch & 1) * 1024);
   };
   auto issue_piece = [&](const PDesc& d, int pb, const int i) {
-    int pix = d.mode == 1 ? ppix[i] : ((d.mode == 2 && i < 4) ? spix(i) : -1);
+    if (d.mode == 0 || (d.mode == 2 && i >= 4)) return;
+    if (d.mode == 1 && (wave * 64 + HB_NT * i) >= npiece) return;          // wave-uniform: this instruction lies beyond the patch
+    int pix = d.mode == 1 ? ppix[i] : spix(i);
     asm volatile("" : "+v"(pix));                      // keep the address arithmetic here: hoisted out of the chunk loop it is 40 registers of pointers
     const char* src = pix >= 0 ? (const char*)(d.base + (size_t)pix * d.ld + pslot) : zp;
-    const bool live = d.mode == 1 ? (wave * 64 + HB_NT * i) < npiece : (d.mode == 2 && i < 4);      // wave-uniform
-    dma(src, live ? pb + (wave * 64 + HB_NT * i) * 16 : L::JUNK);
+    dma(src, pb + (wave * 64 + HB_NT * i) * 16);
   };
 
   // ---- fragment addresses: m-fragment i of this wave = tile pixels wm*64 + 16 i + lr, one tile row (TW = 16) or half a row (TW = 32);
   // n-fragment j = weight-tile rows wn*16NF + 16 j + lr.  Rows 16 apart share row & 7, so the swizzle term is the same for every fragment:
   // one base register each, the fragment index is an immediate / uniform offset.
-  const int pp0 = wm * 64 + lr;
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;                    // LDS byte address of smem[0]
+  const int pp0 = wm * (16 * MFR) + lr;
   const int xrow0 = (pp0 >> twsh) * PW + (pp0 & (TW - 1));                 // main taps: patch row of fragment 0 at tap (0, 0)
-  const int xd1 = TW == 32 ? 16 : PW, xd2 = TW == 32 ? PW : 2 * PW, xd3 = TW == 32 ? PW + 16 : 3 * PW;   // ... of fragments 1..3 relative to it (uniform)
+  auto xdelta = [&](int i) { return ((16 * i) >> twsh) * PW + ((16 * i) & (TW - 1)); };                  // ... of fragment i relative to it (uniform)
   const int xsc0 = pp0 * 128 + ((lq ^ (pp0 & 7)) << 4);                    // shortcut step: row = tile pixel index; fragment i is 2048 bytes further
   const int wn0 = wn * (16 * NF) + lr;
-  const int wad0 = wn0 * 128 + ((lq ^ (wn0 & 7)) << 4);                    // fragment j is 2048 bytes further
-  f32x4 acc[NF][4];
+  const unsigned wad0 = lds0 + wn0 * 128 + ((lq ^ (wn0 & 7)) << 4);        // fragment j is 2048 bytes further; k-step 1 = this ^ 64
+  f32x4 acc[NF][MFR];
 #pragma unroll
   for (int j = 0; j < NF; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MFR; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // one tap: 2 k-steps of 32 channels.  The four pixel fragments of a k-step stay in registers, the weight fragments pass through two
-  // register sets one at a time (j-major MFMA order, 40 fragment registers); the reads for the next group of four MFMAs are pinned in
-  // front of the current group (sched_group_barrier), so LDS latency hides under the matrix pipe
-  auto mma = [&](const char* xb, const int* xa, const char* wbase) {
-    const char* wb = wbase + wad0;
-    const char* wb1 = wbase + (wad0 ^ 64);             // k-step 1: chunk index ^ 4 (an XOR on the swizzled offset, not + 64)
-    bf16x8 xf[2][4], wf[2];
+  // ---- MFMA phase of one tap: 2 k-steps of 32 channels = 2 NF groups of four MFMAs (j-major: one weight fragment x four pixel fragments).
+  // Hand-scheduled: the fragment reads are inline-asm ds_read_b128 with COUNTED lgkmcnt waits (hipcc waits lgkmcnt(0) in front of
+  // every other group of this loop, i.e. for the prefetches it has just issued).  Read order: X0[0..3] (issued before the barrier: the
+  // patch is stable), W[0], W[1], then in front of group g: X1[g] (g < 4) and W[g + 2]; weight fragments rotate through three
+  // register sets.  Group g needs W[g] (and X0 / X1 at g = 0 / NF): reads issued after it = [g - 1 < 4] + [g + 1 < 2 NF].
+#define HB_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+  u32x4 fx0[MFR], fx1[MFR], fw[3];
+  auto mma_pre = [&](const unsigned* xa) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xf[0][i] = *(const bf16x8*)(xb + xa[i]);
-    wf[0] = *(const bf16x8*)(wb);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int cur = (kk * NF + j) & 1;
-        int nrd = 0;
-        if (j + 1 < NF) { wf[cur ^ 1] = *(const bf16x8*)((kk ? wb1 : wb) + (j + 1) * 2048); ++nrd; }
-        else if (kk == 0) { wf[cur ^ 1] = *(const bf16x8*)(wb1); ++nrd; }
-        if (kk == 0 && j < 4) { xf[1][j] = *(const bf16x8*)(xb + (xa[j] ^ 64)); ++nrd; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = DMX_MFMA_16x16x32(wf[cur], xf[kk][i], acc[j][i]);
-        if (nrd == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        else if (nrd == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < MFR; ++i) HB_DSR(fx0[i], xa[i], 0);
   };
-  auto mma_main = [&](int pb, int tapoff, int st) {
+  auto mma_post = [&](const unsigned* xa, unsigned wbase, auto&& after_group) {
+    const unsigned wb = wbase + wad0, wb1 = wbase + (wad0 ^ 64);
+    HB_DSR(fw[0], wb, 0);
+    HB_DSR(fw[1], wb, 2048);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int g = 0; g < 2 * NF; ++g) {
+      const int kk = g / NF, j = g - kk * NF;
+      constexpr int dummy_ = 0; (void)dummy_;
+      // the wait is tied to the registers the group reads ("+v"): the MFMAs cannot be scheduled in front of it
+      if (g == 0) {
+        if constexpr (MFR == 4) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fx0[0]), "+v"(fx0[1]), "+v"(fx0[2]), "+v"(fx0[3]), "+v"(fw[0]) : "n"(hb_wait(NF, MFR, 0)) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fx0[0]), "+v"(fx0[1]), "+v"(fw[0]) : "n"(hb_wait(NF, MFR, 0)) : "memory");
+      } else if (g == NF) {
+        if constexpr (MFR == 4) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fx1[0]), "+v"(fx1[1]), "+v"(fx1[2]), "+v"(fx1[3]), "+v"(fw[NF % 3]) : "n"(hb_wait(NF, MFR, NF)) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fx1[0]), "+v"(fx1[1]), "+v"(fw[NF % 3]) : "n"(hb_wait(NF, MFR, NF)) : "memory");
+      } else {
+        switch (hb_wait(NF, MFR, g)) {             // (g is a constant after unrolling; the immediate has to be a literal)
+          case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw[g % 3]) :: "memory"); break;
+          case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fw[g % 3]) :: "memory"); break;
+          case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fw[g % 3]) :: "memory"); break;
+          default: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fw[g % 3]) :: "memory"); break;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g < MFR) { const unsigned x1 = xa[g] ^ 64; HB_DSR(fx1[g], x1, 0); }
+      if (g + 2 < 2 * NF) {
+        const int g2 = g + 2, k2 = g2 / NF, j2 = g2 - k2 * NF;
+        const unsigned wsel = k2 ? wb1 : wb;
+        switch (j2) {
+          case 0: HB_DSR(fw[g2 % 3], wsel, 0); break;
+          case 1: HB_DSR(fw[g2 % 3], wsel, 2048); break;
+          case 2: HB_DSR(fw[g2 % 3], wsel, 2 * 2048); break;
+          case 3: HB_DSR(fw[g2 % 3], wsel, 3 * 2048); break;
+          default: HB_DSR(fw[g2 % 3], wsel, 4 * 2048); break;
+        }
+      }
+      const bf16x8 wv = __builtin_bit_cast(bf16x8, fw[g % 3]);
+#pragma unroll
+      for (int i = 0; i < MFR; ++i) acc[j][i] = DMX_MFMA_16x16x32(wv, __builtin_bit_cast(bf16x8, kk ? fx1[i] : fx0[i]), acc[j][i]);
+      __builtin_amdgcn_sched_barrier(0);
+      after_group(std::integral_constant<int, 0>{}, g);    // (VALU work that rides in the shadow of the group's MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto xa_main = [&](int pb, int tapoff, unsigned* xa) {
     int pr = xrow0;
     asm volatile("" : "+v"(pr));                       // (the tap addresses are loop-invariant: hoisted they would live across the whole K loop)
     pr += tapoff;
-    const int rr4[4] = {pr, pr + xd1, pr + xd2, pr + xd3};
-    int xa[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xa[i] = rr4[i] * 128 + ((lq ^ (rr4[i] & 7)) << 4);
-    mma(smem + pb, xa, smem + st * WSTAGE);
+    for (int i = 0; i < MFR; ++i) { const int rr = pr + xdelta(i); xa[i] = lds0 + pb + rr * 128 + ((lq ^ (rr & 7)) << 4); }
   };
-  auto mma_sc = [&](int pb, int st) {
+  auto xa_sc = [&](int pb, unsigned* xa) {
     int x0 = xsc0;
     asm volatile("" : "+v"(x0));
-    const int xa[4] = {x0, x0 + 2048, x0 + 4096, x0 + 6144};
-    mma(smem + pb, xa, smem + st * WSTAGE);
+#pragma unroll
+    for (int i = 0; i < MFR; ++i) xa[i] = lds0 + pb + x0 + 2048 * i;
   };
 
   // ---- GroupNorm pieces
@@ -235,29 +302,54 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     float* cf = (float*)(smem + L::COEF);
     cf[2 * lane] = a; cf[2 * lane + 1] = gb[64 + lane] - gs[2 * g] * a;
   };
-  // normalise piece i of the patch in buffer `pb` in place
+  // normalise piece i of the patch in buffer `pb` in place (a thread normalises the pieces it requested itself: its own vmcnt wait
+  // is all the ordering this needs).  Three parts so that the K loop can put the arithmetic in the shadow of its MFMAs: nrm_load (LDS
+  // reads of the piece and of its 8 channels' (a, s), in the DMA phase), nrm_slice(e) (element e: fma, SiLU - after MFMA group e), nrm_store.
+  u32x4 nrm_x; f32x4 nrm_c[4]; float nrm_y[8]; int nrm_q = -1;
+  auto nrm_load = [&](int pb, const int i) {           // (call only with p.gn; every lane loads - lanes beyond the patch re-read piece 0 and store nothing)
+    const int q = t + HB_NT * i;
+    nrm_q = q >= npiece ? -1 : (ppix[i] < 0 ? -2 - q : q);                 // (padding pieces are written as zeros: the conv pads the NORMALISED tensor)
+    nrm_x = *(const u32x4*)(smem + pb + (q >= npiece ? 0 : q) * 16);
+    const float* cf = (const float*)(smem + L::COEF) + pslot * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nrm_c[k] = *(const f32x4*)(cf + 4 * k);
+  };
+  // (a use of the loaded registers right behind the loads, in the same branch: the compiler's wait for them lands HERE and not in front
+  // of every slice, where it would also wait for the fragment prefetches in flight)
+  auto nrm_ready = [&]() { asm volatile("" : "+v"(nrm_x), "+v"(nrm_c[0]), "+v"(nrm_c[1]), "+v"(nrm_c[2]), "+v"(nrm_c[3])); };
+  auto nrm_slice = [&](const int e) {
+    const float x = (e & 1) ? h2f_hi(nrm_x[e >> 1]) : h2f_lo(nrm_x[e >> 1]);
+    float y = __builtin_fmaf(x, nrm_c[e >> 1][(e & 1) * 2], nrm_c[e >> 1][(e & 1) * 2 + 1]);
+    if (p.silu) y *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * y));
+    nrm_y[e] = y;
+  };
+  auto nrm_store = [&](int pb) {
+    if (nrm_q == -1) return;
+    u32x4 o = pack_bf8(nrm_y);
+    int q = nrm_q;
+    if (q < 0) { o = u32x4{0u, 0u, 0u, 0u}; q = -2 - q; }
+    *(u32x4*)(smem + pb + q * 16) = o;
+  };
   auto norm_piece = [&](int pb, const int i) {
     if (!p.gn) return;
-    const int q = t + HB_NT * i;
-    if (q >= npiece) return;
-    u32x4* ptr = (u32x4*)(smem + pb + q * 16);
-    const float* cf = (const float*)(smem + L::COEF) + pslot * 2;
-    const f32x4 c0 = *(const f32x4*)cf, c1 = *(const f32x4*)(cf + 4), c2 = *(const f32x4*)(cf + 8), c3 = *(const f32x4*)(cf + 12);
-    float f[8]; unpack_bf8(*ptr, f);
-    const float av[8] = {c0[0], c0[2], c1[0], c1[2], c2[0], c2[2], c3[0], c3[2]};
-    const float sv[8] = {c0[1], c0[3], c1[1], c1[3], c2[1], c2[3], c3[1], c3[3]};
+    nrm_load(pb, i);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float y = __builtin_fmaf(f[e], av[e], sv[e]);
-      if (p.silu) y *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * y));
-      f[e] = y;
-    }
-    u32x4 o = pack_bf8(f);
-    if (ppix[i] < 0) o = u32x4{0u, 0u, 0u, 0u};        // the conv pads the NORMALISED tensor with zeros
-    *ptr = o;
+    for (int e = 0; e < 8; ++e) nrm_slice(e);
+    nrm_store(pb);
   };
 
-  // ---- prologue: group statistics of this block's sample (main chunks in range and gn), first patch, first two weight tiles
+  // ---- prologue: the first patch and weight tile are requested FIRST (their latency covers the statistics), then the group statistics
+  // of this block's sample
+  int cur = ch_first, seq = 0;
+  int gstep = cur < nc ? 9 * cur : 9 * nc + (cur - nc);   // pipeline step of the chunk's first step (inactive steps of a partial chunk included)
+  {
+    const PDesc d = pdesc(cur);
+    issue_coef(d);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_piece(d, L::PATCH0, i);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) { const long k0 = koff_of(gstep + d); if (k0 >= 0) issue_w(k0, (gstep + d) % NSTG); }
+  }
   if (p.gn && ch_first < nc) {
     // 16 threads per group sum the group's channels' records (integers: exact, any order), then mean / variance in double
     const int g = t >> 4, sub = t & 15;
@@ -279,84 +371,106 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
       double var = dmx_stat_sumsq(qh, ql) / n - mean * mean;
       var = var < 0.0 ? 0.0 : var;
       float* gs = (float*)(smem + L::GST);
-      gs[2 * g] = (float)mean; gs[2 * g + 1] = (float)(1.0 / __builtin_sqrt(var + (double)p.eps));
+      gs[2 * g] = (float)mean; gs[2 * g + 1] = rsqrtf((float)var + p.eps);
     }
   }
-  int cur = ch_first, seq = 0;
-  int gstep = cur < nc ? 9 * cur : 9 * nc + (cur - nc);   // pipeline step of the chunk's first step (inactive steps of a partial chunk included)
-  {
-    const PDesc d = pdesc(cur);
-    issue_coef(d);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) issue_piece(d, L::PATCH0, i);
-  }
-  issue_w(koff_of(gstep), gstep % 3);
-  issue_w(koff_of(gstep + 1), (gstep + 1) % 3);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WI) : "memory");     // the patch (and gamma | beta) landed; the weight tiles stay in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                        // (also publishes the group statistics)
+  __builtin_amdgcn_s_barrier();                        // the group statistics are published (the patch pieces a thread normalises are its own)
   if (cur < nc && p.gn) {
     coef_table(cur);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 6; ++i) norm_piece(L::PATCH0, i);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
   if (TIMING) tm[1] = __builtin_amdgcn_s_memrealtime();
-  // ---- K loop: the main chunks of the slice, then its shortcut steps (two loops: one loop with both bodies makes the compiler
-  // shuffle the 80 accumulators at the merge)
-  while (cur < nc) {
+  // ---- K loop, main chunks: TWO-GROUP PING-PONG.  Waves w and w + 4 share a SIMD; group A = waves 0..3, B = waves 4..7.  Per tap every
+  // wave runs a DMA phase (weights of the next tap; in steps 1 / 2 the next chunk's patch; one piece of normalisation; the first fragment
+  // reads), a barrier, an MFMA phase (40 MFMAs back to back), a barrier.  Both groups run the same instruction stream, B one barrier
+  // behind: on every SIMD one wave is in its MFMA phase while its partner issues LDS-DMA and does the normalisation VALU work (an
+  // LDS-DMA instruction stalls its wave 60-180 cycles; in lock step both waves of a SIMD pay that together and the matrix pipe idles).
+  //   A: dma(s) |X| mfma(s) |Y| dma(s+1) ...          B: |.| dma(s) |X'| mfma(s) |Y'| ...      X' = A's Y
+  // Weights of step s + 1 go to stage (s + 1) % 3 while the partner reads stage (s - 1) % 3 and this wave reads s % 3 next; a wave
+  // confirms its own requests (vmcnt(0)) at the END of its MFMA phase - a DMA + an MFMA phase after issuing them - so both groups'
+  // pieces of step s + 1 are confirmed by the barrier in front of mfma(s + 1).  The next chunk's patch is requested in steps 1 / 2 (in
+  // step 0 the partner still reads that buffer for step 8 of the previous chunk) and normalised in steps 3 .. 8 by the threads that
+  // requested it.
+  const bool grpB = wave >= 4;
+  const bool pingpong = cur >= 0 && cur < nc;
+#ifdef DMX_PROBES
+  long long pa_dma = 0, pa_wx = 0, pa_mma = 0, pa_wy = 0, pa_t = __builtin_amdgcn_s_memtime();   // shader cycles in: DMA phase, barrier X, MFMA phase, barrier Y
+#define HB_STAMP(acc_) { const long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - pa_t; pa_t = n_; }
+#else
+#define HB_STAMP(acc_)
+#endif
+  if (pingpong && grpB) __builtin_amdgcn_s_barrier();
+  while (cur >= 0 && cur < nc) {
     const int next = cur < ch_last ? cur + 1 : -1;
     const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0, pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
     const PDesc dn = pdesc(next);
-    // main chunk: nine statically scheduled steps.  Step s: [wait: weights of s landed] [barrier] [DMA: weights of s + 2; steps 0 / 1
-    // also the next chunk's patch] [MFMA tap s] [steps >= 3: normalise one piece of the next patch]
     auto step = [&](auto S_) {
       constexpr int s = decltype(S_)::value;
-      constexpr int nwait = s == 1 ? (4 + WI) : s == 2 ? (3 + WI) : WI;     // DMA instructions issued after the group this step needs
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nwait) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
-      if (!(DBG & 8)) {
-        if constexpr (s == 0) { issue_coef(dn); issue_piece(dn, pbn, 0); issue_piece(dn, pbn, 1); issue_piece(dn, pbn, 2); }
-        if constexpr (s == 1) { issue_piece(dn, pbn, 3); issue_piece(dn, pbn, 4); issue_piece(dn, pbn, 5); }
-      }
-      if (!(DBG & 2)) issue_w(koff_of(gstep + s + 2), (s + 2) % 3);
-      if constexpr (s == 2) { if (dn.mode == 1) coef_table(next); }
       const int g = gstep + s;
-      if (g >= sb && g < se && !(DBG & 1)) mma_main(pb, (s / 3) * PW + (s % 3), s % 3);
+      const bool active = g >= sb && g < se;
+      // ---- DMA phase
+      if (!(DBG & 8)) {
+        if constexpr (s == 1) { issue_coef(dn); issue_piece(dn, pbn, 0); issue_piece(dn, pbn, 1); issue_piece(dn, pbn, 2); }
+        if constexpr (s == 2) { issue_piece(dn, pbn, 3); issue_piece(dn, pbn, 4); issue_piece(dn, pbn, 5); }
+      }
+      int nw = 0;                                        // (patch pieces first, the weight tile last: the counted wait below leaves only IT in flight)
+      if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) nw = issue_w(kn, (g + PD) % NSTG); }
+      if constexpr (s == 2) { if (dn.mode == 1) coef_table(next); }
       if constexpr (s >= 3) { if (dn.mode == 1 && !(DBG & 4)) norm_piece(pbn, s - 3); }
+      unsigned xa[MFR];
+      if (active) xa_main(pb, (s / 3) * PW + (s % 3), xa);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (active && !(DBG & 1)) mma_pre(xa);
+      HB_STAMP(pa_dma)
+      if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+      HB_STAMP(pa_wx)
+      // ---- MFMA phase.  (The normalisation arithmetic as per-group slices in here - loads in the DMA phase, one element after each
+      // MFMA group - was built and measured slower, 65 vs 60 us: one wave per SIMD is in this phase, so VALU between its MFMAs delays them)
+      if (active && !(DBG & 1)) mma_post(xa, lds0 + (g % NSTG) * WSTAGE, [&](auto, const int) {});
+      // this wave's pieces of the NEXT tap's weight tile (requested PD DMA phases ago) and everything older have landed; with PD = 2 the
+      // tile requested in this step's DMA phase stays in flight
+      wait_vm(PD >= 2 ? nw : 0);
+      HB_STAMP(pa_mma)
+      if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+      HB_STAMP(pa_wy)
     };
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
     step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
     gstep += 9; ++seq;
-    if (next < 0) { cur = -1; break; }
     cur = next;
   }
+  if (pingpong && !grpB) __builtin_amdgcn_s_barrier(); // (group B's extra barrier of the entry: the groups are level again)
+  // ---- shortcut steps: lock step, the next shortcut patch requested one step ahead into the other patch buffer
   while (cur >= nc) {
-    // shortcut step: the next shortcut patch is requested one step ahead (P before W, so vmcnt(WI) covers it)
     const int next = cur < ch_last ? cur + 1 : -1;
     const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0, pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
     const PDesc dn = pdesc(next);
-    const int st = gstep % 3;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WI) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     issue_piece(dn, pbn, 0); issue_piece(dn, pbn, 1); issue_piece(dn, pbn, 2); issue_piece(dn, pbn, 3);
-    issue_w(koff_of(gstep + 2), (gstep + 2) % 3);
-    mma_sc(pb, st);
+    int nw = 0;
+    { const long kn = koff_of(gstep + PD); if (kn >= 0) nw = issue_w(kn, (gstep + PD) % NSTG); }
+    unsigned xa[MFR];
+    xa_sc(pb, xa);
+    mma_pre(xa);
+    __builtin_amdgcn_s_barrier();
+    mma_post(xa, lds0 + (gstep % NSTG) * WSTAGE, [&](auto, const int) {});
+    wait_vm(PD >= 2 ? nw : 0);                         // (the next shortcut patch, requested before the weight tile, has landed)
+    __builtin_amdgcn_s_barrier();
     gstep += 1; ++seq;
     cur = next;                                        // (-1 ends the loop)
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy tail loads must land before LDS is reused
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+#undef HB_DSR
 
   if (TIMING) tm[2] = __builtin_amdgcn_s_memrealtime();
   // ---------------------------------------------------------------- epilogue
-  // acc[j][i][e] = out[pixel wm*64 + i*16 + lr][channel n0 + wn*16NF + j*16 + 4 lq + e].  Rows (tile pixels) [own0, own0 + RO) are
+  // acc[j][i][e] = out[pixel wm*16MFR + i*16 + lr][channel n0 + wn*16NF + j*16 + 4 lq + e].  Rows (tile pixels) [own0, own0 + RO) are
   // this block's; the other rows of its accumulators go to its slab for their owners.
   constexpr int LDT = L::LDT, OCP = L::OCP, RL = L::RL;
   const int RO = 256 / S, own0 = r * RO;
@@ -365,8 +479,8 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
   if (S > 1) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slabs + (tile_slot + r) * slab_elems), 0, (int)(slab_elems * 4), 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row0 = wm * 64 + i * 16;
+    for (int i = 0; i < MFR; ++i) {
+      const int row0 = wm * (16 * MFR) + i * 16;
       if (row0 / RO == r) continue;                    // wave-uniform
 #pragma unroll
       for (int j = 0; j < NF; ++j)
@@ -400,8 +514,8 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     const int prow0 = own0 + ep * RPP;                 // first tile pixel of this pass
     if (ep) __builtin_amdgcn_s_barrier();              // the previous pass is done with the staging tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row0 = wm * 64 + i * 16;
+    for (int i = 0; i < MFR; ++i) {
+      const int row0 = wm * (16 * MFR) + i * 16;
       if (row0 < prow0 || row0 >= prow0 + RPP) continue;
 #pragma unroll
       for (int j = 0; j < NF; ++j) *(f32x4*)(tile + (row0 - prow0 + lr) * LDT + wn * 16 * NF + j * 16 + 4 * lq) = acc[j][i];
@@ -420,7 +534,9 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (TIMING && ep == 0) tm[4] = __builtin_amdgcn_s_memrealtime();
-    // items: (row lane rl, octet o), the octet fixed per thread so the column partial sums stay in registers
+    // items: (row lane rl, octet o), the octet fixed per thread so the column partial sums stay in registers.  (Requesting the residual
+    // rows of both passes up front and every load of a pass before its first store was measured: slower - 67.7 vs 60.0 us - the extra
+    // live registers spill next to the accumulators)
     auto items = [&](auto S_, auto U_) {
       constexpr int SS = decltype(S_)::value, U = decltype(U_)::value;
       for (int k0 = 0; k0 * RL < RPP; k0 += U) {
@@ -486,6 +602,7 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     else if (S == 4) items(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
     else items(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
   }
+  if (TIMING) tm[6] = __builtin_amdgcn_s_memrealtime();
   if (p.colstats) {
     // per-channel (sum, sum of squares) of the ROUNDED outputs of this block's rows: float inside the block in a fixed order, 64-bit
     // fixed point across blocks (DmxStat)
@@ -501,103 +618,139 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
       dmx_stat_add(p.colstats + ((size_t)b * p.N + n0 + c) * DMX_STAT_WORDS, sa, sq);
     }
   }
+#ifdef DMX_PROBES
+  if (TIMING && (t == 0 || t == 256)) {                // phase sums of wave 0 (group A) and wave 4 (group B), behind the 4096 block records
+    long long* o2 = TIMING + (size_t)(4096 + blockIdx.x * 2 + (t >> 8)) * 8;
+    o2[0] = pa_dma; o2[1] = pa_wx; o2[2] = pa_mma; o2[3] = pa_wy; o2[4] = gstep;
+  }
+#endif
   if (TIMING && t == 0) {
     long long* o_ = TIMING + (size_t)blockIdx.x * 8;
     tm[5] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) o_[i] = tm[i];
-    o_[6] = r; o_[7] = se - sb;
+    for (int i = 0; i < 7; ++i) o_[i] = tm[i];
+    o_[7] = se - sb;
   }
 }
 
-// statistics of a tensor whose producer emitted none: block = 64 rows x all channels of one sample
-__global__ __launch_bounds__(256) void dmx_colstats_kernel(const bf16* x, int ldx, int HW, int C, long long* st, int rows_per_block) {
-  const int b = blockIdx.y, row0 = blockIdx.x * rows_per_block;
-  const int oc = C >> 3;
-  for (int o = threadIdx.x; o < oc; o += 256) {
-    float s[8], q[8];
+// statistics of a tensor whose producer emitted none: block = `rows_per_block` rows x all channels of one sample; thread = (row lane,
+// channel octet), 4 rows in flight per thread, row lanes folded through LDS in a fixed order, one DmxStat add per channel and block
+__global__ __launch_bounds__(512) void dmx_colstats_kernel(const bf16* x, int ldx, int HW, int C, long long* st, int rows_per_block) {
+  extern __shared__ float cs_red[];                    // [RL][C][2]
+  const int b = blockIdx.y, row0 = blockIdx.x * rows_per_block, row1 = min(row0 + rows_per_block, HW);
+  const int oc = C >> 3, RL = 512 / oc;
+  const int t = threadIdx.x, o = t % oc, rl = t / oc;
+  float s[8], q[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    const int row1 = min(row0 + rows_per_block, HW);
-    for (int row = row0; row < row1; row += 4) {
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  if (rl < RL) {
+    for (int row = row0 + rl; row < row1; row += 4 * RL) {
       u32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(x + ((size_t)b * HW + min(row + u, row1 - 1)) * ldx + o * 8);
+      for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(x + ((size_t)b * HW + min(row + u * RL, row1 - 1)) * ldx + o * 8);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (row + u >= row1) continue;
+        if (row + u * RL >= row1) continue;
         float f[8]; unpack_bf8(v[u], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
       }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dmx_stat_add(st + ((size_t)b * C + o * 8 + e) * DMX_STAT_WORDS, s[e], q[e]);
+    for (int e = 0; e < 8; ++e) { cs_red[(rl * C + o * 8 + e) * 2] = s[e]; cs_red[(rl * C + o * 8 + e) * 2 + 1] = q[e]; }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 512) {
+    float sa = 0.f, sq = 0.f;
+    for (int k = 0; k < RL; ++k) { sa += cs_red[(k * C + c) * 2]; sq += cs_red[(k * C + c) * 2 + 1]; }
+    dmx_stat_add(st + ((size_t)b * C + c) * DMX_STAT_WORDS, sa, sq);
   }
 }
 
-int halo_nf(const HaloConvArgs& a) { return a.N % 160 == 0 ? 5 : (a.N % 128 == 0 ? 4 : 0); }
-
-void halo_geometry(HaloConvArgs& a) {
-  if (a.W % 32 == 0 && a.H % 8 == 0) { a.TW = 32; a.TH = 8; }
-  else if (a.W % 16 == 0 && a.H % 16 == 0) { a.TW = 16; a.TH = 16; }
-  else { a.TW = 0; a.TH = 0; }
-  const int nf = halo_nf(a);
-  if (!a.TW || !nf) { a.splits = 0; return; }
+int n_cus() {
   static int n_cu = 0;
   if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-  const long tiles = (long)a.B * (a.H / a.TH) * (a.W / a.TW) * (a.N / (32 * nf));
+  return n_cu;
+}
+
+// Plan: tile geometry, column width BN (160 / 128: 4 x 2 waves; 80 / 64: 8 x 1 waves) and K split.  A K split costs an exchange of fp32
+// slabs through memory ((S - 1) / S x 256 x BN x 4 bytes per block, written and read back) and the co-residency of a tile's blocks, so the
+// plan takes the narrow tiles where they make the split unnecessary or smaller; with tiles to spare the wide tile wins (twice the work per
+// weight byte and per barrier).  Costs in us, fitted on scripts/halo_probe.py.
+struct HaloPlan { int TH, TW, nf, wmw, bn, splits; };
+HaloPlan halo_plan(const HaloConvArgs& a) {
+  HaloPlan P{0, 0, 0, 0, 0, 0};
+  if (a.W % 32 == 0 && a.H % 8 == 0) { P.TW = 32; P.TH = 8; }
+  else if (a.W % 16 == 0 && a.H % 16 == 0) { P.TW = 16; P.TH = 16; }
+  else return P;
+  const long tiles_m = (long)a.B * (a.H / P.TH) * (a.W / P.TW);
   const int T = 9 * (a.Cin / 64) + a.Csc / 64;
-  int s = 1;
-  if (a.force_split) s = a.force_split;
-  else while (s < 8 && tiles * (s * 2) <= n_cu && T / (s * 2) >= 9) s *= 2;
-  a.splits = s;
+  double best = 1e300;
+  const int cand[4][3] = {{5, 4, 160}, {4, 4, 128}, {5, 8, 80}, {4, 8, 64}};
+  for (int c = 0; c < 4; ++c) {
+    const int bn = cand[c][2];
+    if (a.N % bn) continue;
+    if (a.force_bn && a.force_bn != bn) continue;
+    const long tiles = tiles_m * (a.N / bn);
+    for (int s = 1; s <= 8; s *= 2) {
+      if (a.force_split && s != a.force_split) continue;
+      if (s > 1 && (tiles * s > n_cus() || T / s < 3)) continue;
+      const double rounds = (double)((tiles * s + n_cus() - 1) / n_cus());
+      const double step = bn >= 128 ? 1.39 : 1.04;                         // us per tap and block (measured, B = 4 64x64x320: K = 2880 / 5760 / 8640)
+      double cost = rounds * ((double)((T + s - 1) / s) * step + 15.0);    // + prologue / epilogue of a block
+      if (s > 1) cost += 3.5 + 2.0 * (double)(s - 1) * bn / 160.0;         // publish + wait + the peers' slabs
+      if (cost < best) { best = cost; P.nf = cand[c][0]; P.wmw = cand[c][1]; P.bn = bn; P.splits = s; }
+    }
+  }
+  return P;
 }
 
 }  // namespace
 
-bool dmx_conv_halo_supported(const HaloConvArgs& a0) {
-  HaloConvArgs a = a0;
+// what the model executors ask: the fused launch is at least as fast IN SITU as GroupNorm + the implicit-GEMM conv (+ its split-K reduce).
+// Measured per shape inside the 50-step pass (B = 4; halo incl. GroupNorm vs conv + reduce + GroupNorm): 64x64 level 61 vs 69, 87 vs 105,
+// 119 vs 129 us; 32x32 level 63 vs 66, 89 vs 98, 124 vs 125; 16x16 level 64 vs 61, 85 vs 77, 48 vs 44 - the blocks of the deep levels
+// are 8-way K splits whose fp32 slab exchange costs what the fusion saves.
+bool dmx_conv_halo_pays(const HaloConvArgs& a) {
+  if (!dmx_conv_halo_supported(a)) return false;
+  return (long)a.H * a.W >= 1024;
+}
+
+bool dmx_conv_halo_supported(const HaloConvArgs& a) {
   if (a.Cin <= 0 || a.Cin % 64 || a.cx0 % 64 || a.cx0 > a.Cin || a.Csc % 64 || (a.Csc && a.cs0 % 64) || a.N % 8 || a.ldo % 8) return false;
   if (a.ldx0 % 8 || (a.x1 && a.ldx1 % 8) || a.ldw % 8 || (a.res && a.ldres % 8)) return false;
   if (a.gn && (a.groups != 32 || a.Cin % a.groups)) return false;
-  halo_geometry(a);
-  if (!a.splits) return false;
-  const long blocks = (long)a.B * (a.H / a.TH) * (a.W / a.TW) * (a.N / (32 * halo_nf(a))) * a.splits;
-  if (a.splits > 1) {
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-    if (blocks > n_cu) return false;                   // the blocks of a tile wait for each other: all of them must be resident
-    if ((a.splits & (a.splits - 1)) || a.splits > 8) return false;
-    const int T = 9 * (a.Cin / 64) + a.Csc / 64;
-    if (T / a.splits < 3) return false;
-  }
-  return true;
+  if (a.force_split && (a.force_split & (a.force_split - 1) || a.force_split > 8)) return false;
+  return halo_plan(a).splits > 0;
 }
 
-int dmx_conv_halo_flag_count(const HaloConvArgs& a0) {
-  HaloConvArgs a = a0; halo_geometry(a);
-  if (a.splits <= 1) return 0;
-  return (int)((long)a.B * (a.H / a.TH) * (a.W / a.TW) * (a.N / (32 * halo_nf(a))) * a.splits);
+static long halo_blocks(const HaloConvArgs& a, const HaloPlan& P) {
+  return (long)a.B * (a.H / P.TH) * (a.W / P.TW) * (a.N / P.bn) * P.splits;
+}
+
+int dmx_conv_halo_flag_count(const HaloConvArgs& a) {
+  const HaloPlan P = halo_plan(a);
+  return P.splits > 1 ? (int)halo_blocks(a, P) : 0;
 }
 
 static size_t halo_flag_bytes(int n) { return align_up((size_t)n * sizeof(int), 256); }
 
-size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a0) {
-  const int n = dmx_conv_halo_flag_count(a0);
-  if (!n) return 0;
-  return halo_flag_bytes(n) + (size_t)n * 256 * (32 * halo_nf(a0)) * sizeof(float);
+size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a) {
+  const HaloPlan P = halo_plan(a);
+  if (P.splits <= 1) return 0;
+  const long n = halo_blocks(a, P);
+  return halo_flag_bytes((int)n) + (size_t)n * 256 * P.bn * sizeof(float);
 }
 
-template <int NF> static int halo_launch_(const HaloConvArgs& a, int blocks, hipStream_t stream) {
-  DMX_LDS_OPT_IN((dmx_conv_halo_kernel<NF>), HaloLds<NF>::TOTAL);
-  hipLaunchKernelGGL((dmx_conv_halo_kernel<NF>), dim3(blocks), dim3(HB_NT), HaloLds<NF>::TOTAL, stream, a);
+template <int NF, int WMW> static int halo_launch_(const HaloConvArgs& a, int blocks, hipStream_t stream) {
+  DMX_LDS_OPT_IN((dmx_conv_halo_kernel<NF, WMW>), (HaloLds<NF, WMW>::TOTAL));
+  hipLaunchKernelGGL((dmx_conv_halo_kernel<NF, WMW>), dim3(blocks), dim3(HB_NT), (HaloLds<NF, WMW>::TOTAL), stream, a);
   return dmx_check_launch("dmx_conv_halo_kernel");
 }
 
 int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   DMX_REQUIRE(a.x0 && a.w && a.out, "conv_halo: null argument");
-  DMX_REQUIRE(dmx_conv_halo_supported(a), "conv_halo: unsupported problem (H=%d W=%d Cin=%d cx0=%d Csc=%d N=%d split=%d)", a.H, a.W, a.Cin, a.cx0, a.Csc, a.N, a.force_split);
+  DMX_REQUIRE(dmx_conv_halo_supported(a), "conv_halo: unsupported problem (H=%d W=%d Cin=%d cx0=%d Csc=%d N=%d split=%d bn=%d)", a.H, a.W, a.Cin, a.cx0, a.Csc, a.N, a.force_split, a.force_bn);
   if (a.gn) DMX_REQUIRE(a.st0 && a.gamma && a.beta && (a.cx0 == a.Cin || a.st1), "conv_halo: the fused GroupNorm needs statistics records, gamma and beta");
   if (a.Csc) DMX_REQUIRE(a.s0 && (a.cs0 == a.Csc || a.s1), "conv_halo: the shortcut segment needs its source tensor(s)");
   DMX_REQUIRE(a.ldw >= 9 * a.Cin + a.Csc, "conv_halo: weight rows shorter than K");
@@ -605,12 +758,18 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
   if (!a.s1) { a.s1 = a.s0; a.lds1 = a.lds0; }
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;
-  halo_geometry(a);
-  const int nf = halo_nf(a);
-  const int tiles = a.B * (a.H / a.TH) * (a.W / a.TW) * (a.N / (32 * nf));
-  const int blocks = tiles * a.splits;
+  const HaloPlan P = halo_plan(a);
+  a.TH = P.TH; a.TW = P.TW; a.splits = P.splits;
+  const int blocks = (int)halo_blocks(a, P);
+  // block -> XCD dealing: weights-major when the weight slab is the larger stream of an XCD, pixel-tile-major otherwise
+  {
+    const double wbytes = 2.0 * a.N * (9.0 * a.Cin + a.Csc), abytes = 2.0 * a.B * a.H * a.W * (double)(a.Cin + a.Csc) * 1.33;
+    const int combos = (a.N / P.bn) * P.splits;
+    // weights-major: every XCD reads its combos' weights once, the activations combos / 8 .. combos times; tile-major: the reverse
+    a.xcd_tile_major = (abytes * (combos >= 8 ? combos / 8.0 : 1.0) + wbytes > abytes + wbytes * 8.0) ? 1 : 0;
+  }
   if (a.splits > 1) {
-    const size_t fb = halo_flag_bytes(blocks), need = fb + (size_t)blocks * 256 * (32 * nf) * sizeof(float);
+    const size_t fb = halo_flag_bytes(blocks), need = fb + (size_t)blocks * 256 * P.bn * sizeof(float);
     if (!workspace || workspace_bytes < need) { dmx_set_error("conv_halo: the K split needs %zu bytes of workspace, got %zu", need, workspace_bytes); return DMX_ERR_WORKSPACE; }
     a.slabs = (float*)((char*)workspace + fb);
     if (!a.flags) { a.flags = (int*)workspace; DMX_HIP(hipMemsetAsync(a.flags, 0, fb, stream)); }
@@ -618,17 +777,22 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
   const double flops = 2.0 * a.B * a.H * a.W * (double)a.N * (9.0 * a.Cin + a.Csc);
   const double bytes = 2.0 * ((double)a.B * a.H * a.W * (a.Cin + a.Csc + a.N) + (double)a.N * (9.0 * a.Cin + a.Csc));
   char tag[96];
-  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d halo gn=%d sk=%d", a.B * a.H * a.W, a.N, 9 * a.Cin + a.Csc, a.gn, a.splits);
+  snprintf(tag, sizeof(tag), "M=%d N=%d K=%d halo gn=%d bn=%d sk=%d", a.B * a.H * a.W, a.N, 9 * a.Cin + a.Csc, a.gn, P.bn, a.splits);
   ProfScope ps(PROF_HALO, stream, flops, bytes, tag);
-  return nf == 5 ? halo_launch_<5>(a, blocks, stream) : halo_launch_<4>(a, blocks, stream);
+  if (P.nf == 5 && P.wmw == 4) return halo_launch_<5, 4>(a, blocks, stream);
+  if (P.nf == 4 && P.wmw == 4) return halo_launch_<4, 4>(a, blocks, stream);
+  if (P.nf == 5 && P.wmw == 8) return halo_launch_<5, 8>(a, blocks, stream);
+  return halo_launch_<4, 8>(a, blocks, stream);
 }
 
 int dmx_colstats_launch(const bf16* x, int ldx, int B, int HW, int C, long long* st, hipStream_t stream) {
-  DMX_REQUIRE(x && st && C % 8 == 0 && ldx % 8 == 0, "colstats: C and ld must be multiples of 8");
-  int rpb = 64;
-  while ((long)B * cdiv(HW, rpb) > 4096) rpb *= 2;
+  DMX_REQUIRE(x && st && C % 8 == 0 && ldx % 8 == 0 && C >= 8 && C <= 4096, "colstats: C and ld must be multiples of 8, 8 <= C <= 4096");
+  const int oc = C / 8, RL = 512 / oc;
+  int rpb = 4 * RL;                                    // >= 4 rows per thread; fewer, larger blocks once the chip is covered twice
+  while ((long)B * cdiv(HW, rpb) > 2 * n_cus() && rpb < HW) rpb *= 2;
   char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d colstats", B * HW, C);
   ProfScope ps(PROF_GNORM, stream, 0.0, 2.0 * (double)B * HW * C, tag);
-  hipLaunchKernelGGL(dmx_colstats_kernel, dim3(cdiv(HW, rpb), B), dim3(256), 0, stream, x, ldx, HW, C, st, rpb);
+  const size_t lds = (size_t)RL * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(dmx_colstats_kernel, dim3(cdiv(HW, rpb), B), dim3(512), lds, stream, x, ldx, HW, C, st, rpb);
   return dmx_check_launch("dmx_colstats_kernel");
 }

@@ -137,6 +137,12 @@ class Exec {
   long long* cs_pool = nullptr; size_t cs_cap = 0, cs_used = 0;
   void want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B);
   long long* stat_slice(int B, int C);
+  // statistics records of a tensor whose producer emitted none (one streaming pass, conv_halo.hip dmx_colstats_launch); no-op when
+  // the tensor has them, in fp32 validation mode or when the halo conv is switched off
+  void ensure_stats(Tn& t);
+  // y = conv3x3(SiLU(GroupNorm(x0 | x1))) [+ bias + row bias + residual | fused 1x1 shortcut] as ONE launch (conv_halo.hip) when the
+  // kernel takes the problem and both sources carry statistics records; otherwise GroupNorm + conv as two ops
+  Tn conv_gn(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, const bf16* w, int Cout, const ConvOpts& o);
   void drop(const void* p) { ws.release(p); }
   void drop(const Tn& t) { drop((const void*)t.p); }
 
@@ -161,6 +167,7 @@ class Exec {
   // operation take them (C = 320, rows % 64 == 0, bf16 path, dmx_set_xf_chain(1))
   bool chain_ok(const Tn& x) const;
   void xf_chain(int mode, XfChainArgs& a);
+  void chain_stats(XfChainArgs& a, Tn& y);            // mode-1 chain: also emit the statistics records of its output y (when a fused GroupNorm -> conv can use them)
   // fused attention core; V row-major (LDS transpose-read path)
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                  bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale);

@@ -269,6 +269,61 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   return y;
 }
 
+bool dmx_halo_conv_enabled();
+void Exec::ensure_stats(Tn& t) {
+  if (rc || f32 || t.cst || !dmx_halo_conv_enabled() || !g_gn_producer_stats || (t.C & 7) || (t.ld & 7)) return;
+  // only where a fused GroupNorm -> conv launch can consume them (the tile geometries of conv_halo.hip, levels where it pays)
+  if (!((t.W % 32 == 0 && t.H % 8 == 0) || (t.W % 16 == 0 && t.H % 16 == 0)) || (g_halo_conv == 1 && (long)t.H * t.W < 1024)) return;
+  long long* st = stat_slice(t.B, t.C);
+  if (!st) return;
+  if (!dry && !rc) rc = dmx_colstats_launch(t.p, t.ld, t.B, t.H * t.W, t.C, st, stream);
+  t.cst = st;
+}
+
+Tn Exec::conv_gn(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, const bf16* w, int Cout, const ConvOpts& o) {
+  HaloConvArgs a{};
+  bool fused = !f32 && dmx_halo_conv_enabled() && o.ksize == 3 && o.stride == 1 && o.pad == 1 && !o.ups && !o.out_f32 && x0.cst && (!x1 || x1->cst);
+  if (fused) {
+    a.x0 = x0.p; a.ldx0 = x0.ld; a.cx0 = x0.C; a.Cin = x0.C + (x1 ? x1->C : 0);
+    if (x1) { a.x1 = x1->p; a.ldx1 = x1->ld; }
+    a.B = x0.B; a.H = x0.H; a.W = x0.W;
+    a.gn = 1; a.silu = 1; a.groups = groups; a.eps = eps; a.st0 = x0.cst; a.st1 = x1 ? x1->cst : nullptr; a.gamma = gamma; a.beta = beta;
+    if (o.sc0) {
+      a.s0 = o.sc0->p; a.lds0 = o.sc0->ld; a.cs0 = o.sc0->C; a.Csc = o.sc0->C;
+      if (o.sc1) { a.s1 = o.sc1->p; a.lds1 = o.sc1->ld; a.Csc += o.sc1->C; }
+    }
+    a.w = w; a.ldw = 9 * a.Cin + a.Csc; a.N = Cout;
+    a.bias = o.bias; a.rowbias = o.rowbias; a.ldrb = o.ldrb;
+    if (o.res) { a.res = o.res->p; a.ldres = o.res->ld; }
+    a.ldo = Cout;
+    fused = g_halo_conv > 1 ? dmx_conv_halo_supported(a) : dmx_conv_halo_pays(a);      // (dmx_set_halo_conv(2): wherever the kernel runs - tests, A/B)
+  }
+  if (!fused) {
+    Tn t = groupnorm(x0, x1, gamma, beta, groups, eps, true);
+    Tn y = conv(t, nullptr, w, Cout, o);
+    drop(t);
+    return y;
+  }
+  Tn y = make(x0.B, x0.H, x0.W, Cout);
+  a.out = y.p;
+  if (o.stats && g_gn_producer_stats) { a.colstats = stat_slice(x0.B, Cout); y.cst = a.colstats; }
+  const int nflags = dmx_conv_halo_flag_count(a);
+  if (nflags) {                                        // one zeroed int per block from the pool the stream-K GEMMs use (zeroed once per forward)
+    constexpr size_t POOL = 64 * 1024;
+    if (!flag_pool) {
+      flag_pool = (int*)raw(POOL * sizeof(int)); flag_cap = POOL; flag_used = 0;
+      if (!dry && !rc && hipMemsetAsync(flag_pool, 0, POOL * sizeof(int), stream) != hipSuccess) { dmx_set_error("flag pool memset failed"); rc = DMX_ERR_HIP; return y; }
+    }
+    const size_t n = align_up((size_t)nflags, 64);
+    if (flag_used + n <= flag_cap) { a.flags = flag_pool + flag_used; flag_used += n; }   // else: the launcher zeroes a slice of its own workspace
+  }
+  const size_t wsb = dmx_conv_halo_workspace_bytes(a);
+  void* wsp = wsb ? raw(wsb) : nullptr;
+  if (!dry && !rc) rc = dmx_conv_halo_launch(a, wsp, wsb, stream);
+  if (wsp) ws.release(wsp);
+  return y;
+}
+
 Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu,
                 RowStats* rowstats, const LnIn* ln, bool gn_stats) {
   const int Nout = geglu ? N / 2 : N;
@@ -350,6 +405,13 @@ Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps
 static int g_xf_chain = 1;
 extern "C" int dmx_set_xf_chain(int on) { const int old = g_xf_chain; g_xf_chain = on; return old; }
 bool Exec::chain_ok(const Tn& x) const { return g_xf_chain && !f32 && x.ld == x.C && (g_xf_chain > 1 ? dmx_xf_chain_supported(x.rows(), x.C) : dmx_xf_chain_pays(x.rows(), x.C)); }
+void Exec::chain_stats(XfChainArgs& a, Tn& y) {
+  if (rc || f32 || !dmx_halo_conv_enabled() || !g_gn_producer_stats || (y.H * y.W) % 64) return;
+  if (!((y.W % 32 == 0 && y.H % 8 == 0) || (y.W % 16 == 0 && y.H % 16 == 0)) || (g_halo_conv == 1 && (long)y.H * y.W < 1024)) return;
+  a.colstats = stat_slice(y.B, y.C);
+  if (!a.colstats) return;
+  a.cs_rows = y.H * y.W; y.cst = a.colstats;
+}
 void Exec::xf_chain(int mode, XfChainArgs& a) {
   if (dry || rc) return;
   rc = dmx_xf_chain_launch(a, mode, stream);
@@ -419,17 +481,14 @@ Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn
               const float* tproj, int tproj_total, int wmul) {
   auto F = [&](size_t off) { return (const float*)(arena + off * (size_t)wmul); };
   auto H = [&](size_t off) { return (const bf16*)(arena + off * (size_t)wmul); };
-  Tn t1 = ex.groupnorm(x0, x1, F(r.n1g), F(r.n1b), groups, eps, true);
+  // [GroupNorm -> SiLU -> conv3x3] twice; each pair is ONE launch where the halo conv takes it (Exec::conv_gn)
   ConvOpts o1; o1.bias = F(r.b1); o1.stats = 1;        // norm2 reads conv1's output
   if (r.temb_off >= 0 && tproj) { o1.rowbias = tproj + r.temb_off; o1.ldrb = tproj_total; }
-  Tn t2 = ex.conv(t1, nullptr, H(r.w1), r.cout, o1);
-  ex.drop(t1);
-  Tn t3 = ex.groupnorm(t2, nullptr, F(r.n2g), F(r.n2b), groups, eps, true);
-  ex.drop(t2);
+  Tn t2 = ex.conv_gn(x0, x1, F(r.n1g), F(r.n1b), groups, eps, H(r.w1), r.cout, o1);
   ConvOpts o2; o2.bias = F(r.b2); o2.stats = 1;        // a GroupNorm comes next in every graph (next resnet / transformer / out norm)
   if (ex.f32 && r.shortcut) { o2.bias = F(r.b2raw); o2.bias2 = F(r.bscraw); }     // the folded bias is derived data: not in the master arena
   if (r.shortcut) { o2.sc0 = &x0; o2.sc1 = x1; } else { o2.res = &x0; }
-  Tn y = ex.conv(t3, nullptr, H(r.w2), r.cout, o2);
-  ex.drop(t3);
+  Tn y = ex.conv_gn(t2, nullptr, F(r.n2g), F(r.n2b), groups, eps, H(r.w2), r.cout, o2);
+  ex.drop(t2);
   return y;
 }

@@ -94,11 +94,13 @@ struct HaloConvArgs {
   bf16* out; int ldo;
   long long* colstats;                               // DmxStat records of the OUTPUT [B][N][4], added to (zero before the launch), or null
   int force_split;                                   // 0 = automatic K split (1 / 2 / 4 / 8 blocks per tile)
+  int force_bn;                                      // 0 = automatic column tile (160 / 128 / 80 / 64)
   int dbg; long long* timing;                        // measurement aids (0 / null in the product path)
   // filled by the launcher
-  int TH, TW, splits; float* slabs; int* flags; const bf16* zeros;
+  int TH, TW, splits, xcd_tile_major; float* slabs; int* flags; const bf16* zeros;
 };
 bool dmx_conv_halo_supported(const HaloConvArgs& a);
+bool dmx_conv_halo_pays(const HaloConvArgs& a);        // supported AND at least as fast in situ as GroupNorm + implicit-GEMM conv (what the executors ask)
 size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a);
 int dmx_conv_halo_flag_count(const HaloConvArgs& a);   // ints of zeroed flags the launch needs (0: none)
 int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
@@ -187,6 +189,9 @@ struct XfChainArgs {
   const bf16* xres; int ldxres;          //         the Transformer2DModel residual
   float eps;
   int dbg; long long* timing;            // measurement aids (0 / null in the product path): bit 0 no MFMA phase, bit 1 no DMA refills; [blocks][8] phase timestamps
+  // mode 1: DmxStat records of the block output y for the GroupNorm that reads it next ([M / cs_rows][C][4], added to; cs_rows = rows per
+  // sample, a multiple of 64), or null
+  long long* colstats; int cs_rows;
 };
 bool dmx_xf_chain_supported(int M, int C);
 bool dmx_xf_chain_pays(int M, int C);      // what the model executors use: enough 64-row blocks to fill the chip

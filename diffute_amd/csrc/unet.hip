@@ -338,6 +338,7 @@ struct Fwd {
       d.wf1 = u->at<bf16>(w.wf1); d.wf2 = u->at<bf16>(w.wf2); d.bf2 = u->at<float>(w.bf2);
       d.wpo = u->at<bf16>(w.wpo); d.bpo = u->at<float>(w.bpo); d.xres = x.p; d.ldxres = x.ld;
       d.y = y.p; d.ldy = y.ld;
+      ex.chain_stats(d, y);                            // (statistics records of y for the GroupNorm -> conv launch that reads it next)
       ex.xf_chain(1, d);
       ex.drop(a); ex.drop(h2); ex.drop(h3);
       return y;
@@ -490,6 +491,7 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
     ex.drop(col);
   }
   ex.tap(h);                                           // "conv_in"
+  ex.ensure_stats(h);
   std::vector<Tn> skips; skips.push_back(h);
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L; ++j) {
@@ -501,17 +503,20 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
       Tn y = f.resnet(u->down_res[i][j], h, nullptr);
       if (fine) ex.tap(y);
       if (cfg.down_has_attn[i]) { Tn z = f.xformer(u->down_xf[i][j], y); ex.drop(y); y = z; if (fine) ex.tap(y); }
+      ex.ensure_stats(y);                             // (two GroupNorms read it: the next block's and the up path's concat)
       h = y; skips.push_back(h);                      // previous h stays alive as a skip
     }
     if (i < 3) {
       ConvOpts o; o.stride = 2; o.pad = 1; o.bias = f.W<float>(u->down_ds[i].b); o.stats = 1;
       h = ex.conv(h, nullptr, f.W<bf16>(u->down_ds[i].w), boc[i], o);
+      ex.ensure_stats(h);
       skips.push_back(h);
     }
     ex.tap(h);                                         // "down{i}"
   }
   { Tn y = f.resnet(u->mid_res[0], h, nullptr);          // h is also skips.back(): keep it
     Tn z = f.xformer(u->mid_xf, y); ex.drop(y);
+    ex.ensure_stats(z);
     h = f.resnet(u->mid_res[1], z, nullptr); ex.drop(z); }
   ex.tap(h);                                           // "mid"
   for (int i = 0; i < 4; ++i) {
@@ -520,6 +525,7 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
       Tn y = f.resnet(u->up_res[i][j], h, &s);
       ex.drop(h); ex.drop(s);
       if (cfg.up_has_attn[i]) { Tn z = f.xformer(u->up_xf[i][j], y); ex.drop(y); y = z; }
+      ex.ensure_stats(y);
       h = y;
     }
     if (i < 3) {
@@ -527,6 +533,7 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
       const bool direct = ex.f32;                                          // (the phase weights are derived data of the bf16 path)
       ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = f.W<float>(u->up_us[i].b); o.stats = 1;
       Tn y = ex.conv(h, nullptr, direct ? f.W<bf16>(u->up_us[i].w) : u->at<bf16>(u->up_us[i].wp), boc[3 - i], o);
+      ex.ensure_stats(y);
       ex.drop(h); h = y;
     }
     ex.tap(h);                                         // "up{i}"

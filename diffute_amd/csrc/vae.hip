@@ -96,6 +96,7 @@ int vae_encode_run(dmx_vae* v, Exec& ex, const float* x, float* moments, int B, 
     h = ex.linear(col, v->W<bf16>(v->e_in.w), c.block_out_channels[0], v->W<float>(v->e_in.b), nullptr, false, nullptr, nullptr, true);
     ex.drop(col);
   }
+  ex.ensure_stats(h);                                  // (statistics records for the first resnet's fused GroupNorm -> conv launch)
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L; ++j) {
       Tn y = resnet_run(ex, v->wbase(), v->e_res[i][j], h, nullptr, G, 1e-6f, nullptr, 0, v->wmul());
@@ -104,11 +105,13 @@ int vae_encode_run(dmx_vae* v, Exec& ex, const float* x, float* moments, int B, 
     if (i < 3) {                       // F.pad(h,(0,1,0,1)) + conv s2 p0: the gather's range check is the pad
       ConvOpts o; o.stride = 2; o.pad = 0; o.bias = v->W<float>(v->e_ds[i].b); o.stats = 1;
       Tn y = ex.conv(h, nullptr, v->W<bf16>(v->e_ds[i].w), c.block_out_channels[i], o);
+      ex.ensure_stats(y);
       ex.drop(h); h = y;
     }
   }
   { Tn y = resnet_run(ex, v->wbase(), v->e_mid[0], h, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(h);
     Tn z = attn_run(ex, v, v->e_attn, y, G); ex.drop(y);
+    ex.ensure_stats(z);
     h = resnet_run(ex, v->wbase(), v->e_mid[1], z, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(z); }
   Tn t = ex.groupnorm(h, nullptr, v->W<float>(v->e_ng), v->W<float>(v->e_nb), G, 1e-6f, true);
   ex.drop(h);
@@ -171,8 +174,10 @@ int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, in
   h = ex.linear(col, v->W<bf16>(v->d_in.w), c.block_out_channels[3], v->W<float>(v->d_in.b), nullptr, false, nullptr, nullptr, true);
   ex.drop(col);
   }
+  ex.ensure_stats(h);
   { Tn y = resnet_run(ex, v->wbase(), v->d_mid[0], h, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(h);
     Tn zz = attn_run(ex, v, v->d_attn, y, G); ex.drop(y);
+    ex.ensure_stats(zz);
     h = resnet_run(ex, v->wbase(), v->d_mid[1], zz, nullptr, G, 1e-6f, nullptr, 0, v->wmul()); ex.drop(zz); }
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L + 1; ++j) {
@@ -184,6 +189,7 @@ int vae_decode_run(dmx_vae* v, Exec& ex, const float* z, float* image, int B, in
       const bool direct = ex.f32;                                          // (the phase weights are derived data of the bf16 path)
       ConvOpts o; o.ups = 1; o.ups2 = direct ? 0 : 1; o.bias = v->W<float>(v->d_us[i].b); o.stats = 1;
       Tn y = ex.conv(h, nullptr, v->W<bf16>(direct ? v->d_us[i].w : v->d_us[i].wp), c.block_out_channels[3 - i], o);
+      ex.ensure_stats(y);
       ex.drop(h); h = y;
     }
   }

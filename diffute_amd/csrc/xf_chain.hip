@@ -295,6 +295,35 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
         const u32x4 v = *(const u32x4*)(X + row * (XC * 2) + (xsw(ch, row) << 4));
         *(u32x4*)(gout + (size_t)(m0 + row) * ldg + ch * 8) = v;
       }
+      if (MODE == 1 && p.colstats && gout == p.y) {
+        // GroupNorm statistics of the block output for its next reader (the fused GroupNorm -> conv launch of conv_halo.hip): per-channel
+        // (sum, sum of squares) of the ROUNDED values in the exchange image, 8 row groups x 40 octets, folded in a fixed order through
+        // the (idle) feed-forward chunk buffer, one DmxStat add per channel and block
+        float* red = (float*)(smem + XFF_OFF);         // [8][320][2]
+        if (t < 320) {
+          const int o = t % 40, rg = t / 40;
+          float sa[8], sq[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8) {
+            const int row = rg * 8 + r8;
+            float f[8]; unpack_bf8(*(const u32x4*)(X + row * (XC * 2) + (xsw(o, row) << 4)), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sa[e] += f[e]; sq[e] += f[e] * f[e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { red[((rg * XC) + o * 8 + e) * 2] = sa[e]; red[((rg * XC) + o * 8 + e) * 2 + 1] = sq[e]; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t < XC) {
+          float sa = 0.f, sq = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { sa += red[(k * XC + t) * 2]; sq += red[(k * XC + t) * 2 + 1]; }
+          dmx_stat_add(p.colstats + ((size_t)(m0 / p.cs_rows) * XC + t) * DMX_STAT_WORDS, sa, sq);
+        }
+      }
     }
     // (the next XSTEP's barrier comes before the DMA that reuses this slot)
   };
@@ -452,6 +481,7 @@ int dmx_xf_chain_launch(const XfChainArgs& a, int mode, hipStream_t stream) {
   DMX_REQUIRE(mode >= 0 && mode <= 2, "xf_chain: mode %d", mode);
   DMX_REQUIRE(dmx_xf_chain_supported(a.M, a.C), "xf_chain: M=%d C=%d unsupported (C = 320, M %% 64 == 0)", a.M, a.C);
   DMX_REQUIRE(a.x && (a.res || mode == 2) && a.w0 && a.b0 && a.h_out && a.y && a.c1 && a.c2, "xf_chain: null operand");
+  if (a.colstats) DMX_REQUIRE(mode == 1 && a.cs_rows > 0 && a.cs_rows % 64 == 0 && a.M % a.cs_rows == 0, "xf_chain: output statistics need mode 1 and samples of a multiple of 64 rows");
   DMX_REQUIRE(a.ldx % 8 == 0 && a.ldres % 4 == 0 && a.ldh % 8 == 0 && a.ldy % 8 == 0, "xf_chain: row strides must be multiples of 8 elements");
   if (mode != 1) DMX_REQUIRE(a.w1 != nullptr, "xf_chain: null operand");
   else DMX_REQUIRE(a.wf1 && a.wf2 && a.bf2 && a.wpo && a.bpo && a.xres && a.ldxres % 4 == 0, "xf_chain: null operand");
