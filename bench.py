@@ -47,7 +47,7 @@ def pmc_traffic(kernel_name):
     """bytes per launch of `kernel_name` from the committed PMC summary (scripts/rocprof_to_profiles.py), or None"""
     import csv
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(here, f) for f in ("r03_pmc_traffic.csv", "r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if os.path.exists(os.path.join(here, f))), None)
+    path = next((os.path.join(here, f) for f in ("r04_pmc_traffic.csv", "r03_pmc_traffic.csv", "r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if os.path.exists(os.path.join(here, f))), None)
     if path is None:
         return None
     for r in csv.DictReader(open(path)):
@@ -57,8 +57,8 @@ def pmc_traffic(kernel_name):
 
 
 def secondary_configs(dev, unet):
-    """One timed repetition (after one warm-up) of the other BASELINE configs and of the reference's own operating point, so the
-    driver sees them: cfg3 (AutoencoderKL encode + decode, 512 px, batch 32), the reference's loop (app.ipynb:545,806-816,914:
+    """The other BASELINE configs and the reference's own operating point (each: 3 warm-ups, the MEDIAN of 5 timed repetitions -
+    SURVEY 8d), so the driver sees them: cfg3 (AutoencoderKL encode + decode, 512 px, batch 32), the reference's loop (app.ipynb:545,806-816,914:
     DDPMScheduler, 150 steps, batch 1 - weight-bandwidth bound, priced against HBM), cfg5 (768 px, 50 steps, batch 2, FP16: the
     fp16 build of the library) and one cfg4 training step at the per-GPU shape (8 x 512 px, forward + backward + fused AdamW).
     Builder-side detail: scripts/bench_extra.py, scripts/bench_train.py."""
@@ -68,10 +68,15 @@ def secondary_configs(dev, unet):
     from diffute_amd.synthetic import synth_inputs, text_crop_images
     out = {}
 
-    def timed(fn):
-        fn(); torch.cuda.synchronize(dev)
-        t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0, r
+    def timed(fn, warm=3, reps=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2], r
 
     try:
         # ---- the reference's operating point: B = 1, 150 DDPM steps (injected variance noise = the device randn it draws)
@@ -84,6 +89,16 @@ def secondary_configs(dev, unet):
                              "roofline": {"bound": "hbm", "achieved": round(wbytes * 150 / t / 1e9, 1), "peak": 6300.0, "unit": "GB/s",
                                           "frac": round(wbytes * 150 / t / 6.3e12, 4), "note": "algorithmic bytes = the 1.73 GB of bf16 weights every UNet call must stream; peak = 6.3 TB/s achievable HBM"},
                              "finite": bool(torch.isfinite(o).all())}
+        # ---- diagnostic only (the headline stays batch 4): the same 50-step loop at batch 16 - separates "the kernels are slow" from
+        # "batch 4 is small for 256 CUs"
+        lat, mask, mlat, ctx = synth_inputs(16, 64, 64, 577, 1024, device=dev)
+        t, o = timed(lambda: D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 50), warm=1, reps=3)
+        fl = 50 * unet_flops(unet.config, 16, 64, 64, 577, True, phase_upsample=True)
+        out["b16"] = {"config": "diagnostic: the headline loop (512 px, 50 DDIM steps, bf16) at batch 16", "ms_per_batch": round(t * 1e3, 1), "images_per_s": round(16 / t, 3),
+                      "loop_tflops": round(fl / t / 1e12, 1), "mfma_frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "finite": bool(torch.isfinite(o).all())}
+        del lat, mask, mlat, ctx, o
+        unet._slots = {}
+        torch.cuda.empty_cache()
         # ---- cfg5: 768 px, fp16 build
         unet.to(dtype=torch.float16)
         lat, mask, mlat, ctx = synth_inputs(2, 96, 96, 577, 1024, device=dev)
@@ -117,7 +132,7 @@ def secondary_configs(dev, unet):
         sched = D.DDPMScheduler()
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
-            t, r = timed(lambda: train_step(unet, vae, sched, opt, batch, generator=g))
+            t, r = timed(lambda: train_step(unet, vae, sched, opt, batch, generator=g), warm=3, reps=5)
         out["cfg4_train_step_b8"] = {"config": "one training step at the cfg4 per-GPU shape: 8 x 512 px, bf16, VAE encodes + UNet forward + backward + clip + fused AdamW (1 GPU, no exchange)",
                                      "ms_per_step": round(t * 1e3, 1), "images_per_s": round(8 / t, 2), "loss": float(r["loss"]),
                                      "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
@@ -250,6 +265,7 @@ def main():
                               "kernel": KERNEL_NAMES[dom],
                               "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+                              "algorithmic_bytes_per_launch": round(by / n),      # launch-weighted activations + weights + output of this class: compare with `traffic`
                               "whole_loop_frac": result["loop_mfma_frac"],
                               "note": "hipEvent-bracketed launches over one 50-step pass, minus %.1f us of event overhead per launch; whole_loop_frac = algorithmic FLOPs of the whole 50-step loop / timed pass / peak; traffic = HBM bytes per launch of this kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ (FETCH x2 per the gfx950 note), null if absent" % EVENT_OVERHEAD_US}
         result["kernel_classes"] = classes

@@ -49,7 +49,7 @@ class HaloConvDesc(ctypes.Structure):
         ("s0", c_void_p), ("s1", c_void_p), ("lds0", c_int), ("lds1", c_int), ("cs0", c_int), ("Csc", c_int),
         ("w", c_void_p), ("ldw", c_int), ("N", c_int), ("bias", c_void_p), ("rowbias", c_void_p), ("ldrb", c_int),
         ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("colstats", c_void_p),
-        ("force_split", c_int), ("force_bn", c_int), ("dbg", c_int), ("timing", c_void_p),
+        ("force_split", c_int), ("force_bn", c_int), ("force_waves", c_int), ("dbg", c_int), ("timing", c_void_p),
     ]
 
 

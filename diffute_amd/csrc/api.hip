@@ -124,7 +124,7 @@ static HaloConvArgs halo_args(const dmx_halo_conv_desc* d) {
   a.s0 = (const bf16*)d->s0; a.s1 = (const bf16*)d->s1; a.lds0 = d->lds0; a.lds1 = d->lds1; a.cs0 = d->s1 ? d->cs0 : d->Csc; a.Csc = d->s0 ? d->Csc : 0;
   a.w = (const bf16*)d->w; a.ldw = d->ldw; a.N = d->N; a.bias = d->bias; a.rowbias = d->rowbias; a.ldrb = d->ldrb;
   a.res = (const bf16*)d->res; a.ldres = d->ldres; a.out = (bf16*)d->out; a.ldo = d->ldo; a.colstats = d->colstats;
-  a.force_split = d->force_split; a.force_bn = d->force_bn; a.dbg = d->dbg; a.timing = d->timing;
+  a.force_split = d->force_split; a.force_bn = d->force_bn; a.force_waves = d->force_waves; a.dbg = d->dbg; a.timing = d->timing;
   return a;
 }
 extern "C" int dmx_conv3x3_gn_supported(const dmx_halo_conv_desc* d) { return d && dmx_conv_halo_supported(halo_args(d)) ? 1 : 0; }

@@ -36,14 +36,18 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 namespace {
 
-constexpr int HB_NT = 512;                 // threads
 constexpr int HB_PATCH = 44032;            // patch buffer: 2752 pieces of 16 B (340 rows of 128 B, rounded up to whole 1-KB DMA instructions)
 
 // WMW = waves along the pixel axis: 4 -> 4 x 2 waves of 64-pixel x 16 NF-channel tiles (BN = 32 NF = 160 / 128 columns),
 //                                   8 -> 8 x 1 waves of 32-pixel x 16 NF-channel tiles (BN = 16 NF = 80 / 64 columns: twice the tiles - levels
 //                                        where the wider tile would need a K split, i.e. an exchange of fp32 slabs through memory)
-template <int NF, int WMW> struct HaloLds {
-  static constexpr int BN = (8 / WMW) * 16 * NF;
+//   WNW = waves along the channel axis (1 or 2).  WMW x WNW = 8 waves: two-group ping-pong K loop; 16 waves (8 x 2, 32 x 16 NF wave tiles,
+//   <= 128 registers per lane, four waves per SIMD): lock step, one barrier per tap - what bounds the 8-wave loop is every wave's SERIAL
+//   non-MFMA work per tap (DMA issue, normalisation, addressing), and twice the waves halve it per wave at 1.55 x the LDS fragment bytes
+template <int NF, int WMW, int WNW> struct HaloLds {
+  static constexpr int NT = 64 * WMW * WNW;           // threads
+  static constexpr bool PP = (WMW * WNW == 8);        // two-group ping-pong (8 waves) / lock step (16 waves)
+  static constexpr int BN = WNW * 16 * NF;
   static constexpr int MFR = 16 / WMW;                // 16-pixel fragments per wave
   static constexpr int WSTAGE = BN * 128;
   // weight ring: 3 stages = prefetch distance 1 under the two-group ping-pong (stage (s - 1) % 3 is the partner's, s % 3 this wave's next).
@@ -58,7 +62,7 @@ template <int NF, int WMW> struct HaloLds {
   // epilogue: fp32 staging of 128 rows + the statistics fold
   static constexpr int LDT = BN + 4;
   static constexpr int EPI_FOLD = 128 * LDT * 4;
-  static constexpr int OCP = BN / 8, RL = HB_NT / OCP;
+  static constexpr int OCP = BN / 8, RL = NT / OCP;
   static constexpr int EPI_TOTAL = EPI_FOLD + RL * BN * 8;
   static_assert(EPI_TOTAL <= TOTAL && TOTAL <= 163840, "LDS budget");
 };
@@ -80,10 +84,13 @@ constexpr int hb_wait(int NF, int MFR, int g) {
   return issued_at_wait - 1 - need;
 }
 
-template <int NF, int WMW>
-__global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvArgs p) {
-  typedef HaloLds<NF, WMW> L;
-  constexpr int BN = L::BN, WSTAGE = L::WSTAGE, MFR = L::MFR, NSTG = L::NSTG, PD = L::NSTG - 2;   // PD = prefetch distance of the weight tiles (taps)
+template <int NF, int WMW, int WNW>
+__global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_kernel(const HaloConvArgs p) {
+  typedef HaloLds<NF, WMW, WNW> L;
+  constexpr int BN = L::BN, WSTAGE = L::WSTAGE, MFR = L::MFR, NSTG = L::NSTG, HB_NT = L::NT;
+  constexpr bool PP = L::PP;
+  constexpr int PD = PP ? 1 : 2;                       // prefetch distance of the weight tiles (taps): the ping-pong keeps one stage for the partner group
+  constexpr int NPP = (HB_PATCH / 16 + HB_NT - 1) / HB_NT;   // patch pieces per thread (6 / 3)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave % WMW, wn = wave / WMW;
@@ -129,9 +136,9 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
 
   // ---- per-thread DMA geometry.  Patch piece i of thread t: q = t + 512 i -> patch row q >> 3 (pixel (py, px) of the halo tile),
   // 16-byte slot q & 7 holding source chunk slot ^ (row & 7).  ppix[i] = pixel index in the image tensor, -1 = padding / beyond the patch.
-  int ppix[6];
+  int ppix[NPP];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < NPP; ++i) {
     const int q = t + HB_NT * i, prow = q >> 3;
     const int py = prow / PW, px = prow - py * PW;
     const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
@@ -139,11 +146,12 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
   }
   const int pslot = ((t & 7) ^ ((t >> 3) & 7)) * 8;    // source channel octet of every piece of this thread ((q >> 3) & 7 = (t >> 3) & 7)
   // weight pieces: instruction j = wave + 8 i covers tile rows 8 j .. 8 j + 7
-  constexpr int WI = (BN * 8 + HB_NT - 1) / HB_NT;     // rounds of DMA instructions per weight tile (BN / 8 instructions over 8 waves)
+  constexpr int WI = (BN * 8 + HB_NT - 1) / HB_NT;     // rounds of DMA instructions per weight tile (BN / 8 instructions over the block's waves)
+  constexpr int NWV = HB_NT / 64;
   // (byte offset of this thread's piece of instruction 0 inside the [BN][ldw] weight slab; instruction i is 64 rows further)
   const char* const wslab = (const char*)(p.w + (size_t)n0 * p.ldw);
   const unsigned woff0 = (unsigned)(((t >> 3) * p.ldw + (((t & 7) ^ ((t >> 3) & 7)) * 8)) * 2);
-  const unsigned wstep = (unsigned)(64 * p.ldw * 2);
+  const unsigned wstep = (unsigned)((HB_NT / 8) * p.ldw * 2);
   const char* zp = (const char*)p.zeros;
 
   auto dma = [&](const char* src, int lds_off) {
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     int n = 0;
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      if ((wave + 8 * i) * 64 >= BN * 8) continue;     // wave-uniform (BN / 8 instructions over 8 waves: the last round is the low waves only)
+      if ((wave + NWV * i) * 64 >= BN * 8) continue;   // wave-uniform (BN / 8 instructions over the waves: the last round is the low waves only)
       unsigned off = woff0 + wstep * i;
       asm volatile("" : "+v"(off));
       dma(wslab + koff * 2 + off, st * WSTAGE + (wave * 64 + HB_NT * i) * 16);
@@ -167,7 +175,10 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   };
   // K offset of the weight tile of pipeline step g (-1 outside this block's slice)
   auto koff_of = [&](int g) -> long {
@@ -187,18 +198,20 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     int tt = t; asm volatile("" : "+v"(tt));
     const int pp = (tt + HB_NT * i) >> 3; return (b * p.H + ty0 + (pp >> twsh)) * p.W + tx0 + (pp & (TW - 1));
   };
-  auto issue_coef = [&](const PDesc& d) {
-    if (d.mode != 1 || !p.gn) return;
+  auto issue_coef = [&](const PDesc& d) -> int {        // (all return the number of DMA instructions this wave issued)
+    if (d.mode != 1 || !p.gn) return 0;
     const float* g = ((lane & 16) ? p.beta : p.gamma) + d.ch * 64 + (lane & 15) * 4;
     dma((const char*)g, L::GB + (d.ch & 1) * 1024);
+    return 1;
   };
-  auto issue_piece = [&](const PDesc& d, int pb, const int i) {
-    if (d.mode == 0 || (d.mode == 2 && i >= 4)) return;
-    if (d.mode == 1 && (wave * 64 + HB_NT * i) >= npiece) return;          // wave-uniform: this instruction lies beyond the patch
+  auto issue_piece = [&](const PDesc& d, int pb, const int i) -> int {
+    if (d.mode == 0 || (d.mode == 2 && (wave * 64 + HB_NT * i) >= 2048)) return 0;                 // (shortcut chunk: 2048 pieces = the 256 centre pixels)
+    if (d.mode == 1 && (wave * 64 + HB_NT * i) >= npiece) return 0;        // wave-uniform: this instruction lies beyond the patch
     int pix = d.mode == 1 ? ppix[i] : spix(i);
     asm volatile("" : "+v"(pix));                      // keep the address arithmetic here: hoisted out of the chunk loop it is 40 registers of pointers
     const char* src = pix >= 0 ? (const char*)(d.base + (size_t)pix * d.ld + pslot) : zp;
     dma(src, pb + (wave * 64 + HB_NT * i) * 16);
+    return 1;
   };
 
   // ---- fragment addresses: m-fragment i of this wave = tile pixels wm*64 + 16 i + lr, one tile row (TW = 16) or half a row (TW = 32);
@@ -346,13 +359,13 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     const PDesc d = pdesc(cur);
     issue_coef(d);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_piece(d, L::PATCH0, i);
+    for (int i = 0; i < NPP; ++i) issue_piece(d, L::PATCH0, i);
 #pragma unroll
     for (int d = 0; d < PD; ++d) { const long k0 = koff_of(gstep + d); if (k0 >= 0) issue_w(k0, (gstep + d) % NSTG); }
   }
   if (p.gn && ch_first < nc) {
     // 16 threads per group sum the group's channels' records (integers: exact, any order), then mean / variance in double
-    const int g = t >> 4, sub = t & 15;
+    const int g = t >> 4, sub = t & 15;                // (threads 0 .. 511)
     long long s0 = 0, qh = 0, ql = 0;
     if (g < p.groups) {
       for (int c = g * cpg + sub; c < (g + 1) * cpg; c += 16) {
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     coef_table(cur);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 6; ++i) norm_piece(L::PATCH0, i);
+    for (int i = 0; i < NPP; ++i) norm_piece(L::PATCH0, i);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -398,6 +411,7 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
   // pieces of step s + 1 are confirmed by the barrier in front of mfma(s + 1).  The next chunk's patch is requested in steps 1 / 2 (in
   // step 0 the partner still reads that buffer for step 8 of the previous chunk) and normalised in steps 3 .. 8 by the threads that
   // requested it.
+  if constexpr (PP) {
   const bool grpB = wave >= 4;
   const bool pingpong = cur >= 0 && cur < nc;
 #ifdef DMX_PROBES
@@ -419,6 +433,7 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
       if (!(DBG & 8)) {
         if constexpr (s == 1) { issue_coef(dn); issue_piece(dn, pbn, 0); issue_piece(dn, pbn, 1); issue_piece(dn, pbn, 2); }
         if constexpr (s == 2) { issue_piece(dn, pbn, 3); issue_piece(dn, pbn, 4); issue_piece(dn, pbn, 5); }
+        static_assert(!PP || NPP == 6, "ping-pong schedule: six patch pieces per thread");
       }
       int nw = 0;                                        // (patch pieces first, the weight tile last: the counted wait below leaves only IT in flight)
       if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) nw = issue_w(kn, (g + PD) % NSTG); }
@@ -434,9 +449,8 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
       // ---- MFMA phase.  (The normalisation arithmetic as per-group slices in here - loads in the DMA phase, one element after each
       // MFMA group - was built and measured slower, 65 vs 60 us: one wave per SIMD is in this phase, so VALU between its MFMAs delays them)
       if (active && !(DBG & 1)) mma_post(xa, lds0 + (g % NSTG) * WSTAGE, [&](auto, const int) {});
-      // this wave's pieces of the NEXT tap's weight tile (requested PD DMA phases ago) and everything older have landed; with PD = 2 the
-      // tile requested in this step's DMA phase stays in flight
-      wait_vm(PD >= 2 ? nw : 0);
+      // this wave's pieces of the NEXT tap's weight tile (requested a DMA + an MFMA phase ago) and everything older have landed
+      wait_vm(0); (void)nw;
       HB_STAMP(pa_mma)
       if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
       HB_STAMP(pa_wy)
@@ -461,10 +475,82 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
     mma_pre(xa);
     __builtin_amdgcn_s_barrier();
     mma_post(xa, lds0 + (gstep % NSTG) * WSTAGE, [&](auto, const int) {});
-    wait_vm(PD >= 2 ? nw : 0);                         // (the next shortcut patch, requested before the weight tile, has landed)
+    wait_vm(0); (void)nw;                              // (the next shortcut patch and weight tile have landed)
     __builtin_amdgcn_s_barrier();
     gstep += 1; ++seq;
     cur = next;                                        // (-1 ends the loop)
+  }
+  } else {
+  // ---- K loop, 16-wave instances: LOCK STEP, one barrier per tap, four waves per SIMD (their stalls overlap without choreography).
+  // Step s: [this wave's DMA of step s - 2 and older has landed: counted vmcnt, the requests of step s - 1 stay in flight] [barrier]
+  // [DMA: steps 0 / 1 the next chunk's patch, then the weight tile of tap s + 2 into the stage tap s - 1 has just freed] [step 2: the
+  // next chunk's (a, s) table; steps 3.. : one piece of its normalisation] [MFMA tap s].
+  int n_prev = 0;                                      // DMA instructions this wave issued in the previous step
+  while (cur >= 0 && cur < nc) {
+    const int next = cur < ch_last ? cur + 1 : -1;
+    const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0, pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
+    const PDesc dn = pdesc(next);
+    auto step = [&](auto S_) {
+      constexpr int s = decltype(S_)::value;
+      const int g = gstep + s;
+      const bool active = g >= sb && g < se;
+      wait_vm(n_prev);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+      int n = 0;
+      if (!(DBG & 8)) {
+        constexpr int H0 = (NPP + 1) / 2;              // pieces requested in step 0, the rest in step 1
+        if constexpr (s == 0) { n += issue_coef(dn);
+#pragma unroll
+          for (int i = 0; i < H0; ++i) n += issue_piece(dn, pbn, i); }
+        if constexpr (s == 1) {
+#pragma unroll
+          for (int i = H0; i < NPP; ++i) n += issue_piece(dn, pbn, i); }
+      }
+      if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) n += issue_w(kn, (g + PD) % NSTG); }
+      n_prev = n;
+      // (a thread normalises the pieces it requested itself: those of step 0 / 1 are confirmed by the waits of steps 2 / 3)
+      if constexpr (s == 2) { if (dn.mode == 1) coef_table(next); }
+      if constexpr (s >= 3 && s - 3 < NPP) { if (dn.mode == 1 && !(DBG & 4)) norm_piece(pbn, s - 3); }
+      __builtin_amdgcn_sched_barrier(0);               // (the normalisation's registers are dead before the fragments' come alive: 128 per lane)
+      if (active && !(DBG & 1)) {
+        unsigned xa[MFR];
+        xa_main(pb, (s / 3) * PW + (s % 3), xa);
+        mma_pre(xa);
+        mma_post(xa, lds0 + (g % NSTG) * WSTAGE, [&](auto, const int) {});
+      }
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    gstep += 9; ++seq;
+    cur = next;
+  }
+  // ---- shortcut steps: the next shortcut patch requested one step ahead into the other patch buffer, the weight tile two steps ahead
+  while (cur >= nc) {
+    const int next = cur < ch_last ? cur + 1 : -1;
+    const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0, pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
+    const PDesc dn = pdesc(next);
+    // everything but the weight tile requested in the previous step has landed (its patch request was issued BEFORE it)
+    int nwprev = n_prev; if (nwprev > WI) nwprev = WI;
+    wait_vm(nwprev);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int n = 0, nwt = 0;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) n += issue_piece(dn, pbn, i);
+    { const long kn = koff_of(gstep + PD); if (kn >= 0) nwt = issue_w(kn, (gstep + PD) % NSTG); }
+    n_prev = nwt; (void)n;
+    unsigned xa[MFR];
+    xa_sc(pb, xa);
+    mma_pre(xa);
+    mma_post(xa, lds0 + (gstep % NSTG) * WSTAGE, [&](auto, const int) {});
+    gstep += 1; ++seq;
+    cur = next;                                        // (-1 ends the loop)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // every wave is done with the ring and the patches: LDS is the epilogue's
   }
 #undef HB_DSR
 
@@ -597,10 +683,11 @@ __global__ __launch_bounds__(HB_NT, 2) void dmx_conv_halo_kernel(const HaloConvA
         }
       }
     };
-    if (S == 1) items(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
-    else if (S == 2) items(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
-    else if (S == 4) items(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
-    else items(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+    // (rows in flight per thread: bounded by the register budget - 128 per lane in the 16-wave instances)
+    if (S == 1) items(std::integral_constant<int, 1>{}, std::integral_constant<int, PP ? 3 : 2>{});
+    else if (S == 2) items(std::integral_constant<int, 2>{}, std::integral_constant<int, PP ? 3 : 1>{});
+    else if (S == 4) items(std::integral_constant<int, 4>{}, std::integral_constant<int, PP ? 3 : 1>{});
+    else if constexpr (PP) items(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});      // (8-way splits: 8-wave instances only - the plan sees to it)
   }
   if (TIMING) tm[6] = __builtin_amdgcn_s_memrealtime();
   if (p.colstats) {
@@ -677,9 +764,9 @@ int n_cus() {
 // slabs through memory ((S - 1) / S x 256 x BN x 4 bytes per block, written and read back) and the co-residency of a tile's blocks, so the
 // plan takes the narrow tiles where they make the split unnecessary or smaller; with tiles to spare the wide tile wins (twice the work per
 // weight byte and per barrier).  Costs in us, fitted on scripts/halo_probe.py.
-struct HaloPlan { int TH, TW, nf, wmw, bn, splits; };
+struct HaloPlan { int TH, TW, nf, wmw, bn, splits, waves; };
 HaloPlan halo_plan(const HaloConvArgs& a) {
-  HaloPlan P{0, 0, 0, 0, 0, 0};
+  HaloPlan P{0, 0, 0, 0, 0, 0, 8};
   if (a.W % 32 == 0 && a.H % 8 == 0) { P.TW = 32; P.TH = 8; }
   else if (a.W % 16 == 0 && a.H % 16 == 0) { P.TW = 16; P.TH = 16; }
   else return P;
@@ -702,6 +789,10 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
       if (cost < best) { best = cost; P.nf = cand[c][0]; P.wmw = cand[c][1]; P.bn = bn; P.splits = s; }
     }
   }
+  // the 16-wave lock-step instances of the wide tiles are built, tested and SLOWER than the 8-wave ping-pong (64x64x320, K = 2880 / 5760 /
+  // 8640: 68 / 95 / 130 vs 60 / 87 / 118 us): force_waves = 16 only (tests, A/B)
+  P.waves = (a.force_waves == 16 && P.bn >= 128 && P.splits <= 4) ? 16 : 8;
+  if (a.force_waves == 16 && P.waves != 16) P.splits = 0;
   return P;
 }
 
@@ -742,9 +833,9 @@ size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a) {
   return halo_flag_bytes((int)n) + (size_t)n * 256 * P.bn * sizeof(float);
 }
 
-template <int NF, int WMW> static int halo_launch_(const HaloConvArgs& a, int blocks, hipStream_t stream) {
-  DMX_LDS_OPT_IN((dmx_conv_halo_kernel<NF, WMW>), (HaloLds<NF, WMW>::TOTAL));
-  hipLaunchKernelGGL((dmx_conv_halo_kernel<NF, WMW>), dim3(blocks), dim3(HB_NT), (HaloLds<NF, WMW>::TOTAL), stream, a);
+template <int NF, int WMW, int WNW> static int halo_launch_(const HaloConvArgs& a, int blocks, hipStream_t stream) {
+  DMX_LDS_OPT_IN((dmx_conv_halo_kernel<NF, WMW, WNW>), (HaloLds<NF, WMW, WNW>::TOTAL));
+  hipLaunchKernelGGL((dmx_conv_halo_kernel<NF, WMW, WNW>), dim3(blocks), dim3(HaloLds<NF, WMW, WNW>::NT), (HaloLds<NF, WMW, WNW>::TOTAL), stream, a);
   return dmx_check_launch("dmx_conv_halo_kernel");
 }
 
@@ -779,10 +870,11 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
   char tag[96];
   snprintf(tag, sizeof(tag), "M=%d N=%d K=%d halo gn=%d bn=%d sk=%d", a.B * a.H * a.W, a.N, 9 * a.Cin + a.Csc, a.gn, P.bn, a.splits);
   ProfScope ps(PROF_HALO, stream, flops, bytes, tag);
-  if (P.nf == 5 && P.wmw == 4) return halo_launch_<5, 4>(a, blocks, stream);
-  if (P.nf == 4 && P.wmw == 4) return halo_launch_<4, 4>(a, blocks, stream);
-  if (P.nf == 5 && P.wmw == 8) return halo_launch_<5, 8>(a, blocks, stream);
-  return halo_launch_<4, 8>(a, blocks, stream);
+  if (P.waves == 16) return P.nf == 5 ? halo_launch_<5, 8, 2>(a, blocks, stream) : halo_launch_<4, 8, 2>(a, blocks, stream);
+  if (P.nf == 5 && P.wmw == 4) return halo_launch_<5, 4, 2>(a, blocks, stream);
+  if (P.nf == 4 && P.wmw == 4) return halo_launch_<4, 4, 2>(a, blocks, stream);
+  if (P.nf == 5 && P.wmw == 8) return halo_launch_<5, 8, 1>(a, blocks, stream);
+  return halo_launch_<4, 8, 1>(a, blocks, stream);
 }
 
 int dmx_colstats_launch(const bf16* x, int ldx, int B, int HW, int C, long long* st, hipStream_t stream) {

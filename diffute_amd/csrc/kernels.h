@@ -95,6 +95,7 @@ struct HaloConvArgs {
   long long* colstats;                               // DmxStat records of the OUTPUT [B][N][4], added to (zero before the launch), or null
   int force_split;                                   // 0 = automatic K split (1 / 2 / 4 / 8 blocks per tile)
   int force_bn;                                      // 0 = automatic column tile (160 / 128 / 80 / 64)
+  int force_waves;                                   // 0 = automatic; 8 / 16 waves per block (16: the 160 / 128-column tiles only)
   int dbg; long long* timing;                        // measurement aids (0 / null in the product path)
   // filled by the launcher
   int TH, TW, splits, xcd_tile_major; float* slabs; int* flags; const bf16* zeros;

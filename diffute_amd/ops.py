@@ -311,7 +311,7 @@ def colstats(x):
 
 
 def conv3x3_gn(x0, w, N, *, x1=None, gn=None, st0=None, st1=None, sc0=None, sc1=None, bias=None, rowbias=None, res=None,
-               out_stats=False, force_split=0, force_bn=0, timing=None, dbg=0):
+               out_stats=False, force_split=0, force_bn=0, force_waves=0, timing=None, dbg=0):
     """conv3x3 (stride 1, pad 1) over a halo tile staged in LDS, with GroupNorm(+SiLU) applied to the staged tile in place
     (dmx_conv3x3_gn).  gn = (gamma, beta, groups, eps, silu) with st0 / st1 the statistics records of x0 / x1, or None for a plain
     conv.  Returns out, or (out, records of out) with out_stats."""
@@ -344,7 +344,7 @@ def conv3x3_gn(x0, w, N, *, x1=None, gn=None, st0=None, st1=None, sc0=None, sc1=
     if out_stats:
         cst = torch.zeros(B, N, 4, dtype=torch.int64, device=x0.device)
         d.colstats = cst.data_ptr()
-    d.force_split = force_split; d.force_bn = force_bn; d.dbg = dbg
+    d.force_split = force_split; d.force_bn = force_bn; d.force_waves = force_waves; d.dbg = dbg
     if timing is not None:
         d.timing = timing.data_ptr()
     if not lib().dmx_conv3x3_gn_supported(ctypes.byref(d)):

@@ -172,6 +172,7 @@ typedef struct dmx_halo_conv_desc {
   long long* colstats;
   int force_split;                  /* 0 = automatic; 1 / 2 / 4 / 8 blocks share the K range of a tile (tests, tuning) */
   int force_bn;                     /* 0 = automatic; 160 / 128 / 80 / 64 output columns per block (tests, tuning) */
+  int force_waves;                  /* 0 = automatic; 8 / 16 waves per block (16: the 160 / 128-column tiles) */
   int dbg; long long* timing;       /* measurement aids, 0 / NULL */
 } dmx_halo_conv_desc;
 int dmx_conv3x3_gn_supported(const dmx_halo_conv_desc* d);

@@ -1,5 +1,5 @@
 """A/B of a library switch inside ONE process and on one box: alternating timed 50-step passes with the switch on / off.
-    python scripts/ab_pass.py gn_stats|xf_chain [--rounds 4]"""
+    python scripts/ab_pass.py gn_stats|xf_chain|temb_table|halo|halo_all [--rounds 4] [--batch 4]"""
 import sys
 import time
 
@@ -29,6 +29,10 @@ def setting(on):
     elif what == "temb_table":
         import diffute_amd.pipeline as P
         P.TEMB_TABLE = bool(on)
+    elif what == "halo":
+        lib.dmx_set_halo_conv(1 if on else 0)         # 1: the fused GroupNorm -> conv launch where it pays (the default)
+    elif what == "halo_all":
+        lib.dmx_set_halo_conv(2 if on else 1)         # 2: wherever the kernel takes the problem vs the default rule
     elif what == "xf_chain":
         lib.dmx_set_xf_chain(2 if on else 0)          # 2: at every supported size (the executor's own rule needs >= 192 row blocks)
     for sl in unet._slots.values():

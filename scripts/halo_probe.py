@@ -6,7 +6,7 @@ import torch
 from diffute_amd import ops
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=30); ap.add_argument("--split", type=int, default=0); ap.add_argument("--bn", type=int, default=0)
+    ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=30); ap.add_argument("--split", type=int, default=0); ap.add_argument("--bn", type=int, default=0); ap.add_argument("--waves", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     shapes = [  # B, H, W, C0, C1, N, Csc
@@ -27,7 +27,7 @@ def main():
         g = torch.ones(Cin, device=dev); be = torch.zeros(Cin, device=dev)
         st0 = ops.colstats(x0); st1 = ops.colstats(x1) if C1 else None
         def halo(i):
-            return ops.conv3x3_gn(x0, ws[i % 4], N, x1=x1, gn=(g, be, 32, 1e-5, True), st0=st0, st1=st1, sc0=sc, bias=b, rowbias=te, res=r, out_stats=True, force_split=a.split, force_bn=a.bn)
+            return ops.conv3x3_gn(x0, ws[i % 4], N, x1=x1, gn=(g, be, 32, 1e-5, True), st0=st0, st1=st1, sc0=sc, bias=b, rowbias=te, res=r, out_stats=True, force_split=a.split, force_bn=a.bn, force_waves=a.waves)
         def old(i):
             t = ops.groupnorm(x0, g, be, 32, 1e-5, True, x1=x1)
             return ops.conv_gemm(t, ws[i % 4], N, sc0=sc, bias=b, rowbias=te, res=r)

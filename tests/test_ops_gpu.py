@@ -627,6 +627,13 @@ HALO_CASES = [
     ("gn_16x16_w80_split4", 1, 16, 16, 640, 0, 320, 0, 0, True, 4, 80),
     ("gn_n128_w64_vae", 1, 32, 32, 128, 0, 128, 128, 0, True, 1, 64),
     ("gn_16x16_w64_split8", 1, 16, 16, 640, 640, 128, 0, 0, True, 8, 64),
+    # the 16-wave lock-step instances (160 / 128 columns, splits 1 / 2 / 4) and the 8-wave ping-pong instances of the same tiles
+    ("gn_64x64_320_16w_split2", 2, 64, 64, 320, 0, 320, 0, 0, True, 2, 160, 16),
+    ("gn_32x32_concat_sc_16w_split4", 1, 32, 32, 640, 320, 320, 640, 320, True, 4, 160, 16),
+    ("gn_32x32_16w_split1", 1, 32, 32, 320, 0, 320, 320, 0, True, 1, 160, 16),
+    ("gn_n128_16w_vae", 1, 64, 64, 128, 0, 256, 128, 0, True, 0, 128, 16),
+    ("gn_64x64_320_8w_split2", 2, 64, 64, 320, 0, 320, 0, 0, True, 2, 160, 8),
+    ("plain_16w_sc_only", 1, 16, 32, 64, 64, 160, 64, 64, False, 2, 160, 16),
     ("gn_64x64_320", 2, 64, 64, 320, 0, 320, 0, 0, True, 0),
     ("gn_32x32_concat_sc", 2, 32, 32, 640, 320, 640, 640, 320, True, 0),
     ("gn_16x16_1280", 2, 16, 16, 640, 0, 1280, 0, 0, True, 0),
@@ -650,6 +657,7 @@ def test_conv3x3_gn_halo(cuda, case):
     from diffute_amd import ops
     name, B, H, W, C0, C1, N, S0, S1, gn, split = case[:11]
     bn = case[11] if len(case) > 11 else 0
+    waves = case[12] if len(case) > 12 else 0
     x0 = bf(seeded((B, C0, H, W), 1) * 1.5 + 0.3)
     x1 = bf(seeded((B, C1, H, W), 2) * 0.5 - 1.0) if C1 else None
     x = x0 if x1 is None else torch.cat([x0, x1], 1)
@@ -663,7 +671,7 @@ def test_conv3x3_gn_halo(cuda, case):
     g = 1 + 0.1 * seeded((Cin,), 10); be = 0.1 * seeded((Cin,), 11)
     ref = _halo_ref(x, w, b, gn=(g, be, 1e-5, True) if gn else None, sc=sc, wsc=wsc, temb=temb, res=None if S0 else r)
     X0 = nhwc(x0, cuda); X1 = None if x1 is None else nhwc(x1, cuda)
-    kw = dict(x1=X1, bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(), force_split=split, force_bn=bn, out_stats=True)
+    kw = dict(x1=X1, bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(), force_split=split, force_bn=bn, force_waves=waves, out_stats=True)
     if gn:
         kw.update(gn=(g.to(cuda), be.to(cuda), 32, 1e-5, True), st0=ops.colstats(X0), st1=None if X1 is None else ops.colstats(X1))
     if S0:
