@@ -36,6 +36,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 namespace {
 
+// x / d for x < 2^20, 2 <= d < 2^12 with magic = 2^32 / d + 1; d = 1: magic 0 (host: halo_magic)
+__device__ __forceinline__ int hb_div(int x, unsigned magic) { return magic ? (int)(((unsigned long long)(unsigned)x * magic) >> 32) : x; }
+static unsigned halo_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1); }
+
 constexpr int HB_PATCH = 44032;            // patch buffer: 2752 pieces of 16 B (340 rows of 128 B, rounded up to whole 1-KB DMA instructions)
 
 // WMW = waves along the pixel axis: 4 -> 4 x 2 waves of 64-pixel x 16 NF-channel tiles (BN = 32 NF = 160 / 128 columns),
@@ -107,21 +111,27 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   constexpr long long* TIMING = nullptr;
 #endif
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // 100 MHz ticks at the phase boundaries
+  long long tp[4] = {0, 0, 0, 0};                      // ... inside the prologue: requests issued, statistics done, patch landed + barrier
   if (TIMING) tm[0] = __builtin_amdgcn_s_memrealtime();
 
   // ---- work item: (n-tile, K slice) combos are dealt XCD-contiguously, pixel tiles inside a combo: the blocks resident on one XCD
   // stream the SAME weight slice (the large operand of the deep levels) through that XCD's L2
   const int TW = p.TW, TH = p.TH, PW = TW + 2;
-  const int tiles_x = p.W / TW, tiles_img = tiles_x * (p.H / TH);
-  const int tiles_m = p.B * tiles_img, S = p.splits;
+  const int tiles_x = p.tiles_x, tiles_img = p.tiles_img;
+  const int tiles_m = p.tiles_m, S = p.splits;
+  const int sshift = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : 3;
   const int nb = gridDim.x;
   const int Lb = ((nb & 7) == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const int ncombo = (p.N / BN) * S;
+  const int ncombo = p.ncombo;
   // (xcd_tile_major: pixel tiles XCD-contiguous, their column tiles / K slices inside - the blocks of an XCD share the ACTIVATION tiles)
-  const int combo = p.xcd_tile_major ? Lb % ncombo : Lb / tiles_m, tile_m = p.xcd_tile_major ? Lb / ncombo : Lb - combo * tiles_m;
-  const int tile_n = combo / S, r = combo - tile_n * S;
-  const int b = tile_m / tiles_img, ti = tile_m - b * tiles_img;
-  const int ty0 = (ti / tiles_x) * TH, tx0 = (ti % tiles_x) * TW;
+  // (no integer divisions in the block decode: hb_div with the host's magic numbers - a scalar division is ~25 instructions through
+  // the vector unit, and a dozen of them sat in front of the first DMA request)
+  const int q_nc = hb_div(Lb, p.mg_ncombo), q_tm = hb_div(Lb, p.mg_tiles_m);
+  const int combo = p.xcd_tile_major ? Lb - q_nc * ncombo : q_tm, tile_m = p.xcd_tile_major ? q_nc : Lb - q_tm * tiles_m;
+  const int tile_n = combo >> sshift, r = combo & (S - 1);
+  const int b = hb_div(tile_m, p.mg_tiles_img), ti = tile_m - b * tiles_img;
+  const int tyq = hb_div(ti, p.mg_tiles_x);
+  const int ty0 = tyq * TH, tx0 = (ti - tyq * tiles_x) * TW;
   const int n0 = tile_n * BN;
   const int twsh = (TW == 32) ? 5 : 4;                 // TW is 16 or 32
   const int nprow = (TH + 2) * PW, npiece = nprow * 8;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   // ---- K steps: main chunk c = steps [9c, 9c + 9) (tap = step % 9), then one step per 64 shortcut channels.  Slice r = steps [sb, se):
   // a chunk cut by a boundary runs its nine pipeline steps in both blocks, each with the MFMA phases of its own taps only.
   const int nc = p.Cin >> 6, nsc = p.Csc >> 6, T = 9 * nc + nsc;
-  auto bnd = [&](int q) { int v = (int)((long long)T * q / S); if (v < 9 * nc) v = (v + 1) / 3 * 3; return v; };
+  auto bnd = [&](int q) { int v = (T * q) >> sshift; if (v < 9 * nc) v = (v + 1) / 3 * 3; return v; };
   const int sb = bnd(r), se = bnd(r + 1);
   const int ch_first = sb < 9 * nc ? sb / 9 : nc + (sb - 9 * nc);         // chunk ids: 0 .. nc-1 main, nc + j shortcut
   const int ch_last = (se - 1) < 9 * nc ? (se - 1) / 9 : nc + (se - 1 - 9 * nc);
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #pragma unroll
   for (int i = 0; i < NPP; ++i) {
     const int q = t + HB_NT * i, prow = q >> 3;
-    const int py = prow / PW, px = prow - py * PW;
+    const int py = hb_div(prow, p.mg_pw), px = prow - py * PW;
     const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
     ppix[i] = (q < npiece && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (b * p.H + iy) * p.W + ix : -1;
   }
@@ -304,11 +314,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   // ---- GroupNorm pieces
   // (a, s) of the 64 channels of main chunk `ch` from the group statistics and the chunk's gamma | beta slot; every wave writes the
   // same 64 entries (no divergence, no extra barrier)
-  const int cpg = p.gn ? p.Cin / p.groups : 1;
+  const int cpg = p.cpg;
   auto coef_table = [&](int ch) {
     if (!p.gn) return;
     const int c = ch * 64 + lane;
-    const int g = c / cpg;
+    const int g = hb_div(c, p.mg_cpg);
     const float* gb = (const float*)(smem + L::GB + (ch & 1) * 1024);
     const float* gs = (const float*)(smem + L::GST);
     const float a = gs[2 * g + 1] * gb[lane];
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #pragma unroll
     for (int d = 0; d < PD; ++d) { const long k0 = koff_of(gstep + d); if (k0 >= 0) issue_w(k0, (gstep + d) % NSTG); }
   }
+  if (TIMING) tp[0] = __builtin_amdgcn_s_memrealtime();
   if (p.gn && ch_first < nc) {
     // 16 threads per group sum the group's channels' records (integers: exact, any order), then mean / variance in double
     const int g = t >> 4, sub = t & 15;                // (threads 0 .. 511)
@@ -387,14 +398,37 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
       gs[2 * g] = (float)mean; gs[2 * g + 1] = rsqrtf((float)var + p.eps);
     }
   }
+  if (TIMING) tp[1] = __builtin_amdgcn_s_memrealtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                        // the group statistics are published (the patch pieces a thread normalises are its own)
+  if (TIMING) tp[2] = __builtin_amdgcn_s_memrealtime();
   if (cur < nc && p.gn) {
     coef_table(cur);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      u32x4 px[NPP];
 #pragma unroll
-    for (int i = 0; i < NPP; ++i) norm_piece(L::PATCH0, i);
+      for (int i = 0; i < NPP; ++i) { const int q = t + HB_NT * i; px[i] = *(const u32x4*)(smem + L::PATCH0 + (q >= npiece ? 0 : q) * 16); }
+      const float* cf = (const float*)(smem + L::COEF) + pslot * 2;
+      f32x4 cc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cc[k] = *(const f32x4*)(cf + 4 * k);
+#pragma unroll
+      for (int i = 0; i < NPP; ++i) {
+        const int q = t + HB_NT * i;
+        float f[8]; unpack_bf8(px[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float y = __builtin_fmaf(f[e], cc[e >> 1][(e & 1) * 2], cc[e >> 1][(e & 1) * 2 + 1]);
+          if (p.silu) y *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * y));
+          f[e] = y;
+        }
+        u32x4 o = pack_bf8(f);
+        if (ppix[i] < 0) o = u32x4{0u, 0u, 0u, 0u};
+        if (q < npiece) *(u32x4*)(smem + L::PATCH0 + q * 16) = o;
+      }
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -411,15 +445,15 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   // pieces of step s + 1 are confirmed by the barrier in front of mfma(s + 1).  The next chunk's patch is requested in steps 1 / 2 (in
   // step 0 the partner still reads that buffer for step 8 of the previous chunk) and normalised in steps 3 .. 8 by the threads that
   // requested it.
-  if constexpr (PP) {
-  const bool grpB = wave >= 4;
-  const bool pingpong = cur >= 0 && cur < nc;
 #ifdef DMX_PROBES
   long long pa_dma = 0, pa_wx = 0, pa_mma = 0, pa_wy = 0, pa_t = __builtin_amdgcn_s_memtime();   // shader cycles in: DMA phase, barrier X, MFMA phase, barrier Y
 #define HB_STAMP(acc_) { const long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - pa_t; pa_t = n_; }
 #else
 #define HB_STAMP(acc_)
 #endif
+  if constexpr (PP) {
+  const bool grpB = wave >= 4;
+  const bool pingpong = cur >= 0 && cur < nc;
   if (pingpong && grpB) __builtin_amdgcn_s_barrier();
   while (cur >= 0 && cur < nc) {
     const int next = cur < ch_last ? cur + 1 : -1;
@@ -595,10 +629,70 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   float cs_s[8], cs_q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
-  const int RPP = RO < 128 ? RO : 128, passes = RO / RPP;
-  for (int ep = 0; ep < passes; ++ep) {
-    const int prow0 = own0 + ep * RPP;                 // first tile pixel of this pass
-    if (ep) __builtin_amdgcn_s_barrier();              // the previous pass is done with the staging tile
+  const int RPP = RO < 128 ? RO : 128, passes = RO / RPP;    // (S = 1: two passes of 128 rows; S > 1: one pass of 256 / S rows)
+  // items of one pass: (row lane rl, octet o), the octet fixed per thread so the column partial sums stay in registers; U rows per
+  // thread in flight (loads of the residual and of the peers' slabs first, then the arithmetic and the stores)
+  auto items = [&](auto S_, auto U_, const int prow0) {
+    constexpr int SS = decltype(S_)::value, U = decltype(U_)::value;
+    for (int k0 = 0; k0 * RL < RPP; k0 += U) {
+      u32x4 rr[U]; f32x4 pv[U][SS][2];                 // (indexed by slice: entry r stays unused - static register indices)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int row = rl + RL * (k0 + u); if (row >= RPP) row = RPP - 1;
+        const int pp = prow0 + row;
+        const size_t pix = (size_t)(b * p.H + ty0 + (pp >> twsh)) * p.W + tx0 + (pp & (TW - 1));
+        if (p.res) rr[u] = *(const u32x4*)(p.res + pix * p.ldres + n0 + o * 8);
+        if constexpr (SS > 1) {
+#pragma unroll
+          for (int s = 0; s < SS; ++s) {
+            if (s == r) continue;
+            // sc1 loads of the write-through slabs: served by L2 / the fabric, no agent-scope acquire needed (gemm.hip stream-K)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slabs + (tile_slot + s) * slab_elems), 0, (int)(slab_elems * 4), 0x00020000);
+            const int off = (pp * BN + o * 8) * 4;
+            pv[u][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+            pv[u][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16));
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = rl + RL * (k0 + u);
+        if (!act || row >= RPP) continue;
+        const int pp = prow0 + row;
+        const size_t pix = (size_t)(b * p.H + ty0 + (pp >> twsh)) * p.W + tx0 + (pp & (TW - 1));
+        const f32x4 m0 = *(const f32x4*)(tile + row * LDT + o * 8), m1 = *(const f32x4*)(tile + row * LDT + o * 8 + 4);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        // K order: slice 0, 1, ... (this block's own part sits at position r)
+#pragma unroll
+        for (int s = 0; s < SS; ++s) {
+          if (s == r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += m0[e]; v[4 + e] += m1[e]; }
+          } else if constexpr (SS > 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += pv[u][s][0][e]; v[4 + e] += pv[u][s][1][e]; }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bs[e];
+        if (p.res) {
+          float rf[8]; unpack_bf8(rr[u], rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rf[e];
+        }
+        const u32x4 pk = pack_bf8(v);
+        *(u32x4*)(p.out + pix * p.ldo + n0 + o * 8) = pk;
+        if (p.colstats) {
+          float f[8]; unpack_bf8(pk, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { cs_s[e] += f[e]; cs_q[e] += f[e] * f[e]; }
+        }
+      }
+    }
+  };
+  auto stage = [&](const int prow0) {
 #pragma unroll
     for (int i = 0; i < MFR; ++i) {
       const int row0 = wm * (16 * MFR) + i * 16;
@@ -606,7 +700,21 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #pragma unroll
       for (int j = 0; j < NF; ++j) *(f32x4*)(tile + (row0 - prow0 + lr) * LDT + wn * 16 * NF + j * 16 + 4 * lq) = acc[j][i];
     }
-    if (S > 1 && ep == 0 && t == 0) {
+  };
+  constexpr int KPP = (128 + RL - 1) / RL;             // rows per thread of a 128-row pass
+  if (S == 1) {
+    for (int ep = 0; ep < passes; ++ep) {
+      if (ep) __builtin_amdgcn_s_barrier();            // the previous pass is done with the staging tile
+      stage(own0 + ep * RPP);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (TIMING && ep == 0) tm[4] = __builtin_amdgcn_s_memrealtime();
+      items(std::integral_constant<int, 1>{}, std::integral_constant<int, PP ? 3 : 2>{}, own0 + ep * RPP);
+    }
+  } else {
+    // one pass: after the staging the accumulators are dead, so every row of a thread is in flight at once (8-wave instances)
+    stage(own0);
+    if (t == 0) {
       // peers' slabs: bounded spin (a lost peer must never hang the GPU: after ~40 ms the block goes on with what is there)
       const long long t0 = __builtin_amdgcn_s_memrealtime();
       for (int s = 0; s < S; ++s) {
@@ -619,75 +727,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (TIMING && ep == 0) tm[4] = __builtin_amdgcn_s_memrealtime();
-    // items: (row lane rl, octet o), the octet fixed per thread so the column partial sums stay in registers.  (Requesting the residual
-    // rows of both passes up front and every load of a pass before its first store was measured: slower - 67.7 vs 60.0 us - the extra
-    // live registers spill next to the accumulators)
-    auto items = [&](auto S_, auto U_) {
-      constexpr int SS = decltype(S_)::value, U = decltype(U_)::value;
-      for (int k0 = 0; k0 * RL < RPP; k0 += U) {
-        u32x4 rr[U]; f32x4 pv[U][SS][2];               // (indexed by slice: entry r stays unused - static register indices)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          int row = rl + RL * (k0 + u); if (row >= RPP) row = RPP - 1;
-          const int pp = prow0 + row;
-          const size_t pix = (size_t)(b * p.H + ty0 + (pp >> twsh)) * p.W + tx0 + (pp & (TW - 1));
-          if (p.res) rr[u] = *(const u32x4*)(p.res + pix * p.ldres + n0 + o * 8);
-          if constexpr (SS > 1) {
-#pragma unroll
-            for (int s = 0; s < SS; ++s) {
-              if (s == r) continue;
-              // sc1 loads of the write-through slabs: served by L2 / the fabric, no agent-scope acquire needed (gemm.hip stream-K)
-              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slabs + (tile_slot + s) * slab_elems), 0, (int)(slab_elems * 4), 0x00020000);
-              const int off = (pp * BN + o * 8) * 4;
-              pv[u][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
-              pv[u][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16));
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int row = rl + RL * (k0 + u);
-          if (!act || row >= RPP) continue;
-          const int pp = prow0 + row;
-          const size_t pix = (size_t)(b * p.H + ty0 + (pp >> twsh)) * p.W + tx0 + (pp & (TW - 1));
-          const f32x4 m0 = *(const f32x4*)(tile + row * LDT + o * 8), m1 = *(const f32x4*)(tile + row * LDT + o * 8 + 4);
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = 0.f;
-          // K order: slice 0, 1, ... (this block's own part sits at position r)
-#pragma unroll
-          for (int s = 0; s < SS; ++s) {
-            if (s == r) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] += m0[e]; v[4 + e] += m1[e]; }
-            } else if constexpr (SS > 1) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] += pv[u][s][0][e]; v[4 + e] += pv[u][s][1][e]; }
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bs[e];
-          if (p.res) {
-            float rf[8]; unpack_bf8(rr[u], rf);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rf[e];
-          }
-          const u32x4 pk = pack_bf8(v);
-          *(u32x4*)(p.out + pix * p.ldo + n0 + o * 8) = pk;
-          if (p.colstats) {
-            float f[8]; unpack_bf8(pk, f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { cs_s[e] += f[e]; cs_q[e] += f[e] * f[e]; }
-          }
-        }
-      }
-    };
-    // (rows in flight per thread: bounded by the register budget - 128 per lane in the 16-wave instances)
-    if (S == 1) items(std::integral_constant<int, 1>{}, std::integral_constant<int, PP ? 3 : 2>{});
-    else if (S == 2) items(std::integral_constant<int, 2>{}, std::integral_constant<int, PP ? 3 : 1>{});
-    else if (S == 4) items(std::integral_constant<int, 4>{}, std::integral_constant<int, PP ? 3 : 1>{});
-    else if constexpr (PP) items(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});      // (8-way splits: 8-wave instances only - the plan sees to it)
+    if (TIMING) tm[4] = __builtin_amdgcn_s_memrealtime();
+    if (S == 2) items(std::integral_constant<int, 2>{}, std::integral_constant<int, PP ? KPP : 1>{}, own0);
+    else if (S == 4) items(std::integral_constant<int, 4>{}, std::integral_constant<int, PP ? (KPP + 1) / 2 : 1>{}, own0);
+    else if constexpr (PP) items(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, own0);      // (8-way splits: 8-wave instances only - the plan sees to it)
   }
   if (TIMING) tm[6] = __builtin_amdgcn_s_memrealtime();
   if (p.colstats) {
@@ -699,16 +742,21 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
       for (int e = 0; e < 8; ++e) { red[(rl * BN + o * 8 + e) * 2] = cs_s[e]; red[(rl * BN + o * 8 + e) * 2 + 1] = cs_q[e]; }
     }
     __syncthreads();
-    for (int c = t; c < BN; c += HB_NT) {
+    {
+      // channel c is folded by FT adjacent lanes (row lanes k = part, part + FT, ...; fixed order inside a lane, then a fixed shuffle tree)
+      constexpr int FT = (HB_NT / BN) >= 2 ? 2 : 1;
+      const int c = t / FT, part = t % FT;
       float sa = 0.f, sq = 0.f;
-      for (int k = 0; k < RL; ++k) { sa += red[(k * BN + c) * 2]; sq += red[(k * BN + c) * 2 + 1]; }
-      dmx_stat_add(p.colstats + ((size_t)b * p.N + n0 + c) * DMX_STAT_WORDS, sa, sq);
+      if (c < BN)
+        for (int k = part; k < RL; k += FT) { sa += red[(k * BN + c) * 2]; sq += red[(k * BN + c) * 2 + 1]; }
+      if (FT == 2) { sa += __shfl_xor(sa, 1); sq += __shfl_xor(sq, 1); }
+      if (c < BN && part == 0) dmx_stat_add(p.colstats + ((size_t)b * p.N + n0 + c) * DMX_STAT_WORDS, sa, sq);
     }
   }
 #ifdef DMX_PROBES
   if (TIMING && (t == 0 || t == 256)) {                // phase sums of wave 0 (group A) and wave 4 (group B), behind the 4096 block records
     long long* o2 = TIMING + (size_t)(4096 + blockIdx.x * 2 + (t >> 8)) * 8;
-    o2[0] = pa_dma; o2[1] = pa_wx; o2[2] = pa_mma; o2[3] = pa_wy; o2[4] = gstep;
+    o2[0] = pa_dma; o2[1] = pa_wx; o2[2] = pa_mma; o2[3] = pa_wy; o2[4] = gstep; o2[5] = tp[0]; o2[6] = tp[1]; o2[7] = tp[2];
   }
 #endif
   if (TIMING && t == 0) {
@@ -852,6 +900,11 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
   const HaloPlan P = halo_plan(a);
   a.TH = P.TH; a.TW = P.TW; a.splits = P.splits;
   const int blocks = (int)halo_blocks(a, P);
+  a.tiles_x = a.W / P.TW; a.tiles_img = a.tiles_x * (a.H / P.TH); a.tiles_m = a.B * a.tiles_img; a.ncombo = (a.N / P.bn) * P.splits;
+  a.cpg = a.gn ? a.Cin / a.groups : 1;
+  DMX_REQUIRE(blocks < (1 << 20) && a.Cin < (1 << 20), "conv_halo: problem too large for the block decode (%d blocks)", blocks);
+  a.mg_tiles_x = halo_magic(a.tiles_x); a.mg_tiles_img = halo_magic(a.tiles_img); a.mg_tiles_m = halo_magic(a.tiles_m);
+  a.mg_ncombo = halo_magic(a.ncombo); a.mg_pw = halo_magic(P.TW + 2); a.mg_cpg = halo_magic(a.cpg);
   // block -> XCD dealing: weights-major when the weight slab is the larger stream of an XCD, pixel-tile-major otherwise
   {
     const double wbytes = 2.0 * a.N * (9.0 * a.Cin + a.Csc), abytes = 2.0 * a.B * a.H * a.W * (double)(a.Cin + a.Csc) * 1.33;

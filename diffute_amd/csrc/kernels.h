@@ -99,6 +99,9 @@ struct HaloConvArgs {
   int dbg; long long* timing;                        // measurement aids (0 / null in the product path)
   // filled by the launcher
   int TH, TW, splits, xcd_tile_major; float* slabs; int* flags; const bf16* zeros;
+  // (the block decode of the kernel without integer divisions: x / d = (x * magic) >> 32 for the dividends that occur, all < 2^20)
+  int tiles_x, tiles_img, tiles_m, ncombo, cpg;
+  unsigned mg_tiles_x, mg_tiles_img, mg_tiles_m, mg_ncombo, mg_pw, mg_cpg;
 };
 bool dmx_conv_halo_supported(const HaloConvArgs& a);
 bool dmx_conv_halo_pays(const HaloConvArgs& a);        // supported AND at least as fast in situ as GroupNorm + implicit-GEMM conv (what the executors ask)

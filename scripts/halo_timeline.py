@@ -25,7 +25,8 @@ for i in range(3): ops.conv3x3_gn(x0, w, N, **kw)
 ops.conv3x3_gn(x0, w, N, timing=tm, **kw)
 torch.cuda.synchronize()
 tall = tm.cpu()
-ph = tall[4096:].reshape(-1, 2, 8)[: , :, :5].double()
+ph8 = tall[4096:].reshape(-1, 2, 8)
+ph = ph8[:, :, :5].double()
 t = tall[:4096]
 t = t[t[:, 0] > 0]
 ph = ph[: len(t)]
@@ -40,6 +41,8 @@ t0 = t[:, 0].min()
 t = t[:, [0, 1, 2, 3, 4, 6, 5, 7]]          # (stamp 6 = items done, before the statistics fold; 5 = end)
 us = (t[:, :7] - t0).double() / 100.0
 print(f"{len(t)} blocks; steps per block {sorted(set(t[:, 7].tolist()))}")
+pro = (ph8[: len(t), 0, 5:8] - t[:, 0:1]).double() / 100.0
+print("  prologue (us from block start, mean): requests issued %.2f  statistics done %.2f  patch landed + barrier %.2f" % tuple(pro.mean(0).tolist()))
 names = ["start", "prologue done", "K loop done", "published", "peers arrived", "items done", "end"]
 for i, n in enumerate(names):
     print(f"  {n:15s}: mean {us[:, i].mean():7.2f}  min {us[:, i].min():7.2f}  max {us[:, i].max():7.2f} us")
