@@ -53,7 +53,12 @@ template <int NF, int WMW, int WNW> struct HaloLds {
   static constexpr bool PP = (WMW * WNW == 8);        // two-group ping-pong (8 waves) / lock step (16 waves)
   static constexpr int BN = WNW * 16 * NF;
   static constexpr int MFR = 16 / WMW;                // 16-pixel fragments per wave
-  static constexpr int WSTAGE = BN * 128;
+  // TPS = taps per pipeline step: the narrow tiles have the LDS for TWO weight tiles per ring stage (2 x 10 KB = one stage of the
+  // 160-column tile): per step the same DMA / MFMA work as the wide tile with half the barriers, DMA-phase overheads and
+  // normalisation slots per FLOP - and twice the tiles, i.e. no K split (no fp32 slab exchange) at the 64 x 64 level
+  static constexpr int TPS = (WMW == 8 && WNW == 1) ? 2 : 1;
+  static constexpr int WTILE = BN * 128;              // one tap's [BN][64] weight tile
+  static constexpr int WSTAGE = TPS * WTILE;
   // weight ring: 3 stages = prefetch distance 1 under the two-group ping-pong (stage (s - 1) % 3 is the partner's, s % 3 this wave's next).
   // A 4-stage ring / distance 2 with a counted vmcnt was built for the tiles that have the LDS for it and measured SLOWER (64x64x320,
   // 80 columns: 72 vs 62 us): what bounds a step is each wave's serial non-MFMA work, not the landing time of the tile (EXPERIMENTS.md)
@@ -71,27 +76,34 @@ template <int NF, int WMW, int WNW> struct HaloLds {
   static_assert(EPI_TOTAL <= TOTAL && TOTAL <= 163840, "LDS budget");
 };
 
-// lgkmcnt of the wait in front of MFMA group g of the hand-scheduled tap (see mma_post): reads issued so far minus the position of
-// the last read the group needs.  Issue order: X0[0 .. MFR), W[0], W[1], then in front of group g: X1[g] (g < MFR), W[g + 2].
-constexpr int hb_wait(int NF, int MFR, int g) {
-  int pos = MFR + 2, posW[16] = {}, posX1[4] = {};
+// lgkmcnt of the wait in front of MFMA group g of the hand-scheduled stream of TAPS taps (see mma_stream): reads issued so far minus the
+// position of the last read the group needs.  Group g = (tap t, k-step kk, weight fragment j), gl = g % (2 NF).  Issue order:
+// X0(tap 0)[0 .. MFR) before the barrier, W[0], W[1], then in front of group g: X1(t)[gl] (gl < MFR), X0(t + 1)[gl - NF]
+// (NF <= gl < NF + MFR, not the last tap), W[g + 2].
+constexpr int hb_wait(int NF, int MFR, int TAPS, int g) {
+  const int G = TAPS * 2 * NF;
+  int pos = MFR + 2, posW[48] = {}, posX0[4][4] = {}, posX1[4][4] = {};
+  for (int i = 0; i < MFR; ++i) posX0[0][i] = i;
   posW[0] = MFR; posW[1] = MFR + 1;
   int issued_at_wait = 0;
-  for (int q = 0; q < 2 * NF; ++q) {
+  for (int q = 0; q < G; ++q) {
+    const int t = q / (2 * NF), gl = q - t * 2 * NF;
     if (q == g) issued_at_wait = pos;
-    if (q < MFR) posX1[q] = pos++;
-    if (q + 2 < 2 * NF) posW[q + 2] = pos++;
+    if (gl < MFR) posX1[t][gl] = pos++;
+    if (t + 1 < TAPS && gl >= NF && gl < NF + MFR) posX0[t + 1][gl - NF] = pos++;
+    if (q + 2 < G) posW[q + 2] = pos++;
   }
+  const int t = g / (2 * NF), gl = g - t * 2 * NF;
   int need = posW[g];
-  if (g == 0 && MFR - 1 > need) need = MFR - 1;
-  if (g == NF && posX1[MFR - 1] > need) need = posX1[MFR - 1];
+  if (gl == 0 && posX0[t][MFR - 1] > need) need = posX0[t][MFR - 1];
+  if (gl == NF && posX1[t][MFR - 1] > need) need = posX1[t][MFR - 1];
   return issued_at_wait - 1 - need;
 }
 
 template <int NF, int WMW, int WNW>
 __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_kernel(const HaloConvArgs p) {
   typedef HaloLds<NF, WMW, WNW> L;
-  constexpr int BN = L::BN, WSTAGE = L::WSTAGE, MFR = L::MFR, NSTG = L::NSTG, HB_NT = L::NT;
+  constexpr int BN = L::BN, WSTAGE = L::WSTAGE, WTILE = L::WTILE, TPS = L::TPS, MFR = L::MFR, NSTG = L::NSTG, HB_NT = L::NT;
   constexpr bool PP = L::PP;
   constexpr int PD = PP ? 1 : 2;                       // prefetch distance of the weight tiles (taps): the ping-pong keeps one stage for the partner group
   constexpr int NPP = (HB_PATCH / 16 + HB_NT - 1) / HB_NT;   // patch pieces per thread (6 / 3)
@@ -136,10 +148,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   const int twsh = (TW == 32) ? 5 : 4;                 // TW is 16 or 32
   const int nprow = (TH + 2) * PW, npiece = nprow * 8;
 
-  // ---- K steps: main chunk c = steps [9c, 9c + 9) (tap = step % 9), then one step per 64 shortcut channels.  Slice r = steps [sb, se):
-  // a chunk cut by a boundary runs its nine pipeline steps in both blocks, each with the MFMA phases of its own taps only.
+  // ---- K steps: main chunk c = taps [9c, 9c + 9), then one tap per 64 shortcut channels.  Slice r = taps [sb, se): a chunk cut by a
+  // boundary runs all its pipeline steps in both blocks, each with the MFMA phases of its own taps only.
   const int nc = p.Cin >> 6, nsc = p.Csc >> 6, T = 9 * nc + nsc;
-  auto bnd = [&](int q) { int v = (T * q) >> sshift; if (v < 9 * nc) v = (v + 1) / 3 * 3; return v; };
+  auto bnd = [&](int q) {
+    int v = (T * q) >> sshift;
+    if (v < 9 * nc) { if (TPS == 1) v = (v + 1) / 3 * 3; else { const int c = v / 9, tp = v - 9 * c; v = 9 * c + (tp & ~1); } }   // whole tap rows / whole steps
+    return v;
+  };
   const int sb = bnd(r), se = bnd(r + 1);
   const int ch_first = sb < 9 * nc ? sb / 9 : nc + (sb - 9 * nc);         // chunk ids: 0 .. nc-1 main, nc + j shortcut
   const int ch_last = (se - 1) < 9 * nc ? (se - 1) / 9 : nc + (se - 1 - 9 * nc);
@@ -168,14 +184,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + lds_off), 16, 0, 0);
   };
   // weight tile at K offset `koff` (elements) -> ring stage `st`
-  auto issue_w = [&](long koff, int st) -> int {
+  auto issue_w = [&](long koff, int lds_tile) -> int {  // (lds_tile: byte offset of the destination tile in the ring)
     int n = 0;
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       if ((wave + NWV * i) * 64 >= BN * 8) continue;   // wave-uniform (BN / 8 instructions over the waves: the last round is the low waves only)
       unsigned off = woff0 + wstep * i;
       asm volatile("" : "+v"(off));
-      dma(wslab + koff * 2 + off, st * WSTAGE + (wave * 64 + HB_NT * i) * 16);
+      dma(wslab + koff * 2 + off, lds_tile + (wave * 64 + HB_NT * i) * 16);
       ++n;
     }
     return n;
@@ -251,52 +267,57 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #pragma unroll
     for (int i = 0; i < MFR; ++i) HB_DSR(fx0[i], xa[i], 0);
   };
-  auto mma_post = [&](const unsigned* xa, unsigned wbase, auto&& after_group) {
-    const unsigned wb = wbase + wad0, wb1 = wbase + (wad0 ^ 64);
-    HB_DSR(fw[0], wb, 0);
-    HB_DSR(fw[1], wb, 2048);
+  // xa: [TAPS][MFR] fragment addresses of the taps, wbase: [TAPS] LDS addresses of their weight tiles
+  auto mma_stream = [&](auto TAPS_, const unsigned* xa, const unsigned* wbase) {
+    constexpr int TAPS = decltype(TAPS_)::value, G = TAPS * 2 * NF;
+    unsigned wb[TAPS][2];
+#pragma unroll
+    for (int tt = 0; tt < TAPS; ++tt) { wb[tt][0] = wbase[tt] + wad0; wb[tt][1] = wbase[tt] + (wad0 ^ 64); }
+    auto rd_w = [&](const int g2) {
+      const int t2 = g2 / (2 * NF), gl2 = g2 - t2 * 2 * NF, k2 = gl2 / NF, j2 = gl2 - k2 * NF;
+      const unsigned wsel = wb[t2][k2];
+      switch (j2) {
+        case 0: HB_DSR(fw[g2 % 3], wsel, 0); break;
+        case 1: HB_DSR(fw[g2 % 3], wsel, 2048); break;
+        case 2: HB_DSR(fw[g2 % 3], wsel, 2 * 2048); break;
+        case 3: HB_DSR(fw[g2 % 3], wsel, 3 * 2048); break;
+        default: HB_DSR(fw[g2 % 3], wsel, 4 * 2048); break;
+      }
+    };
+    rd_w(0); rd_w(1);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int g = 0; g < 2 * NF; ++g) {
-      const int kk = g / NF, j = g - kk * NF;
-      constexpr int dummy_ = 0; (void)dummy_;
+    for (int g = 0; g < G; ++g) {
+      const int tt = g / (2 * NF), gl = g - tt * 2 * NF, kk = gl / NF, j = gl - kk * NF;
       // the wait is tied to the registers the group reads ("+v"): the MFMAs cannot be scheduled in front of it
-      if (g == 0) {
-        if constexpr (MFR == 4) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fx0[0]), "+v"(fx0[1]), "+v"(fx0[2]), "+v"(fx0[3]), "+v"(fw[0]) : "n"(hb_wait(NF, MFR, 0)) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fx0[0]), "+v"(fx0[1]), "+v"(fw[0]) : "n"(hb_wait(NF, MFR, 0)) : "memory");
-      } else if (g == NF) {
-        if constexpr (MFR == 4) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fx1[0]), "+v"(fx1[1]), "+v"(fx1[2]), "+v"(fx1[3]), "+v"(fw[NF % 3]) : "n"(hb_wait(NF, MFR, NF)) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fx1[0]), "+v"(fx1[1]), "+v"(fw[NF % 3]) : "n"(hb_wait(NF, MFR, NF)) : "memory");
-      } else {
-        switch (hb_wait(NF, MFR, g)) {             // (g is a constant after unrolling; the immediate has to be a literal)
-          case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw[g % 3]) :: "memory"); break;
-          case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fw[g % 3]) :: "memory"); break;
-          case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fw[g % 3]) :: "memory"); break;
-          default: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fw[g % 3]) :: "memory"); break;
-        }
+#define HB_WAIT(N_)                                                                                                                   \
+      if (gl == 0) {                                                                                                                  \
+        if constexpr (MFR == 4) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(fx0[0]), "+v"(fx0[1]), "+v"(fx0[2]), "+v"(fx0[3]), "+v"(fw[g % 3]) :: "memory"); \
+        else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(fx0[0]), "+v"(fx0[1]), "+v"(fw[g % 3]) :: "memory");                      \
+      } else if (gl == NF) {                                                                                                          \
+        if constexpr (MFR == 4) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(fx1[0]), "+v"(fx1[1]), "+v"(fx1[2]), "+v"(fx1[3]), "+v"(fw[g % 3]) :: "memory"); \
+        else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(fx1[0]), "+v"(fx1[1]), "+v"(fw[g % 3]) :: "memory");                      \
+      } else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(fw[g % 3]) :: "memory");
+      switch (hb_wait(NF, MFR, TAPS, g)) {           // (g is a constant after unrolling; the immediate has to be a literal)
+        case 0: HB_WAIT(0) break;
+        case 1: HB_WAIT(1) break;
+        case 2: HB_WAIT(2) break;
+        case 3: HB_WAIT(3) break;
+        default: HB_WAIT(4) break;
       }
+#undef HB_WAIT
       __builtin_amdgcn_sched_barrier(0);
-      if (g < MFR) { const unsigned x1 = xa[g] ^ 64; HB_DSR(fx1[g], x1, 0); }
-      if (g + 2 < 2 * NF) {
-        const int g2 = g + 2, k2 = g2 / NF, j2 = g2 - k2 * NF;
-        const unsigned wsel = k2 ? wb1 : wb;
-        switch (j2) {
-          case 0: HB_DSR(fw[g2 % 3], wsel, 0); break;
-          case 1: HB_DSR(fw[g2 % 3], wsel, 2048); break;
-          case 2: HB_DSR(fw[g2 % 3], wsel, 2 * 2048); break;
-          case 3: HB_DSR(fw[g2 % 3], wsel, 3 * 2048); break;
-          default: HB_DSR(fw[g2 % 3], wsel, 4 * 2048); break;
-        }
-      }
+      if (gl < MFR) { const unsigned x1 = xa[tt * MFR + gl] ^ 64; HB_DSR(fx1[gl], x1, 0); }
+      if (tt + 1 < TAPS && gl >= NF && gl < NF + MFR) HB_DSR(fx0[gl - NF], xa[(tt + 1) * MFR + gl - NF], 0);
+      if (g + 2 < G) rd_w(g + 2);
       const bf16x8 wv = __builtin_bit_cast(bf16x8, fw[g % 3]);
 #pragma unroll
       for (int i = 0; i < MFR; ++i) acc[j][i] = DMX_MFMA_16x16x32(wv, __builtin_bit_cast(bf16x8, kk ? fx1[i] : fx0[i]), acc[j][i]);
       __builtin_amdgcn_sched_barrier(0);
-      after_group(std::integral_constant<int, 0>{}, g);    // (VALU work that rides in the shadow of the group's MFMAs)
-      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
+  auto mma_post = [&](const unsigned* xa, unsigned wbase, auto&&) { mma_stream(std::integral_constant<int, 1>{}, xa, &wbase); };
   auto xa_main = [&](int pb, int tapoff, unsigned* xa) {
     int pr = xrow0;
     asm volatile("" : "+v"(pr));                       // (the tap addresses are loop-invariant: hoisted they would live across the whole K loop)
@@ -370,8 +391,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     issue_coef(d);
 #pragma unroll
     for (int i = 0; i < NPP; ++i) issue_piece(d, L::PATCH0, i);
+    if constexpr (TPS == 1) {
 #pragma unroll
-    for (int d = 0; d < PD; ++d) { const long k0 = koff_of(gstep + d); if (k0 >= 0) issue_w(k0, (gstep + d) % NSTG); }
+      for (int d = 0; d < PD; ++d) { const long k0 = koff_of(gstep + d); if (k0 >= 0) issue_w(k0, ((gstep + d) % NSTG) * WSTAGE); }
+    } else {
+#pragma unroll
+      for (int u = 0; u < TPS; ++u) { const long k0 = koff_of(gstep + u); if (k0 >= 0 && (cur < nc || u == 0)) issue_w(k0, u * WTILE); }     // ring step 0: the first step's taps
+    }
   }
   if (TIMING) tp[0] = __builtin_amdgcn_s_memrealtime();
   if (p.gn && ch_first < nc) {
@@ -451,6 +477,83 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #else
 #define HB_STAMP(acc_)
 #endif
+  if constexpr (PP && TPS == 2) {
+  // ---- K loop of the narrow tiles: two-group ping-pong (below) with TWO taps per step - steps (0,1) (2,3) (4,5) (6,7) (8) of a chunk.
+  // The weight tiles of the next step go to ring stage (rs + 1) % 3 (two 10-KB slots); the two taps of a step run as ONE MFMA stream
+  // (the second tap's fragments are prefetched under the first's MFMAs).  The next chunk's patch is requested in steps 1 / 2 and
+  // normalised one piece per PHASE in steps 2 .. 4: in the DMA phase and again behind the MFMAs of the MFMA phase.
+  const bool grpB = wave >= 4;
+  const bool pingpong = cur >= 0 && cur < nc;
+  int rs = 0;                                          // ring step
+  if (pingpong && grpB) __builtin_amdgcn_s_barrier();
+  while (cur >= 0 && cur < nc) {
+    const int next = cur < ch_last ? cur + 1 : -1;
+    const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0, pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
+    const PDesc dn = pdesc(next);
+    const bool nrm = dn.mode == 1 && p.gn && !(DBG & 4);
+    auto step = [&](auto K_) {
+      constexpr int k = decltype(K_)::value, t0 = 2 * k, nt = k < 4 ? 2 : 1;
+      const int g0 = gstep + t0;
+      const bool active = g0 >= sb && g0 < se;           // (slices are cut on step starts: a step is active or not as a whole)
+      // ---- DMA phase
+      if (!(DBG & 8)) {
+        if constexpr (k == 1) { issue_coef(dn); issue_piece(dn, pbn, 0); issue_piece(dn, pbn, 1); issue_piece(dn, pbn, 2); }
+        if constexpr (k == 2) { issue_piece(dn, pbn, 3); issue_piece(dn, pbn, 4); issue_piece(dn, pbn, 5); }
+      }
+      if (!(DBG & 2)) {
+        // the next step's taps: 2 (k + 1) .. of this chunk, or the first tap(s) of the next chunk (one tap if that is a shortcut chunk)
+        const int n0g = k < 4 ? g0 + 2 : gstep + 9;
+        const int nn = (k + 1 < 4) ? 2 : ((k + 1 == 4) ? 1 : ((next >= 0 && next < nc) ? 2 : 1));
+        const int dst = ((rs + 1) % 3) * WSTAGE;
+        { const long kn = koff_of(n0g); if (kn >= 0) issue_w(kn, dst); }
+        if (nn == 2) { const long kn = koff_of(n0g + 1); if (kn >= 0) issue_w(kn, dst + WTILE); }
+      }
+      if constexpr (k == 2) { if (dn.mode == 1) coef_table(next); }
+      if constexpr (k >= 2) { if (nrm) norm_piece(pbn, 2 * (k - 2)); }
+      unsigned xa[2 * MFR];
+      if (active) { xa_main(pb, (t0 / 3) * PW + (t0 % 3), xa); if (nt == 2) xa_main(pb, ((t0 + 1) / 3) * PW + ((t0 + 1) % 3), xa + MFR); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (active && !(DBG & 1)) mma_pre(xa);
+      HB_STAMP(pa_dma)
+      if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+      HB_STAMP(pa_wx)
+      // ---- MFMA phase
+      if (active && !(DBG & 1)) {
+        const unsigned wbs[2] = {lds0 + (rs % 3) * WSTAGE, lds0 + (rs % 3) * WSTAGE + WTILE};
+        mma_stream(std::integral_constant<int, nt>{}, xa, wbs);
+      }
+      if constexpr (k >= 2) { if (nrm) norm_piece(pbn, 2 * (k - 2) + 1); }
+      wait_vm(0);                                        // this wave's requests of this step's DMA phase have landed
+      HB_STAMP(pa_mma)
+      if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+      HB_STAMP(pa_wy)
+      ++rs;
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
+    gstep += 9; ++seq;
+    cur = next;
+  }
+  if (pingpong && !grpB) __builtin_amdgcn_s_barrier(); // (group B's extra barrier of the entry: the groups are level again)
+  // ---- shortcut steps (one tap each): lock step, the next shortcut patch requested one step ahead into the other patch buffer
+  while (cur >= nc) {
+    const int next = cur < ch_last ? cur + 1 : -1;
+    const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0, pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
+    const PDesc dn = pdesc(next);
+    issue_piece(dn, pbn, 0); issue_piece(dn, pbn, 1); issue_piece(dn, pbn, 2); issue_piece(dn, pbn, 3);
+    { const long kn = koff_of(gstep + 1); if (kn >= 0) issue_w(kn, ((rs + 1) % 3) * WSTAGE); }
+    unsigned xa[MFR];
+    xa_sc(pb, xa);
+    mma_pre(xa);
+    __builtin_amdgcn_s_barrier();
+    const unsigned wb1 = lds0 + (rs % 3) * WSTAGE;
+    mma_stream(std::integral_constant<int, 1>{}, xa, &wb1);
+    wait_vm(0);                                        // (the next shortcut patch and weight tile have landed)
+    __builtin_amdgcn_s_barrier();
+    gstep += 1; ++seq; ++rs;
+    cur = next;                                        // (-1 ends the loop)
+  }
+  } else
   if constexpr (PP) {
   const bool grpB = wave >= 4;
   const bool pingpong = cur >= 0 && cur < nc;
@@ -470,7 +573,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
         static_assert(!PP || NPP == 6, "ping-pong schedule: six patch pieces per thread");
       }
       int nw = 0;                                        // (patch pieces first, the weight tile last: the counted wait below leaves only IT in flight)
-      if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) nw = issue_w(kn, (g + PD) % NSTG); }
+      if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) nw = issue_w(kn, ((g + PD) % NSTG) * WSTAGE); }
       if constexpr (s == 2) { if (dn.mode == 1) coef_table(next); }
       if constexpr (s >= 3) { if (dn.mode == 1 && !(DBG & 4)) norm_piece(pbn, s - 3); }
       unsigned xa[MFR];
@@ -503,7 +606,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     const PDesc dn = pdesc(next);
     issue_piece(dn, pbn, 0); issue_piece(dn, pbn, 1); issue_piece(dn, pbn, 2); issue_piece(dn, pbn, 3);
     int nw = 0;
-    { const long kn = koff_of(gstep + PD); if (kn >= 0) nw = issue_w(kn, (gstep + PD) % NSTG); }
+    { const long kn = koff_of(gstep + PD); if (kn >= 0) nw = issue_w(kn, ((gstep + PD) % NSTG) * WSTAGE); }
     unsigned xa[MFR];
     xa_sc(pb, xa);
     mma_pre(xa);
@@ -541,7 +644,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #pragma unroll
           for (int i = H0; i < NPP; ++i) n += issue_piece(dn, pbn, i); }
       }
-      if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) n += issue_w(kn, (g + PD) % NSTG); }
+      if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) n += issue_w(kn, ((g + PD) % NSTG) * WSTAGE); }
       n_prev = n;
       // (a thread normalises the pieces it requested itself: those of step 0 / 1 are confirmed by the waits of steps 2 / 3)
       if constexpr (s == 2) { if (dn.mode == 1) coef_table(next); }
@@ -573,7 +676,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     int n = 0, nwt = 0;
 #pragma unroll
     for (int i = 0; i < NPP; ++i) n += issue_piece(dn, pbn, i);
-    { const long kn = koff_of(gstep + PD); if (kn >= 0) nwt = issue_w(kn, (gstep + PD) % NSTG); }
+    { const long kn = koff_of(gstep + PD); if (kn >= 0) nwt = issue_w(kn, ((gstep + PD) % NSTG) * WSTAGE); }
     n_prev = nwt; (void)n;
     unsigned xa[MFR];
     xa_sc(pb, xa);
@@ -831,8 +934,8 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
       if (a.force_split && s != a.force_split) continue;
       if (s > 1 && (tiles * s > n_cus() || T / s < 3)) continue;
       const double rounds = (double)((tiles * s + n_cus() - 1) / n_cus());
-      const double step = bn >= 128 ? 1.39 : 1.04;                         // us per tap and block (measured, B = 4 64x64x320: K = 2880 / 5760 / 8640)
-      double cost = rounds * ((double)((T + s - 1) / s) * step + 15.0);    // + prologue / epilogue of a block
+      const double step = bn >= 128 ? 1.45 : 0.96;                         // us per tap and block (measured, B = 4 64x64x320: K = 2880 / 5760 / 8640)
+      double cost = rounds * ((double)((T + s - 1) / s) * step + 13.0);    // + prologue / epilogue of a block
       if (s > 1) cost += 3.5 + 2.0 * (double)(s - 1) * bn / 160.0;         // publish + wait + the peers' slabs
       if (cost < best) { best = cost; P.nf = cand[c][0]; P.wmw = cand[c][1]; P.bn = bn; P.splits = s; }
     }

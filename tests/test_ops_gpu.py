@@ -634,6 +634,7 @@ HALO_CASES = [
     ("gn_n128_16w_vae", 1, 64, 64, 128, 0, 256, 128, 0, True, 0, 128, 16),
     ("gn_64x64_320_8w_split2", 2, 64, 64, 320, 0, 320, 0, 0, True, 2, 160, 8),
     ("plain_16w_sc_only", 1, 16, 32, 64, 64, 160, 64, 64, False, 2, 160, 16),
+    ("gn_32x32_concat_sc_8w_split4", 2, 32, 32, 640, 320, 640, 640, 320, True, 4, 160, 8),
     ("gn_64x64_320", 2, 64, 64, 320, 0, 320, 0, 0, True, 0),
     ("gn_32x32_concat_sc", 2, 32, 32, 640, 320, 640, 640, 320, True, 0),
     ("gn_16x16_1280", 2, 16, 16, 640, 0, 1280, 0, 0, True, 0),
