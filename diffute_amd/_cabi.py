@@ -14,6 +14,7 @@ _LIB_PATH = os.environ.get("DIFFUTE_HIP_LIB") or os.path.join(_LIB_DIR, "libdiff
 _LIB_PATH_F16 = os.environ.get("DIFFUTE_HIP_LIB_F16") or os.path.join(_LIB_DIR, "libdiffute_hip_f16.so")
 _lib = None
 _lib_f16 = None
+_last_elem = "bf16"      # the build handed out last: check() reads ITS error message (the call that failed went through it)
 
 
 class XfChainDesc(ctypes.Structure):
@@ -244,15 +245,17 @@ def _load(path, want_elem):
 def lib(elem="bf16"):
     """Load (once) and return the C-ABI library - the bf16 build, or with elem="fp16" the fp16 build of the same sources;
     raises if it has not been built."""
-    global _lib, _lib_f16
+    global _lib, _lib_f16, _last_elem
     if elem == "fp16":
         if _lib_f16 is None:
             _lib_f16 = _load(_LIB_PATH_F16, "fp16")
+        _last_elem = "fp16"
         return _lib_f16
     if elem != "bf16":
         raise ValueError(f"diffute_amd: no build for element type {elem!r}")
     if _lib is None:
         _lib = _load(_LIB_PATH, "bf16")
+    _last_elem = "bf16"
     return _lib
 
 
@@ -273,10 +276,12 @@ def exported_symbols():
 
 
 def check(rc, what="", l=None):
+    """raise on a non-zero return code with the message of the library the call went through: `l`, or the build that lib() handed
+    out last (every wrapper fetches its library right before the call)"""
     if rc != 0:
-        msg = (l or lib()).dmx_last_error()
-        if not msg and _lib_f16 is not None and l is None:
-            msg = _lib_f16.dmx_last_error()
+        if l is None:
+            l = _lib_f16 if (_last_elem == "fp16" and _lib_f16 is not None) else lib()
+        msg = l.dmx_last_error()
         raise RuntimeError(f"diffute_amd: {what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 

@@ -143,10 +143,10 @@ class _HipModel(nn.Module):
         if getattr(self, "_fused", None) is not None or getattr(self, "_tb", None) is not None:
             raise NotImplementedError(f"{type(self).__name__}: changing the compute type after training state exists is not supported")
         torch.cuda.synchronize() if torch.cuda.is_initialized() else None
-        getattr(_cabi.lib(self._elem), f"dmx_{self._kind}_destroy")(self._h)
-        self._h = None
-        self._elem = elem
-        self._h = self._create_handle(elem)
+        new_h = self._create_handle(elem)                 # (first the new handle: a missing build / failed create leaves the model as it was)
+        old_h, old_elem = self._h, self._elem
+        self._h, self._elem = new_h, elem
+        getattr(_cabi.lib(old_elem), f"dmx_{self._kind}_destroy")(old_h)
         self._arena = None; self._packed_sig = None; self._ws = None
         for attr in ("_masters32", "_train"):
             if hasattr(self, attr):

@@ -139,6 +139,50 @@ def test_tiny_unet_on_the_160_column_tiles(cuda):
     assert rel_l2(y, ref) < 2e-2 and not torch.equal(y, ref), "the override must have changed at least one GEMM's tile plan"
 
 
+def test_fused_groupnorm_conv_inside_the_models(cuda):
+    """conv_halo.hip inside whole models: the executors fuse GroupNorm -> SiLU -> conv3x3 of every ResnetBlock2D only at the levels
+    where it pays at the bench batch (>= 32 x 32 pixels), which the tiny configurations barely reach - so here the fused launch is
+    forced wherever the kernel takes the problem (dmx_set_halo_conv(2): 64 / 128-column tiles, 16 x 16 and 8 x 32 tile geometries, K
+    splits, statistics records from convs, from the transformer's last GEMM and from dmx_colstats) and held to the oracle like the
+    unfused path, for the tiny UNet (16 x 32 latents) and the tiny autoencoder (32 x 64 px)."""
+    import diffute_amd as D
+    from diffute_amd import _cabi
+    from diffute_amd.synthetic import synth_inputs
+    from oracle import unet as OU, vae as OV
+    lib = _cabi.lib()
+    lat, mask, mlat, ctx = synth_inputs(1, 16, 32, 40, 128, device=cuda, seed=5)
+    x = torch.cat([lat, mask, mlat], 1)
+    img = torch.rand(1, 3, 32, 64, device=cuda) * 2 - 1
+    outs = {}
+    try:
+        for mode in (0, 2):
+            lib.dmx_set_halo_conv(mode)
+            torch.manual_seed(3)
+            unet = D.UNet2DConditionModel(**TINY_UNET).cuda().requires_grad_(False)
+            vae = D.AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=1).cuda().requires_grad_(False)
+            with torch.no_grad():
+                eps = unet(x, torch.tensor(500), ctx).sample
+                z = vae.encode(img).latent_dist.mode()
+                rec = vae.decode(z).sample
+            outs[mode] = (eps, z, rec, unet, vae)
+    finally:
+        lib.dmx_set_halo_conv(1)
+    eps0, z0, rec0, unet, vae = outs[0]
+    eps2, z2, rec2, _, _ = outs[2]
+    P = {k: v.detach().cpu().float() for k, v in unet.state_dict().items()}
+    ref = OU.unet_forward(P, OU.TINY_UNET, x.cpu().float(), torch.tensor(500), ctx.cpu().float(), emulate_bf16=True)
+    assert_close(eps2, ref, E2E_EMU, "tiny unet, fused GroupNorm -> conv everywhere vs bf16-emulating oracle")
+    assert_close(eps0, ref, E2E_EMU, "tiny unet, unfused vs bf16-emulating oracle")
+    assert rel_l2(eps2, eps0) < 2e-2 and not torch.equal(eps2, eps0), "fused vs unfused: two bf16 roundings apart, and the switch must have changed the launch sequence"
+    PV = {k: v.detach().cpu().float() for k, v in vae.state_dict().items()}
+    zref = OV.vae_encode_moments(PV, OV.TINY_VAE, img.cpu().float(), emulate_bf16=True)[:, :4] if hasattr(OV, "vae_encode_moments") else None
+    if zref is not None:
+        assert_close(z2, zref, E2E_EMU, "tiny vae encode, fused vs oracle")
+    rref = OV.vae_decode(PV, OV.TINY_VAE, z2.cpu().float(), emulate_bf16=True)
+    assert_close(rec2, rref, E2E_EMU, "tiny vae decode, fused GroupNorm -> conv everywhere vs bf16-emulating oracle")
+    assert rel_l2(z2, z0) < 2e-2 and rel_l2(rec2, rec0) < 4e-2          # (the two decodes start from their own, slightly different latents)
+
+
 def test_tiny_vae(cuda, tiny_vae):
     from diffute_amd.synthetic import synth_images
     from diffute_amd.init import normal
