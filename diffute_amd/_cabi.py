@@ -23,7 +23,8 @@ class XfChainDesc(ctypes.Structure):
         ("w0", c_void_p), ("b0", c_void_p), ("h_out", c_void_p), ("ldh", c_int), ("w1", c_void_p),
         ("c1", c_void_p), ("c2", c_void_p), ("y", c_void_p), ("ldy", c_int), ("wf1", c_void_p),
         ("wf2", c_void_p), ("bf2", c_void_p), ("wpo", c_void_p), ("bpo", c_void_p), ("xres", c_void_p), ("ldxres", c_int),
-        ("eps", c_float), ("dbg", c_int), ("timing", c_void_p),
+        ("eps", c_float), ("dbg", c_int), ("timing", c_void_p), ("colstats", c_void_p), ("cs_rows", c_int),
+        ("gn_st", c_void_p), ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_groups", c_int), ("gn_rows", c_int), ("gn_eps", c_float),
     ]
 
 

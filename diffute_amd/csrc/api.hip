@@ -145,6 +145,8 @@ extern "C" int dmx_xf_chain(const dmx_xf_chain_desc* d, int mode, dmx_stream_t s
   a.w0 = (const bf16*)d->w0; a.b0 = d->b0; a.h_out = (bf16*)d->h_out; a.ldh = d->ldh; a.w1 = (const bf16*)d->w1;
   a.c1 = d->c1; a.c2 = d->c2; a.y = (bf16*)d->y; a.ldy = d->ldy; a.wf1 = (const bf16*)d->wf1; a.wf2 = (const bf16*)d->wf2; a.bf2 = d->bf2;
   a.wpo = (const bf16*)d->wpo; a.bpo = d->bpo; a.xres = (const bf16*)d->xres; a.ldxres = d->ldxres; a.eps = d->eps; a.dbg = d->dbg; a.timing = d->timing;
+  a.colstats = d->colstats; a.cs_rows = d->cs_rows;
+  a.gn_st = d->gn_st; a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.gn_groups = d->gn_groups; a.gn_rows = d->gn_rows; a.gn_eps = d->gn_eps;
   return dmx_xf_chain_launch(a, mode, (hipStream_t)stream);
 }
 extern "C" int dmx_groupnorm_train(const void* x0, int ldx0, const void* x1, int ldx1, int c0, int C, int groups,

@@ -871,37 +871,47 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   }
 }
 
-// statistics of a tensor whose producer emitted none: block = `rows_per_block` rows x all channels of one sample; thread = (row lane,
-// channel octet), 4 rows in flight per thread, row lanes folded through LDS in a fixed order, one DmxStat add per channel and block
+// statistics of a tensor whose producer emitted none: block = `rows_per_block` rows x one slab of CW channels of one sample; thread =
+// (row lane, channel octet), 4 rows in flight per thread, row lanes folded through LDS in a fixed order (two stages), one DmxStat add per
+// channel and block - the integer atomics are what a launch of many small blocks pays for (4096 x 1280: 50 us with 344 blocks x 1280
+// channels, 1.3 M atomics on 15 k addresses), so a block takes a narrow slab over many rows
+template <int CW>
 __global__ __launch_bounds__(512) void dmx_colstats_kernel(const bf16* x, int ldx, int HW, int C, long long* st, int rows_per_block) {
-  extern __shared__ float cs_red[];                    // [RL][C][2]
-  const int b = blockIdx.y, row0 = blockIdx.x * rows_per_block, row1 = min(row0 + rows_per_block, HW);
-  const int oc = C >> 3, RL = 512 / oc;
-  const int t = threadIdx.x, o = t % oc, rl = t / oc;
+  constexpr int OC = CW / 8, RL = 512 / OC, P2 = RL >= 8 ? 8 : RL;       // row lanes, second-stage parts
+  __shared__ float red[RL][CW][2];
+  __shared__ float red2[P2][CW][2];
+  const int b = blockIdx.z, c0 = blockIdx.y * CW, row0 = blockIdx.x * rows_per_block, row1 = min(row0 + rows_per_block, HW);
+  const int t = threadIdx.x, o = t % OC, rl = t / OC;
   float s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-  if (rl < RL) {
-    for (int row = row0 + rl; row < row1; row += 4 * RL) {
-      u32x4 v[4];
+  for (int row = row0 + rl; row < row1; row += 4 * RL) {
+    u32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(x + ((size_t)b * HW + min(row + u * RL, row1 - 1)) * ldx + o * 8);
+    for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(x + ((size_t)b * HW + min(row + u * RL, row1 - 1)) * ldx + c0 + o * 8);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (row + u * RL >= row1) continue;
-        float f[8]; unpack_bf8(v[u], f);
+    for (int u = 0; u < 4; ++u) {
+      if (row + u * RL >= row1) continue;
+      float f[8]; unpack_bf8(v[u], f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
-      }
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
     }
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { cs_red[(rl * C + o * 8 + e) * 2] = s[e]; cs_red[(rl * C + o * 8 + e) * 2 + 1] = q[e]; }
+  for (int e = 0; e < 8; ++e) { red[rl][o * 8 + e][0] = s[e]; red[rl][o * 8 + e][1] = q[e]; }
+  __syncthreads();
+  if (t < P2 * CW) {
+    const int c = t % CW, part = t / CW;
+    float sa = 0.f, sq = 0.f;
+    for (int k = part * (RL / P2); k < (part + 1) * (RL / P2); ++k) { sa += red[k][c][0]; sq += red[k][c][1]; }
+    red2[part][c][0] = sa; red2[part][c][1] = sq;
   }
   __syncthreads();
-  for (int c = t; c < C; c += 512) {
+  if (t < CW) {
     float sa = 0.f, sq = 0.f;
-    for (int k = 0; k < RL; ++k) { sa += cs_red[(k * C + c) * 2]; sq += cs_red[(k * C + c) * 2 + 1]; }
-    dmx_stat_add(st + ((size_t)b * C + c) * DMX_STAT_WORDS, sa, sq);
+#pragma unroll
+    for (int k = 0; k < P2; ++k) { sa += red2[k][t][0]; sq += red2[k][t][1]; }
+    dmx_stat_add(st + ((size_t)b * C + c0 + t) * DMX_STAT_WORDS, sa, sq);
   }
 }
 
@@ -1034,13 +1044,15 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
 }
 
 int dmx_colstats_launch(const bf16* x, int ldx, int B, int HW, int C, long long* st, hipStream_t stream) {
-  DMX_REQUIRE(x && st && C % 8 == 0 && ldx % 8 == 0 && C >= 8 && C <= 4096, "colstats: C and ld must be multiples of 8, 8 <= C <= 4096");
-  const int oc = C / 8, RL = 512 / oc;
+  DMX_REQUIRE(x && st && C % 8 == 0 && ldx % 8 == 0 && C >= 8, "colstats: C and ld must be multiples of 8");
+  const int cw = C % 64 == 0 ? 64 : (C % 32 == 0 ? 32 : 8), RL = 512 / (cw / 8);
   int rpb = 4 * RL;                                    // >= 4 rows per thread; fewer, larger blocks once the chip is covered twice
-  while ((long)B * cdiv(HW, rpb) > 2 * n_cus() && rpb < HW) rpb *= 2;
+  while ((long)B * (C / cw) * cdiv(HW, rpb) > 2 * n_cus() && rpb < HW) rpb *= 2;
   char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d colstats", B * HW, C);
   ProfScope ps(PROF_GNORM, stream, 0.0, 2.0 * (double)B * HW * C, tag);
-  const size_t lds = (size_t)RL * C * 2 * sizeof(float);
-  hipLaunchKernelGGL(dmx_colstats_kernel, dim3(cdiv(HW, rpb), B), dim3(512), lds, stream, x, ldx, HW, C, st, rpb);
+  const dim3 grid(cdiv(HW, rpb), C / cw, B);
+  if (cw == 64) hipLaunchKernelGGL(dmx_colstats_kernel<64>, grid, dim3(512), 0, stream, x, ldx, HW, C, st, rpb);
+  else if (cw == 32) hipLaunchKernelGGL(dmx_colstats_kernel<32>, grid, dim3(512), 0, stream, x, ldx, HW, C, st, rpb);
+  else hipLaunchKernelGGL(dmx_colstats_kernel<8>, grid, dim3(512), 0, stream, x, ldx, HW, C, st, rpb);
   return dmx_check_launch("dmx_colstats_kernel");
 }

@@ -167,6 +167,7 @@ class Exec {
   // operation take them (C = 320, rows % 64 == 0, bf16 path, dmx_set_xf_chain(1))
   bool chain_ok(const Tn& x) const;
   void xf_chain(int mode, XfChainArgs& a);
+  bool chain_gn_fold(const Tn& x) const;              // mode-2 chain: normalise the raw x in its operand load (x carries statistics records)
   void chain_stats(XfChainArgs& a, Tn& y);            // mode-1 chain: also emit the statistics records of its output y (when a fused GroupNorm -> conv can use them)
   // fused attention core; V row-major (LDS transpose-read path)
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,

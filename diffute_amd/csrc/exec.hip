@@ -404,7 +404,9 @@ Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps
 
 static int g_xf_chain = 1;
 extern "C" int dmx_set_xf_chain(int on) { const int old = g_xf_chain; g_xf_chain = on; return old; }
-bool Exec::chain_ok(const Tn& x) const { return g_xf_chain && !f32 && x.ld == x.C && (g_xf_chain > 1 ? dmx_xf_chain_supported(x.rows(), x.C) : dmx_xf_chain_pays(x.rows(), x.C)); }
+bool Exec::chain_ok(const Tn& x) const { return (g_xf_chain & 3) && !f32 && x.ld == x.C && ((g_xf_chain & 3) > 1 ? dmx_xf_chain_supported(x.rows(), x.C) : dmx_xf_chain_pays(x.rows(), x.C)); }
+// (dmx_set_xf_chain bit 2: chains without the folded entry GroupNorm - A/B aid)
+bool Exec::chain_gn_fold(const Tn& x) const { return !(g_xf_chain & 4) && !f32 && x.cst != nullptr && (x.H * x.W) % 64 == 0 && x.ld == x.C; }
 void Exec::chain_stats(XfChainArgs& a, Tn& y) {
   if (rc || f32 || !dmx_halo_conv_enabled() || !g_gn_producer_stats || (y.H * y.W) % 64) return;
   if (!((y.W % 32 == 0 && y.H % 8 == 0) || (y.W % 16 == 0 && y.H % 16 == 0)) || (g_halo_conv == 1 && (long)y.H * y.W < 1024)) return;

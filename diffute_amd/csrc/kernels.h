@@ -196,6 +196,10 @@ struct XfChainArgs {
   // mode 1: DmxStat records of the block output y for the GroupNorm that reads it next ([M / cs_rows][C][4], added to; cs_rows = rows per
   // sample, a multiple of 64), or null
   long long* colstats; int cs_rows;
+  // mode 2: x is the RAW tensor and the block normalises its rows on the way into the fragments: GroupNorm (no activation) from the DmxStat
+  // records of x ([M / gn_rows][C][4]; gn_rows = rows per sample, a multiple of 64) - the same arithmetic, to the bit, as dmx_groupnorm's
+  // apply pass followed by the plain mode 2.  Null gn_st: x is already normalised
+  const long long* gn_st; const float* gn_gamma; const float* gn_beta; int gn_groups; int gn_rows; float gn_eps;
 };
 bool dmx_xf_chain_supported(int M, int C);
 bool dmx_xf_chain_pays(int M, int C);      // what the model executors use: enough 64-row blocks to fill the chip

@@ -289,11 +289,13 @@ struct Fwd {
   Tn xformer(const XfW& w, const Tn& x) {
     if (ex.f32) return xformer_f32(w, x);
     const int G = u->cfg.norm_num_groups, C = w.C, S = x.H * x.W;
-    Tn t = ex.groupnorm(x, nullptr, u->at<float>(w.ng), u->at<float>(w.nb), G, 1e-6f, false);
+    const bool chain = ex.chain_ok(x);     // C = 320 levels: the per-row GEMM chains around the two attention cores are three kernels (xf_chain.hip)
+    // the entry GroupNorm rides in the first chain's operand load when x came with its statistics records (xf_chain.hip mode 2)
+    const bool gn_fold = chain && ex.chain_gn_fold(x);
+    Tn t = gn_fold ? x : ex.groupnorm(x, nullptr, u->at<float>(w.ng), u->at<float>(w.nb), G, 1e-6f, false);
     // LayerNorms are folded: each residual-stream producer also emits per-row (sum, sumsq) partials and the
     // consuming GEMM multiplies the raw rows by W*gamma and normalises in its epilogue - no LN kernels, no LN tensors.
     Exec::RowStats st1, st2, st3;
-    const bool chain = ex.chain_ok(x);     // C = 320 levels: the per-row GEMM chains around the two attention cores are three kernels (xf_chain.hip)
     Tn h, qkv;
     if (chain) {
       // [proj_in -> LN1 -> to_q | to_k | to_v]
@@ -302,8 +304,9 @@ struct Fwd {
       c.M = x.rows(); c.C = C; c.eps = 1e-5f;
       c.x = t.p; c.ldx = t.ld; c.w0 = u->at<bf16>(w.wpi); c.b0 = u->at<float>(w.bpi); c.h_out = h.p; c.ldh = h.ld;
       c.w1 = u->at<bf16>(w.wqkv); c.c1 = u->at<float>(w.c1_qkv); c.c2 = u->at<float>(w.c2_qkv); c.y = qkv.p; c.ldy = qkv.ld;
+      if (gn_fold) { c.gn_st = x.cst; c.gn_gamma = u->at<float>(w.ng); c.gn_beta = u->at<float>(w.nb); c.gn_groups = G; c.gn_rows = S; c.gn_eps = 1e-6f; }
       ex.xf_chain(2, c);
-      ex.drop(t);
+      if (!gn_fold) ex.drop(t);
     } else {
       h = ex.linear(t, u->at<bf16>(w.wpi), C, u->at<float>(w.bpi), nullptr, false, &st1);
       ex.drop(t);

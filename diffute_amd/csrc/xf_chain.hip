@@ -350,6 +350,47 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
     const float* vsrc = MODE == 0 ? (v == 0 ? p.b0 : v == 1 ? p.c1 : p.c2) : (v == 0 ? p.b0 : v == 1 ? p.bf2 : p.bpo);
     *(f32x4*)(smem + XVEC_OFF + (v * XC + 4 * q4) * 4) = *(const f32x4*)(vsrc + 4 * q4);
   }
+  if constexpr (MODE == 2) {
+    if (p.gn_st) {
+      // GroupNorm of the transformer entry folded into the operand load: per-channel affine a = rstd * gamma, s = beta - mean * a of this
+      // block's sample from the statistics records of x (group reduction and variance in double, the order of dmx_gn_apply_kernel), then
+      // y = x * a + s on the fragments - one launch and one round trip of the 64x64 tensor less per transformer block
+      double* cs = (double*)(smem + XFF_OFF + 12288);                // [2][320] (behind the seven column vectors)
+      float* coef = (float*)(smem + XVEC_OFF);                       // a[320] | s[320]
+      const int smp = m0 / p.gn_rows;
+      if (t < XC) {
+        const long long* q = p.gn_st + ((size_t)smp * XC + t) * DMX_STAT_WORDS;
+        cs[t] = dmx_stat_sum(q[0]); cs[XC + t] = dmx_stat_sumsq(q[1], q[2]);
+      }
+      __syncthreads();
+      if (t < XC) {
+        const int cpg = XC / p.gn_groups, g = t / cpg;
+        double a = 0.0, q = 0.0;
+        for (int k = 0; k < cpg; ++k) { a += cs[g * cpg + k]; q += cs[XC + g * cpg + k]; }
+        const double inv_n = 1.0 / ((double)p.gn_rows * (double)cpg);
+        const double mean = a * inv_n;
+        double var = q * inv_n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float mf = (float)mean, rf = (float)(1.0 / __builtin_sqrt(var + (double)p.gn_eps));
+        const float A = rf * p.gn_gamma[t];
+        coef[t] = A; coef[XC + t] = p.gn_beta[t] - mf * A;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 10; ++ks) {
+        const int c0 = 32 * ks + 8 * lh;
+        const f32x4 a0 = *(const f32x4*)(coef + c0), a1 = *(const f32x4*)(coef + c0 + 4);
+        const f32x4 s0 = *(const f32x4*)(coef + XC + c0), s1 = *(const f32x4*)(coef + XC + c0 + 4);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float f[8]; unpack_bf8(__builtin_bit_cast(u32x4, xf[b][ks]), f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = f[i] * (i < 4 ? a0[i] : a1[i - 4]) + (i < 4 ? s0[i] : s1[i - 4]);
+          xf[b][ks] = __builtin_bit_cast(bf16x8, pack_bf8(f));
+        }
+      }
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -483,6 +524,8 @@ int dmx_xf_chain_launch(const XfChainArgs& a, int mode, hipStream_t stream) {
   DMX_REQUIRE(a.x && (a.res || mode == 2) && a.w0 && a.b0 && a.h_out && a.y && a.c1 && a.c2, "xf_chain: null operand");
   if (a.colstats) DMX_REQUIRE(mode == 1 && a.cs_rows > 0 && a.cs_rows % 64 == 0 && a.M % a.cs_rows == 0, "xf_chain: output statistics need mode 1 and samples of a multiple of 64 rows");
   DMX_REQUIRE(a.ldx % 8 == 0 && a.ldres % 4 == 0 && a.ldh % 8 == 0 && a.ldy % 8 == 0, "xf_chain: row strides must be multiples of 8 elements");
+  if (a.gn_st) DMX_REQUIRE(mode == 2 && a.gn_gamma && a.gn_beta && a.gn_groups > 0 && a.C % a.gn_groups == 0 && a.gn_rows > 0 && a.gn_rows % 64 == 0 && a.M % a.gn_rows == 0,
+                           "xf_chain: the folded GroupNorm needs mode 2, gamma / beta, groups dividing C and samples of a multiple of 64 rows");
   if (mode != 1) DMX_REQUIRE(a.w1 != nullptr, "xf_chain: null operand");
   else DMX_REQUIRE(a.wf1 && a.wf2 && a.bf2 && a.wpo && a.bpo && a.xres && a.ldxres % 4 == 0, "xf_chain: null operand");
   const double M = a.M, C = a.C;

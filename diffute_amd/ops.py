@@ -262,9 +262,11 @@ def linear(x, w, bias=None, res=None, geglu=False, out_f32=False, act=0, force_t
     return y.reshape(*x.shape[:-1], y.shape[-1])
 
 
-def xf_chain(mode, x, res, w0, b0, c1, c2, w1=None, wf1=None, wf2=None, bf2=None, wpo=None, bpo=None, xres=None, eps=1e-5, dbg=0, timing=None):
+def xf_chain(mode, x, res, w0, b0, c1, c2, w1=None, wf1=None, wf2=None, bf2=None, wpo=None, bpo=None, xres=None, eps=1e-5, dbg=0, timing=None,
+             out_stats_rows=0, gn=None):
     """The row-local chains of a transformer block at the C = 320 levels, one launch each (include/diffute_hip.h dmx_xf_chain).
-    x / res / xres [M][C]; returns (h_out, y)."""
+    x / res / xres [M][C]; returns (h_out, y).  out_stats_rows (mode 1): also return the statistics records of y, samples of that many
+    rows.  gn = (st, gamma, beta, groups, rows_per_sample, eps) (mode 2): x is raw, GroupNorm from its records in the operand load."""
     M, C = x.shape
     d = _cabi.XfChainDesc()
     h = torch.empty(M, C, dtype=h16(), device=x.device)
@@ -280,9 +282,17 @@ def xf_chain(mode, x, res, w0, b0, c1, c2, w1=None, wf1=None, wf2=None, bf2=None
         d.w1 = ptr(w1)
     else:
         d.wf1, d.wf2, d.bf2, d.wpo, d.bpo, d.xres, d.ldxres = ptr(wf1), ptr(wf2), ptr(bf2), ptr(wpo), ptr(bpo), ptr(xres), _ld(xres)
+    cst = None
+    if out_stats_rows:
+        cst = torch.zeros(M // out_stats_rows, C, 4, dtype=torch.int64, device=x.device)
+        d.colstats, d.cs_rows = cst.data_ptr(), int(out_stats_rows)
+    if gn is not None:
+        st, gamma, beta, groups, rows, geps = gn
+        keep += [st, gamma, beta]
+        d.gn_st, d.gn_gamma, d.gn_beta, d.gn_groups, d.gn_rows, d.gn_eps = st.data_ptr(), ptr(gamma), ptr(beta), int(groups), int(rows), float(geps)
     check(lib().dmx_xf_chain(ctypes.byref(d), int(mode), current_stream()), "xf_chain")
     del keep
-    return h, y
+    return (h, y, cst) if out_stats_rows else (h, y)
 
 
 def groupnorm(x0, gamma, beta, groups, eps, silu, x1=None):

@@ -208,6 +208,13 @@ typedef struct {
   const void* xres; int ldxres;
   float eps;
   int dbg; long long* timing;   /* measurement aids, 0 / NULL: ablation bits (results invalid), [M/64][8] phase timestamps in 10 ns ticks */
+  /* mode 1, optional: statistics records of y for the GroupNorm that reads it next, [M / cs_rows][C][4] int64, ADDED to (zero them first);
+   * cs_rows = rows per sample, a multiple of 64 */
+  long long* colstats; int cs_rows;
+  /* mode 2, optional: x is the RAW tensor and GroupNorm(gn_groups, gn_eps, gn_gamma, gn_beta; no activation) is applied in the operand
+   * load from the statistics records gn_st of x ([M / gn_rows][C][4], as dmx_colstats / a producer's colstats writes them; gn_rows = rows
+   * per sample, a multiple of 64) - bit-identical to dmx_groupnorm_from_stats followed by the plain mode 2 */
+  const long long* gn_st; const float* gn_gamma; const float* gn_beta; int gn_groups; int gn_rows; float gn_eps;
 } dmx_xf_chain_desc;
 int dmx_xf_chain_ok(int M, int C);
 int dmx_xf_chain(const dmx_xf_chain_desc* d, int mode, dmx_stream_t stream);

@@ -36,7 +36,7 @@ def main(stats_dir, fetch_dir, write_dir, out):
     wt, wn = per_kernel(write_dir, "WRITE_SIZE")
     rows = []
     for k in ft:
-        if not k.startswith(("void dmx_", "dmx_")):
+        if "dmx_" not in k:
             continue
         f_kb = ft[k] / fn[k]
         w_kb = wt.get(k, 0.0) / max(wn.get(k, 0), 1)
@@ -59,7 +59,7 @@ def mfma(mfma_dir, out):
     at, an = per_kernel(mfma_dir, "GRBM_GUI_ACTIVE")
     rows = []
     for k in bt:
-        if not k.startswith(("void dmx_", "dmx_")) or at.get(k, 0) <= 0:
+        if "dmx_" not in k or at.get(k, 0) <= 0:
             continue
         rows.append((k, bn[k], bt[k] / bn[k], at[k] / an[k], bt[k] / (1024.0 * at[k] / GRBM_INSTANCES)))
     rows.sort(key=lambda r: -r[1] * r[3])

@@ -548,6 +548,31 @@ def test_xf_chain_proj_in_ln_qkv(cuda, M):
     assert torch.equal(h, h_b) and torch.equal(qkv, qkv_b), "xf_chain mode 2 is not bit-stable"
 
 
+@pytest.mark.parametrize("B,HW", [(1, 64), (3, 1024)])
+def test_xf_chain_entry_groupnorm_folded(cuda, B, HW):
+    """xf_chain mode 2 on the RAW tensor with the transformer's entry GroupNorm applied in the operand load (statistics records of x):
+    bit-identical to dmx_groupnorm_from_stats followed by the plain mode 2, and close to a torch fp32 GroupNorm reference"""
+    from diffute_amd import ops
+    C, G, M = 320, 32, B * HW
+    x = bf(seeded((B, HW, C), 41, 1.5) + seeded((1, 1, C), 42, 2.0))          # per-channel offsets: the mean matters
+    wpi = bf(seeded((C, C), 43, 1 / math.sqrt(C))); bpi = seeded((C,), 44, 0.1)
+    wqkv = bf(seeded((3 * C, C), 45, 1 / math.sqrt(C))); gamma = 1 + seeded((C,), 46, 0.2); beta = seeded((C,), 47, 0.2)
+    gg = 1 + seeded((C,), 48, 0.3); gb = seeded((C,), 49, 0.3)
+    wf, c1, c2 = _ln_fold(wqkv, gamma, beta)
+    dv = lambda v, dt=torch.bfloat16: v.to(cuda).to(dt).contiguous()
+    f32 = lambda v: v.to(cuda).float().contiguous()
+    xd = dv(x).view(B, 1, HW, C)
+    st = ops.colstats(xd)
+    n = ops.groupnorm_from_stats(xd, st, f32(gg), f32(gb), G, 1e-6, False)
+    n_ref = bf(F.group_norm(x.float().permute(0, 2, 1), G, gg, gb, 1e-6).permute(0, 2, 1))
+    assert_close(n.view(B, HW, C), n_ref, 2e-3, "groupnorm_from_stats")
+    h_a, qkv_a = ops.xf_chain(2, n.view(M, C), None, dv(wpi), f32(bpi), f32(c1), f32(c2), w1=dv(wf))
+    h_b, qkv_b = ops.xf_chain(2, xd.view(M, C), None, dv(wpi), f32(bpi), f32(c1), f32(c2), w1=dv(wf), gn=(st, f32(gg), f32(gb), G, HW, 1e-6))
+    assert torch.equal(h_a, h_b) and torch.equal(qkv_a, qkv_b), "folded entry GroupNorm differs from GroupNorm + plain chain"
+    h0 = bf(F.linear(n_ref.reshape(M, C), wpi, bpi))
+    assert_close(h_b, h0, 3e-3, "xf_chain mode 2 with the folded GroupNorm: proj_in")
+
+
 def test_xf_chain_two_rounds_and_fp16_build(cuda):
     """xf_chain on more 64-row blocks than CUs (300: two rounds of the one-block-per-CU grid), bf16 build, and all three modes on
     the fp16 build of the library (same sources, -DDMX_F16) against fp32 math on fp16-rounded operands."""
