@@ -86,6 +86,7 @@ _PROTOS = {
     "dmx_conv3x3_gn": (c_int, [POINTER(HaloConvDesc), _P, c_size_t, _P]),
     "dmx_colstats": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "dmx_set_halo_conv": (c_int, [c_int]),
+    "dmx_set_halo_ws": (c_int, [c_int]),
     "dmx_xf_chain_ok": (c_int, [c_int, c_int]),
     "dmx_xf_chain": (c_int, [POINTER(XfChainDesc), c_int, _P]),
     "dmx_set_xf_chain": (c_int, [c_int]),

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
           }
       }
       auto exponentiate = [&](float mc) {
-        float psum = 0.f;
+        f32x2 ps2 = {0.f, 0.f};                       // (even, odd) scores of the pairs: one v_pk_add_f32 per pair
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -236,16 +236,19 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
             unsigned int w[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float a0 = __builtin_fmaf(s[j][kt][8 * u + 2 * e], sl2, mc), a1 = __builtin_fmaf(s[j][kt][8 * u + 2 * e + 1], sl2, mc);
+              // (one v_pk_fma_f32 per score pair: the accumulator registers of a pair are consecutive)
+              const f32x2 sv = {s[j][kt][8 * u + 2 * e], s[j][kt][8 * u + 2 * e + 1]};
+              const f32x2 av = __builtin_elementwise_fma(sv, (f32x2){sl2, sl2}, (f32x2){mc, mc});
+              const float a0 = av.x, a1 = av.y;
               const float p0 = (PROBE & 1) ? a0 : __builtin_amdgcn_exp2f(a0);
               const float p1 = (PROBE & 1) ? a1 : __builtin_amdgcn_exp2f(a1);
-              if (!(PROBE & 2)) psum += p0 + p1;
+              if (!(PROBE & 2)) ps2 += (f32x2){p0, p1};
               w[e] = pack_bf2(p0, p1);
             }
             u32x4 wv = {w[0], w[1], w[2], w[3]};
             pf[j][2 * kt + u] = __builtin_bit_cast(bf16x8, wv);
           }
-        return psum;
+        return ps2.x + ps2.y;
       };
       float psum = exponentiate(-m_run[j] * sl2);
       if (__any(!(psum <= 8192.0f)) && !(PROBE & 4)) {   // some score is far above the reference max (or there is none yet)

@@ -48,9 +48,17 @@ constexpr int HB_PATCH = 44032;            // patch buffer: 2752 pieces of 16 B 
 //   WNW = waves along the channel axis (1 or 2).  WMW x WNW = 8 waves: two-group ping-pong K loop; 16 waves (8 x 2, 32 x 16 NF wave tiles,
 //   <= 128 registers per lane, four waves per SIMD): lock step, one barrier per tap - what bounds the 8-wave loop is every wave's SERIAL
 //   non-MFMA work per tap (DMA issue, normalisation, addressing), and twice the waves halve it per wave at 1.55 x the LDS fragment bytes
-template <int NF, int WMW, int WNW> struct HaloLds {
-  static constexpr int NT = 64 * WMW * WNW;           // threads
-  static constexpr bool PP = (WMW * WNW == 8);        // two-group ping-pong (8 waves) / lock step (16 waves)
+//   WS (warp-specialised; 4 x 1 compute waves of 64-pixel x 160 / 128-column tiles + four LOADER waves): the compute waves only read
+//   fragments and issue MFMAs, the loaders issue every LDS-DMA instruction and normalise the patches - one barrier per tap.  What bounds a
+//   ping-pong step is the DMA phase of a group (each LDS-DMA instruction holds its wave ~100 cycles; 6-7 per wave and tap plus the
+//   normalisation is longer than the partner's 640 cycles of MFMAs), and the 64 x 80 wave tiles read 144 KB of fragments per tap (88 % of
+//   the LDS bandwidth under the MFMAs); here the loaders have the whole tap for the same DMA work and the fragment reads are 112 KB
+template <int NF, int WMW, int WNW, bool WS_ = false> struct HaloLds {
+  static constexpr bool WS = WS_;
+  static constexpr int NCW = WMW * WNW;               // compute waves
+  static constexpr int NT = 64 * NCW + (WS ? 256 : 0);   // threads (WS: + four loader waves)
+  static constexpr int DNT = WS ? 256 : NT;           // threads that issue DMA / normalise (WS: the last 256 threads of the block)
+  static constexpr bool PP = !WS && (NCW == 8);       // two-group ping-pong (8 waves)
   static constexpr int BN = WNW * 16 * NF;
   static constexpr int MFR = 16 / WMW;                // 16-pixel fragments per wave
   // TPS = taps per pipeline step: the narrow tiles have the LDS for TWO weight tiles per ring stage (2 x 10 KB = one stage of the
@@ -80,7 +88,8 @@ template <int NF, int WMW, int WNW> struct HaloLds {
 // position of the last read the group needs.  Group g = (tap t, k-step kk, weight fragment j), gl = g % (2 NF).  Issue order:
 // X0(tap 0)[0 .. MFR) before the barrier, W[0], W[1], then in front of group g: X1(t)[gl] (gl < MFR), X0(t + 1)[gl - NF]
 // (NF <= gl < NF + MFR, not the last tap), W[g + 2].
-constexpr int hb_wait(int NF, int MFR, int TAPS, int g) {
+// PF: the last tap also prefetches the X0 fragments of the NEXT call's first tap (they stay in flight across the call boundary).
+constexpr int hb_wait(int NF, int MFR, int TAPS, int g, bool PF = false) {
   const int G = TAPS * 2 * NF;
   int pos = MFR + 2, posW[48] = {}, posX0[4][4] = {}, posX1[4][4] = {};
   for (int i = 0; i < MFR; ++i) posX0[0][i] = i;
@@ -90,7 +99,7 @@ constexpr int hb_wait(int NF, int MFR, int TAPS, int g) {
     const int t = q / (2 * NF), gl = q - t * 2 * NF;
     if (q == g) issued_at_wait = pos;
     if (gl < MFR) posX1[t][gl] = pos++;
-    if (t + 1 < TAPS && gl >= NF && gl < NF + MFR) posX0[t + 1][gl - NF] = pos++;
+    if ((t + 1 < TAPS || PF) && gl >= NF && gl < NF + MFR) posX0[t + 1][gl - NF] = pos++;
     if (q + 2 < G) posW[q + 2] = pos++;
   }
   const int t = g / (2 * NF), gl = g - t * 2 * NF;
@@ -100,16 +109,19 @@ constexpr int hb_wait(int NF, int MFR, int TAPS, int g) {
   return issued_at_wait - 1 - need;
 }
 
-template <int NF, int WMW, int WNW>
-__global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_kernel(const HaloConvArgs p) {
-  typedef HaloLds<NF, WMW, WNW> L;
-  constexpr int BN = L::BN, WSTAGE = L::WSTAGE, WTILE = L::WTILE, TPS = L::TPS, MFR = L::MFR, NSTG = L::NSTG, HB_NT = L::NT;
+template <int NF, int WMW, int WNW, bool WS = false>
+__global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW, WNW, WS>::NT + 255) / 256)) void dmx_conv_halo_kernel(const HaloConvArgs p) {
+  typedef HaloLds<NF, WMW, WNW, WS> L;
+  constexpr int BN = L::BN, WSTAGE = L::WSTAGE, WTILE = L::WTILE, TPS = L::TPS, MFR = L::MFR, NSTG = L::NSTG, HB_NT = L::NT, DNT = L::DNT, NCW = L::NCW;
   constexpr bool PP = L::PP;
   constexpr int PD = PP ? 1 : 2;                       // prefetch distance of the weight tiles (taps): the ping-pong keeps one stage for the partner group
-  constexpr int NPP = (HB_PATCH / 16 + HB_NT - 1) / HB_NT;   // patch pieces per thread (6 / 3)
+  constexpr int NPP = (HB_PATCH / 16 + DNT - 1) / DNT; // patch pieces per DMA thread (6; WS: 11)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave % WMW, wn = wave / WMW;
+  // DMA / normalisation roles: every thread (dt = t), or the loader waves of the warp-specialised instances (the last DNT threads)
+  const int dt = t - (HB_NT - DNT), dwave = wave - (HB_NT - DNT) / 64;
+  const bool loader = !WS || wave >= NCW;
   const int lr = lane & 15, lq = lane >> 4;
   // measurement aids, probe builds only (-DDMX_PROBES; they cost registers in the K loop): HaloConvArgs.dbg ablation switches (results
   // invalid: 1 no MFMA phase, 2 no weight DMA, 4 no normalisation, 8 no patch DMA, 16 no barriers) and .timing phase timestamps
@@ -165,19 +177,19 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   int ppix[NPP];
 #pragma unroll
   for (int i = 0; i < NPP; ++i) {
-    const int q = t + HB_NT * i, prow = q >> 3;
+    const int q = (dt < 0 ? 0 : dt) + DNT * i, prow = q >> 3;
     const int py = hb_div(prow, p.mg_pw), px = prow - py * PW;
     const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
     ppix[i] = (q < npiece && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (b * p.H + iy) * p.W + ix : -1;
   }
-  const int pslot = ((t & 7) ^ ((t >> 3) & 7)) * 8;    // source channel octet of every piece of this thread ((q >> 3) & 7 = (t >> 3) & 7)
+  const int pslot = ((dt & 7) ^ ((dt >> 3) & 7)) * 8;  // source channel octet of every piece of this thread ((q >> 3) & 7 = (dt >> 3) & 7)
   // weight pieces: instruction j = wave + 8 i covers tile rows 8 j .. 8 j + 7
-  constexpr int WI = (BN * 8 + HB_NT - 1) / HB_NT;     // rounds of DMA instructions per weight tile (BN / 8 instructions over the block's waves)
-  constexpr int NWV = HB_NT / 64;
+  constexpr int WI = (BN * 8 + DNT - 1) / DNT;         // rounds of DMA instructions per weight tile (BN / 8 instructions over the DMA waves)
+  constexpr int NWV = DNT / 64;
   // (byte offset of this thread's piece of instruction 0 inside the [BN][ldw] weight slab; instruction i is 64 rows further)
   const char* const wslab = (const char*)(p.w + (size_t)n0 * p.ldw);
-  const unsigned woff0 = (unsigned)(((t >> 3) * p.ldw + (((t & 7) ^ ((t >> 3) & 7)) * 8)) * 2);
-  const unsigned wstep = (unsigned)((HB_NT / 8) * p.ldw * 2);
+  const unsigned woff0 = (unsigned)(((dt >> 3) * p.ldw + (((dt & 7) ^ ((dt >> 3) & 7)) * 8)) * 2);
+  const unsigned wstep = (unsigned)((DNT / 8) * p.ldw * 2);
   const char* zp = (const char*)p.zeros;
 
   auto dma = [&](const char* src, int lds_off) {
@@ -188,10 +200,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     int n = 0;
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      if ((wave + NWV * i) * 64 >= BN * 8) continue;   // wave-uniform (BN / 8 instructions over the waves: the last round is the low waves only)
+      if ((dwave + NWV * i) * 64 >= BN * 8) continue;  // wave-uniform (BN / 8 instructions over the waves: the last round is the low waves only)
       unsigned off = woff0 + wstep * i;
       asm volatile("" : "+v"(off));
-      dma(wslab + koff * 2 + off, lds_tile + (wave * 64 + HB_NT * i) * 16);
+      dma(wslab + koff * 2 + off, lds_tile + (dwave * 64 + DNT * i) * 16);
       ++n;
     }
     return n;
@@ -204,7 +216,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   };
   // K offset of the weight tile of pipeline step g (-1 outside this block's slice)
   auto koff_of = [&](int g) -> long {
@@ -221,8 +237,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     const int c0 = (ch - nc) * 64; return c0 < p.cs0 ? PDesc{p.s0 + c0, p.lds0, 2, ch} : PDesc{p.s1 + (c0 - p.cs0), p.lds1, 2, ch};
   };
   auto spix = [&](int i) {                             // shortcut pieces: image pixel of tile pixel (t + 512 i) >> 3
-    int tt = t; asm volatile("" : "+v"(tt));
-    const int pp = (tt + HB_NT * i) >> 3; return (b * p.H + ty0 + (pp >> twsh)) * p.W + tx0 + (pp & (TW - 1));
+    int tt = dt; asm volatile("" : "+v"(tt));
+    const int pp = (tt + DNT * i) >> 3; return (b * p.H + ty0 + (pp >> twsh)) * p.W + tx0 + (pp & (TW - 1));
   };
   auto issue_coef = [&](const PDesc& d) -> int {        // (all return the number of DMA instructions this wave issued)
     if (d.mode != 1 || !p.gn) return 0;
@@ -231,12 +247,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     return 1;
   };
   auto issue_piece = [&](const PDesc& d, int pb, const int i) -> int {
-    if (d.mode == 0 || (d.mode == 2 && (wave * 64 + HB_NT * i) >= 2048)) return 0;                 // (shortcut chunk: 2048 pieces = the 256 centre pixels)
-    if (d.mode == 1 && (wave * 64 + HB_NT * i) >= npiece) return 0;        // wave-uniform: this instruction lies beyond the patch
+    if (d.mode == 0 || (d.mode == 2 && (dwave * 64 + DNT * i) >= 2048)) return 0;                 // (shortcut chunk: 2048 pieces = the 256 centre pixels)
+    if (d.mode == 1 && (dwave * 64 + DNT * i) >= npiece) return 0;         // wave-uniform: this instruction lies beyond the patch
     int pix = d.mode == 1 ? ppix[i] : spix(i);
     asm volatile("" : "+v"(pix));                      // keep the address arithmetic here: hoisted out of the chunk loop it is 40 registers of pointers
     const char* src = pix >= 0 ? (const char*)(d.base + (size_t)pix * d.ld + pslot) : zp;
-    dma(src, pb + (wave * 64 + HB_NT * i) * 16);
+    dma(src, pb + (dwave * 64 + DNT * i) * 16);
     return 1;
   };
 
@@ -262,14 +278,20 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   // patch is stable), W[0], W[1], then in front of group g: X1[g] (g < 4) and W[g + 2]; weight fragments rotate through three
   // register sets.  Group g needs W[g] (and X0 / X1 at g = 0 / NF): reads issued after it = [g - 1 < 4] + [g + 1 < 2 NF].
 #define HB_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#ifdef DMX_F16
+#define HB_MFMA_OP "v_mfma_f32_16x16x32_f16"
+#else
+#define HB_MFMA_OP "v_mfma_f32_16x16x32_bf16"
+#endif
   u32x4 fx0[MFR], fx1[MFR], fw[3];
   auto mma_pre = [&](const unsigned* xa) {
 #pragma unroll
     for (int i = 0; i < MFR; ++i) HB_DSR(fx0[i], xa[i], 0);
   };
   // xa: [TAPS][MFR] fragment addresses of the taps, wbase: [TAPS] LDS addresses of their weight tiles
-  auto mma_stream = [&](auto TAPS_, const unsigned* xa, const unsigned* wbase) {
+  auto mma_stream = [&](auto TAPS_, const unsigned* xa, const unsigned* wbase, auto PF_) {
     constexpr int TAPS = decltype(TAPS_)::value, G = TAPS * 2 * NF;
+    constexpr bool PF = decltype(PF_)::value;          // xa[TAPS * MFR ..): the X0 fragments of the next call's first tap, requested under the last tap's MFMAs
     unsigned wb[TAPS][2];
 #pragma unroll
     for (int tt = 0; tt < TAPS; ++tt) { wb[tt][0] = wbase[tt] + wad0; wb[tt][1] = wbase[tt] + (wad0 ^ 64); }
@@ -281,7 +303,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
         case 1: HB_DSR(fw[g2 % 3], wsel, 2048); break;
         case 2: HB_DSR(fw[g2 % 3], wsel, 2 * 2048); break;
         case 3: HB_DSR(fw[g2 % 3], wsel, 3 * 2048); break;
-        default: HB_DSR(fw[g2 % 3], wsel, 4 * 2048); break;
+        case 4: HB_DSR(fw[g2 % 3], wsel, 4 * 2048); break;
+        case 5: HB_DSR(fw[g2 % 3], wsel, 5 * 2048); break;
+        case 6: HB_DSR(fw[g2 % 3], wsel, 6 * 2048); break;
+        case 7: HB_DSR(fw[g2 % 3], wsel, 7 * 2048); break;
+        case 8: HB_DSR(fw[g2 % 3], wsel, 8 * 2048); break;
+        default: HB_DSR(fw[g2 % 3], wsel, 9 * 2048); break;
       }
     };
     rd_w(0); rd_w(1);
@@ -298,7 +325,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
         if constexpr (MFR == 4) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(fx1[0]), "+v"(fx1[1]), "+v"(fx1[2]), "+v"(fx1[3]), "+v"(fw[g % 3]) :: "memory"); \
         else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(fx1[0]), "+v"(fx1[1]), "+v"(fw[g % 3]) :: "memory");                      \
       } else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(fw[g % 3]) :: "memory");
-      switch (hb_wait(NF, MFR, TAPS, g)) {           // (g is a constant after unrolling; the immediate has to be a literal)
+      switch (hb_wait(NF, MFR, TAPS, g, PF)) {           // (g is a constant after unrolling; the immediate has to be a literal)
         case 0: HB_WAIT(0) break;
         case 1: HB_WAIT(1) break;
         case 2: HB_WAIT(2) break;
@@ -308,16 +335,21 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #undef HB_WAIT
       __builtin_amdgcn_sched_barrier(0);
       if (gl < MFR) { const unsigned x1 = xa[tt * MFR + gl] ^ 64; HB_DSR(fx1[gl], x1, 0); }
-      if (tt + 1 < TAPS && gl >= NF && gl < NF + MFR) HB_DSR(fx0[gl - NF], xa[(tt + 1) * MFR + gl - NF], 0);
+      if ((tt + 1 < TAPS || PF) && gl >= NF && gl < NF + MFR) HB_DSR(fx0[gl - NF], xa[(tt + 1) * MFR + gl - NF], 0);
       if (g + 2 < G) rd_w(g + 2);
-      const bf16x8 wv = __builtin_bit_cast(bf16x8, fw[g % 3]);
+      // (the MFMAs as asm with the accumulator tied in place: left to the compiler every MFMA of this stream writes a NEW register quad -
+      // the accumulator set migrates through the file and the stream needs ~100 registers on top of it; nothing reads an accumulator
+      // sooner than a whole k-step later, so no software wait states are due)
 #pragma unroll
-      for (int i = 0; i < MFR; ++i) acc[j][i] = DMX_MFMA_16x16x32(wv, __builtin_bit_cast(bf16x8, kk ? fx1[i] : fx0[i]), acc[j][i]);
+      for (int i = 0; i < MFR; ++i) {
+        if (kk) asm volatile(HB_MFMA_OP " %0, %1, %2, %0" : "+v"(acc[j][i]) : "v"(fw[g % 3]), "v"(fx1[i]));
+        else asm volatile(HB_MFMA_OP " %0, %1, %2, %0" : "+v"(acc[j][i]) : "v"(fw[g % 3]), "v"(fx0[i]));
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto mma_post = [&](const unsigned* xa, unsigned wbase, auto&&) { mma_stream(std::integral_constant<int, 1>{}, xa, &wbase); };
+  auto mma_post = [&](const unsigned* xa, unsigned wbase, auto&&) { mma_stream(std::integral_constant<int, 1>{}, xa, &wbase, std::false_type{}); };
   auto xa_main = [&](int pb, int tapoff, unsigned* xa) {
     int pr = xrow0;
     asm volatile("" : "+v"(pr));                       // (the tap addresses are loop-invariant: hoisted they would live across the whole K loop)
@@ -351,7 +383,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   // reads of the piece and of its 8 channels' (a, s), in the DMA phase), nrm_slice(e) (element e: fma, SiLU - after MFMA group e), nrm_store.
   u32x4 nrm_x; f32x4 nrm_c[4]; float nrm_y[8]; int nrm_q = -1;
   auto nrm_load = [&](int pb, const int i) {           // (call only with p.gn; every lane loads - lanes beyond the patch re-read piece 0 and store nothing)
-    const int q = t + HB_NT * i;
+    const int q = dt + DNT * i;
     nrm_q = q >= npiece ? -1 : (ppix[i] < 0 ? -2 - q : q);                 // (padding pieces are written as zeros: the conv pads the NORMALISED tensor)
     nrm_x = *(const u32x4*)(smem + pb + (q >= npiece ? 0 : q) * 16);
     const float* cf = (const float*)(smem + L::COEF) + pslot * 2;
@@ -386,7 +418,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
   // of this block's sample
   int cur = ch_first, seq = 0;
   int gstep = cur < nc ? 9 * cur : 9 * nc + (cur - nc);   // pipeline step of the chunk's first step (inactive steps of a partial chunk included)
-  {
+  if (loader) {
     const PDesc d = pdesc(cur);
     issue_coef(d);
 #pragma unroll
@@ -433,16 +465,26 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     coef_table(cur);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-      u32x4 px[NPP];
+      // (every thread of the block takes pieces here - the requests are confirmed and behind a barrier; in the K loop a DMA thread
+      // normalises the pieces it requested itself)
+      constexpr int NPA = (HB_PATCH / 16 + HB_NT - 1) / HB_NT;
+      const int pslot_a = ((t & 7) ^ ((t >> 3) & 7)) * 8;
+      u32x4 px[NPA];
 #pragma unroll
-      for (int i = 0; i < NPP; ++i) { const int q = t + HB_NT * i; px[i] = *(const u32x4*)(smem + L::PATCH0 + (q >= npiece ? 0 : q) * 16); }
-      const float* cf = (const float*)(smem + L::COEF) + pslot * 2;
+      for (int i = 0; i < NPA; ++i) { const int q = t + HB_NT * i; px[i] = *(const u32x4*)(smem + L::PATCH0 + (q >= npiece ? 0 : q) * 16); }
+      const float* cf = (const float*)(smem + L::COEF) + pslot_a * 2;
       f32x4 cc[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) cc[k] = *(const f32x4*)(cf + 4 * k);
 #pragma unroll
-      for (int i = 0; i < NPP; ++i) {
+      for (int i = 0; i < NPA; ++i) {
         const int q = t + HB_NT * i;
+        bool pad;
+        if constexpr (WS) {
+          const int prow = q >> 3, py = hb_div(prow, p.mg_pw), px_ = prow - py * PW;
+          const int iy = ty0 - 1 + py, ix = tx0 - 1 + px_;
+          pad = !(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W);
+        } else pad = ppix[i] < 0;
         float f[8]; unpack_bf8(px[i], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -451,7 +493,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
           f[e] = y;
         }
         u32x4 o = pack_bf8(f);
-        if (ppix[i] < 0) o = u32x4{0u, 0u, 0u, 0u};
+        if (pad) o = u32x4{0u, 0u, 0u, 0u};
         if (q < npiece) *(u32x4*)(smem + L::PATCH0 + q * 16) = o;
       }
     }
@@ -520,7 +562,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
       // ---- MFMA phase
       if (active && !(DBG & 1)) {
         const unsigned wbs[2] = {lds0 + (rs % 3) * WSTAGE, lds0 + (rs % 3) * WSTAGE + WTILE};
-        mma_stream(std::integral_constant<int, nt>{}, xa, wbs);
+        mma_stream(std::integral_constant<int, nt>{}, xa, wbs, std::false_type{});
       }
       if constexpr (k >= 2) { if (nrm) norm_piece(pbn, 2 * (k - 2) + 1); }
       wait_vm(0);                                        // this wave's requests of this step's DMA phase have landed
@@ -547,7 +589,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     mma_pre(xa);
     __builtin_amdgcn_s_barrier();
     const unsigned wb1 = lds0 + (rs % 3) * WSTAGE;
-    mma_stream(std::integral_constant<int, 1>{}, xa, &wb1);
+    mma_stream(std::integral_constant<int, 1>{}, xa, &wb1, std::false_type{});
     wait_vm(0);                                        // (the next shortcut patch and weight tile have landed)
     __builtin_amdgcn_s_barrier();
     gstep += 1; ++seq; ++rs;
@@ -618,78 +660,112 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     cur = next;                                        // (-1 ends the loop)
   }
   } else {
-  // ---- K loop, 16-wave instances: LOCK STEP, one barrier per tap, four waves per SIMD (their stalls overlap without choreography).
-  // Step s: [this wave's DMA of step s - 2 and older has landed: counted vmcnt, the requests of step s - 1 stay in flight] [barrier]
-  // [DMA: steps 0 / 1 the next chunk's patch, then the weight tile of tap s + 2 into the stage tap s - 1 has just freed] [step 2: the
-  // next chunk's (a, s) table; steps 3.. : one piece of its normalisation] [MFMA tap s].
-  int n_prev = 0;                                      // DMA instructions this wave issued in the previous step
-  while (cur >= 0 && cur < nc) {
-    const int next = cur < ch_last ? cur + 1 : -1;
-    const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0, pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
-    const PDesc dn = pdesc(next);
-    auto step = [&](auto S_) {
-      constexpr int s = decltype(S_)::value;
-      const int g = gstep + s;
-      const bool active = g >= sb && g < se;
-      wait_vm(n_prev);
+  // ---- K loop, warp-specialised instances: waves 0 .. 3 COMPUTE (fragment reads + MFMAs of tap s), waves 4 .. 7 LOAD (the weight tile of
+  // tap s + 2 into the ring stage tap s - 1 has just freed; in steps 0 .. 2 the next chunk's patch; step 3: its (a, s) table; steps 3 .. 8:
+  // two pieces of its normalisation per step).  ONE barrier per tap: behind barrier s the loaders' requests of step s - 1 and older have
+  // landed (counted vmcnt: only the requests of the step itself stay in flight) and their LDS writes are complete, and the compute waves
+  // have finished the fragment reads of tap s - 1.  A compute wave requests the first fragments of tap s + 1 under the last MFMAs of tap s
+  // (same patch: stable), so only the first tap of a chunk starts with an exposed LDS round trip.
+  static_assert(!WS || (NSTG == 3 && PD == 2), "warp-specialised schedule: three ring stages, weights two taps ahead");
+  static_assert(!WS || NPP <= 12, "warp-specialised schedule: at most twelve patch pieces per loader thread");
+  // (two separate loops, not one loop with a role branch inside: the compiler cannot know that the role never changes, and would keep
+  // the loaders' piece table and the compute waves' fragments alive through each other's code on top of the 160 accumulator registers)
+  if (loader) {
+    while (cur >= 0 && cur < nc) {
+      const int next = cur < ch_last ? cur + 1 : -1;
+      const int pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
+      const PDesc dn = pdesc(next);
+      auto step = [&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        const int g = gstep + s;
+        if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+        int n = 0;
+        if (!(DBG & 8)) {
+          if constexpr (s == 0) n += issue_coef(dn);
+          if constexpr (s < 3) {
+#pragma unroll
+            for (int i = 4 * s; i < 4 * s + 4 && i < NPP; ++i) n += issue_piece(dn, pbn, i);
+          }
+        }
+        if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) n += issue_w(kn, ((g + PD) % NSTG) * WSTAGE); }
+        if constexpr (s == 3) { if (dn.mode == 1) coef_table(next); }
+        if constexpr (s >= 3) {
+          if (dn.mode == 1 && !(DBG & 4)) {
+            norm_piece(pbn, 2 * (s - 3));
+            if constexpr (2 * (s - 3) + 1 < NPP) norm_piece(pbn, 2 * (s - 3) + 1);
+          }
+        }
+        wait_vm(n);                                      // everything requested before this step has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+      gstep += 9; ++seq;
+      cur = next;
+    }
+    // shortcut steps: the next shortcut patch requested one step ahead into the other patch buffer (confirmed in the same step: its request
+    // goes out BEFORE the weight tile's, the counted wait leaves only that in flight), the weight tile two steps ahead
+    while (cur >= nc) {
+      const int next = cur < ch_last ? cur + 1 : -1;
+      const int pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
+      const PDesc dn = pdesc(next);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int i = 0; i < NPP; ++i) issue_piece(dn, pbn, i);
+      int nwt = 0;
+      { const long kn = koff_of(gstep + PD); if (kn >= 0) nwt = issue_w(kn, ((gstep + PD) % NSTG) * WSTAGE); }
+      wait_vm(nwt);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
-      int n = 0;
-      if (!(DBG & 8)) {
-        constexpr int H0 = (NPP + 1) / 2;              // pieces requested in step 0, the rest in step 1
-        if constexpr (s == 0) { n += issue_coef(dn);
-#pragma unroll
-          for (int i = 0; i < H0; ++i) n += issue_piece(dn, pbn, i); }
-        if constexpr (s == 1) {
-#pragma unroll
-          for (int i = H0; i < NPP; ++i) n += issue_piece(dn, pbn, i); }
-      }
-      if (!(DBG & 2)) { const long kn = koff_of(g + PD); if (kn >= 0) n += issue_w(kn, ((g + PD) % NSTG) * WSTAGE); }
-      n_prev = n;
-      // (a thread normalises the pieces it requested itself: those of step 0 / 1 are confirmed by the waits of steps 2 / 3)
-      if constexpr (s == 2) { if (dn.mode == 1) coef_table(next); }
-      if constexpr (s >= 3 && s - 3 < NPP) { if (dn.mode == 1 && !(DBG & 4)) norm_piece(pbn, s - 3); }
-      __builtin_amdgcn_sched_barrier(0);               // (the normalisation's registers are dead before the fragments' come alive: 128 per lane)
-      if (active && !(DBG & 1)) {
-        unsigned xa[MFR];
-        xa_main(pb, (s / 3) * PW + (s % 3), xa);
-        mma_pre(xa);
-        mma_post(xa, lds0 + (g % NSTG) * WSTAGE, [&](auto, const int) {});
-      }
-    };
-    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-    gstep += 9; ++seq;
-    cur = next;
-  }
-  // ---- shortcut steps: the next shortcut patch requested one step ahead into the other patch buffer, the weight tile two steps ahead
-  while (cur >= nc) {
-    const int next = cur < ch_last ? cur + 1 : -1;
-    const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0, pbn = (seq & 1) ? L::PATCH0 : L::PATCH1;
-    const PDesc dn = pdesc(next);
-    // everything but the weight tile requested in the previous step has landed (its patch request was issued BEFORE it)
-    int nwprev = n_prev; if (nwprev > WI) nwprev = WI;
-    wait_vm(nwprev);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int n = 0, nwt = 0;
-#pragma unroll
-    for (int i = 0; i < NPP; ++i) n += issue_piece(dn, pbn, i);
-    { const long kn = koff_of(gstep + PD); if (kn >= 0) nwt = issue_w(kn, ((gstep + PD) % NSTG) * WSTAGE); }
-    n_prev = nwt; (void)n;
-    unsigned xa[MFR];
-    xa_sc(pb, xa);
-    mma_pre(xa);
-    mma_post(xa, lds0 + (gstep % NSTG) * WSTAGE, [&](auto, const int) {});
-    gstep += 1; ++seq;
-    cur = next;                                        // (-1 ends the loop)
+      gstep += 1; ++seq;
+      cur = next;                                        // (-1 ends the loop)
+    }
+  } else {
+    while (cur >= 0 && cur < nc) {
+      const int next = cur < ch_last ? cur + 1 : -1;
+      const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0;
+      auto step = [&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        const int g = gstep + s;
+        const bool active = g >= sb && g < se;
+        if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+        // (ONE branch around the whole tap and no variants inside it: with run-time variants of the stream the accumulators come out of
+        // the merges in different registers - copies and spills by the hundred)
+        if (active && !(DBG & 1)) {
+          unsigned xa[2 * MFR];
+          xa_main(pb, (s / 3) * PW + (s % 3), xa);
+          if constexpr (s < 8) xa_main(pb, ((s + 1) / 3) * PW + ((s + 1) % 3), xa + MFR);
+          // taps 1 .. 8 find their first fragments requested by the previous tap (same patch: stable) unless the slice starts here
+          if (s == 0 || g == sb) mma_pre(xa);
+          const unsigned wb1 = lds0 + (g % NSTG) * WSTAGE;
+          mma_stream(std::integral_constant<int, 1>{}, xa, &wb1, std::integral_constant<bool, (s < 8)>{});
+        }
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+      gstep += 9; ++seq;
+      cur = next;
+    }
+    while (cur >= nc) {
+      const int next = cur < ch_last ? cur + 1 : -1;
+      const int pb = (seq & 1) ? L::PATCH1 : L::PATCH0;
+      __builtin_amdgcn_s_barrier();
+      unsigned xa[MFR];
+      xa_sc(pb, xa);
+      mma_pre(xa);
+      const unsigned wb1 = lds0 + (gstep % NSTG) * WSTAGE;
+      mma_stream(std::integral_constant<int, 1>{}, xa, &wb1, std::false_type{});
+      gstep += 1; ++seq;
+      cur = next;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                        // every wave is done with the ring and the patches: LDS is the epilogue's
   }
 #undef HB_DSR
+#undef HB_MFMA_OP
 
   if (TIMING) tm[2] = __builtin_amdgcn_s_memrealtime();
   // ---------------------------------------------------------------- epilogue
@@ -704,7 +780,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #pragma unroll
     for (int i = 0; i < MFR; ++i) {
       const int row0 = wm * (16 * MFR) + i * 16;
-      if (row0 / RO == r) continue;                    // wave-uniform
+      if (row0 / RO == r || (WS && wave >= NCW)) continue;   // wave-uniform (the loader waves hold no accumulators)
 #pragma unroll
       for (int j = 0; j < NF; ++j)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), rs, ((row0 + lr) * BN + wn * 16 * NF + j * 16 + 4 * lq) * 4, 0, 16);
@@ -799,7 +875,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
 #pragma unroll
     for (int i = 0; i < MFR; ++i) {
       const int row0 = wm * (16 * MFR) + i * 16;
-      if (row0 < prow0 || row0 >= prow0 + RPP) continue;
+      if (row0 < prow0 || row0 >= prow0 + RPP || (WS && wave >= NCW)) continue;
 #pragma unroll
       for (int j = 0; j < NF; ++j) *(f32x4*)(tile + (row0 - prow0 + lr) * LDT + wn * 16 * NF + j * 16 + 4 * lq) = acc[j][i];
     }
@@ -831,9 +907,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, WMW * WNW / 4) void dmx_conv_halo_k
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (TIMING) tm[4] = __builtin_amdgcn_s_memrealtime();
-    if (S == 2) items(std::integral_constant<int, 2>{}, std::integral_constant<int, PP ? KPP : 1>{}, own0);
-    else if (S == 4) items(std::integral_constant<int, 4>{}, std::integral_constant<int, PP ? (KPP + 1) / 2 : 1>{}, own0);
-    else if constexpr (PP) items(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, own0);      // (8-way splits: 8-wave instances only - the plan sees to it)
+    if (S == 2) items(std::integral_constant<int, 2>{}, std::integral_constant<int, PP ? KPP : (WS ? (KPP + 1) / 2 : 1)>{}, own0);
+    else if (S == 4) items(std::integral_constant<int, 4>{}, std::integral_constant<int, PP ? (KPP + 1) / 2 : (WS ? 2 : 1)>{}, own0);
+    else if constexpr (PP || WS) items(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, own0);      // (8-way splits: 8-wave instances only - the plan sees to it)
   }
   if (TIMING) tm[6] = __builtin_amdgcn_s_memrealtime();
   if (p.colstats) {
@@ -925,6 +1001,7 @@ int n_cus() {
 // slabs through memory ((S - 1) / S x 256 x BN x 4 bytes per block, written and read back) and the co-residency of a tile's blocks, so the
 // plan takes the narrow tiles where they make the split unnecessary or smaller; with tiles to spare the wide tile wins (twice the work per
 // weight byte and per barrier).  Costs in us, fitted on scripts/halo_probe.py.
+int g_halo_ws = 1;                                     // dmx_set_halo_ws: 0 = the planner never takes the warp-specialised instances (A/B aid)
 struct HaloPlan { int TH, TW, nf, wmw, bn, splits, waves; };
 HaloPlan halo_plan(const HaloConvArgs& a) {
   HaloPlan P{0, 0, 0, 0, 0, 0, 8};
@@ -950,10 +1027,16 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
       if (cost < best) { best = cost; P.nf = cand[c][0]; P.wmw = cand[c][1]; P.bn = bn; P.splits = s; }
     }
   }
-  // the 16-wave lock-step instances of the wide tiles are built, tested and SLOWER than the 8-wave ping-pong (64x64x320, K = 2880 / 5760 /
-  // 8640: 68 / 95 / 130 vs 60 / 87 / 118 us): force_waves = 16 only (tests, A/B)
-  P.waves = (a.force_waves == 16 && P.bn >= 128 && P.splits <= 4) ? 16 : 8;
-  if (a.force_waves == 16 && P.waves != 16) P.splits = 0;
+  // waves: 8 = two-group ping-pong, 4 = warp-specialised (4 compute + 4 loader waves; the wide tiles only).  (16-wave lock-step instances
+  // of the wide tiles were built in round 4 and measured slower than the ping-pong - 68 / 95 / 130 vs 60 / 87 / 118 us - and removed.)
+  // Measured (B = 4, stand-alone incl. GroupNorm, us; ping-pong / 4 + 4 / 8 + 4): 64x64x320 K = 2880 / 5760 / 8640 (two-way splits): 62.2 /
+  // 85.3 / 113.1 - 61.0 / 81.7 / 107.0 - 62.6 / 84.2 / 111.1; 32x32x640 K = 5760 (four-way): 59.5 - 64.3 - 66.9; 16x16x1280 K = 11520
+  // (eight-way): 58.8 - 70.0 - 77.6: the warp-specialised K loop is ~10 % faster per tap (1.02 vs 1.13 us), its epilogue with four / eight
+  // slabs per row in flight has fewer registers to hide them in -> 4 + 4 up to two-way splits, the ping-pong beyond
+  P.waves = 8;
+  if (P.bn >= 128 && P.splits <= 2 && g_halo_ws) P.waves = 4;
+  if (P.bn >= 128 && (a.force_waves == 4 || a.force_waves == 12 || a.force_waves == 8)) P.waves = a.force_waves;
+  if (a.force_waves && a.force_waves != P.waves) P.splits = 0;
   return P;
 }
 
@@ -963,6 +1046,7 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
 // Measured per shape inside the 50-step pass (B = 4; halo incl. GroupNorm vs conv + reduce + GroupNorm): 64x64 level 61 vs 69, 87 vs 105,
 // 119 vs 129 us; 32x32 level 63 vs 66, 89 vs 98, 124 vs 125; 16x16 level 64 vs 61, 85 vs 77, 48 vs 44 - the blocks of the deep levels
 // are 8-way K splits whose fp32 slab exchange costs what the fusion saves.
+extern "C" int dmx_set_halo_ws(int on) { const int old = g_halo_ws; g_halo_ws = on; return old; }
 bool dmx_conv_halo_pays(const HaloConvArgs& a) {
   if (!dmx_conv_halo_supported(a)) return false;
   return (long)a.H * a.W >= 1024;
@@ -994,9 +1078,9 @@ size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a) {
   return halo_flag_bytes((int)n) + (size_t)n * 256 * P.bn * sizeof(float);
 }
 
-template <int NF, int WMW, int WNW> static int halo_launch_(const HaloConvArgs& a, int blocks, hipStream_t stream) {
-  DMX_LDS_OPT_IN((dmx_conv_halo_kernel<NF, WMW, WNW>), (HaloLds<NF, WMW, WNW>::TOTAL));
-  hipLaunchKernelGGL((dmx_conv_halo_kernel<NF, WMW, WNW>), dim3(blocks), dim3(HaloLds<NF, WMW, WNW>::NT), (HaloLds<NF, WMW, WNW>::TOTAL), stream, a);
+template <int NF, int WMW, int WNW, bool WS = false> static int halo_launch_(const HaloConvArgs& a, int blocks, hipStream_t stream) {
+  DMX_LDS_OPT_IN((dmx_conv_halo_kernel<NF, WMW, WNW, WS>), (HaloLds<NF, WMW, WNW, WS>::TOTAL));
+  hipLaunchKernelGGL((dmx_conv_halo_kernel<NF, WMW, WNW, WS>), dim3(blocks), dim3(HaloLds<NF, WMW, WNW, WS>::NT), (HaloLds<NF, WMW, WNW, WS>::TOTAL), stream, a);
   return dmx_check_launch("dmx_conv_halo_kernel");
 }
 
@@ -1036,7 +1120,8 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
   char tag[96];
   snprintf(tag, sizeof(tag), "M=%d N=%d K=%d halo gn=%d bn=%d sk=%d", a.B * a.H * a.W, a.N, 9 * a.Cin + a.Csc, a.gn, P.bn, a.splits);
   ProfScope ps(PROF_HALO, stream, flops, bytes, tag);
-  if (P.waves == 16) return P.nf == 5 ? halo_launch_<5, 8, 2>(a, blocks, stream) : halo_launch_<4, 8, 2>(a, blocks, stream);
+  if (P.waves == 4) return P.nf == 5 ? halo_launch_<10, 4, 1, true>(a, blocks, stream) : halo_launch_<8, 4, 1, true>(a, blocks, stream);
+  if (P.waves == 12) return P.nf == 5 ? halo_launch_<5, 4, 2, true>(a, blocks, stream) : halo_launch_<4, 4, 2, true>(a, blocks, stream);
   if (P.nf == 5 && P.wmw == 4) return halo_launch_<5, 4, 2>(a, blocks, stream);
   if (P.nf == 4 && P.wmw == 4) return halo_launch_<4, 4, 2>(a, blocks, stream);
   if (P.nf == 5 && P.wmw == 8) return halo_launch_<5, 8, 1>(a, blocks, stream);

@@ -180,6 +180,7 @@ size_t dmx_conv3x3_gn_workspace_bytes(const dmx_halo_conv_desc* d);
 int dmx_conv3x3_gn(const dmx_halo_conv_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 int dmx_colstats(const void* x, int ldx, int B, int HW, int C, long long* st, dmx_stream_t stream);
 int dmx_set_halo_conv(int on);      /* tuning aid: 0 makes the model executors use GroupNorm + dmx_conv_gemm everywhere; returns the old setting */
+int dmx_set_halo_ws(int on);        /* tuning aid: 0 keeps dmx_conv3x3_gn's planner off the warp-specialised instances (4 compute + 4 loader waves); returns the old setting */
 
 /* The row-local chains of diffusers' BasicTransformerBlock + Transformer2DModel.proj_out (the unet(...) call at
  * /root/reference/app.ipynb:814) at the C = 320 levels, ONE launch each (xf_chain.hip); rows M % 64 == 0:

@@ -22,7 +22,8 @@ def timed():
 res = {1: [], 0: []}
 for r in range(rounds):
     for on in (1, 0):
-        lib.dmx_set_halo_conv(on)
+        if "--ws" in sys.argv: lib.dmx_set_halo_ws(on)       # the warp-specialised halo instances vs the ping-pong
+        else: lib.dmx_set_halo_conv(on)
         for attr in ("_slots", "_ws"):
             if hasattr(vae, attr) and isinstance(getattr(vae, attr), dict): getattr(vae, attr).clear()
         res[on].append(timed())

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffute_amd import ops
 ap = argparse.ArgumentParser(); ap.add_argument("shape", nargs="*", type=int, default=[4, 64, 64, 320, 0, 320, 0])
-ap.add_argument("--split", type=int, default=0); ap.add_argument("--bn", type=int, default=0); ap.add_argument("--dbg", type=int, default=0); ap.add_argument("--nogn", action="store_true")
+ap.add_argument("--split", type=int, default=0); ap.add_argument("--bn", type=int, default=0); ap.add_argument("--dbg", type=int, default=0); ap.add_argument("--waves", type=int, default=0); ap.add_argument("--nogn", action="store_true")
 a = ap.parse_args()
 B, H, W, C0, C1, N, Csc = a.shape
 dev = torch.device("cuda:0")
@@ -19,7 +19,7 @@ r = None if Csc else torch.randn(B, H, W, N, device=dev).to(torch.bfloat16)
 g = torch.ones(Cin, device=dev); be = torch.zeros(Cin, device=dev)
 st0 = ops.colstats(x0); st1 = ops.colstats(x1) if C1 else None
 tm = torch.zeros(4096 * 3, 8, dtype=torch.int64, device=dev)
-kw = dict(x1=x1, sc0=sc, bias=b, rowbias=te, res=r, out_stats=True, force_split=a.split, force_bn=a.bn, dbg=a.dbg)
+kw = dict(x1=x1, sc0=sc, bias=b, rowbias=te, res=r, out_stats=True, force_split=a.split, force_bn=a.bn, force_waves=a.waves, dbg=a.dbg)
 if not a.nogn: kw.update(gn=(g, be, 32, 1e-5, True), st0=st0, st1=st1)
 for i in range(3): ops.conv3x3_gn(x0, w, N, **kw)
 ops.conv3x3_gn(x0, w, N, timing=tm, **kw)

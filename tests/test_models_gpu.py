@@ -543,7 +543,8 @@ def test_fused_adamw_matches_torch(cuda):
         l_fus = mse_loss(fus(x, t, ctx).sample, target); l_fus.backward()
         opt_fus.step()
         # step 0: identical weights -> identical loss; later the fp32 masters agree to ~1e-7, which flips a few bf16 roundings
-        assert abs(float(l_ref.detach()) - float(l_fus.detach())) <= (1e-6 if step == 0 else 2e-4) * abs(float(l_ref.detach())), f"step {step}: losses diverged"
+        # (measured over kernel revisions: 1e-4 .. 4.4e-4 of the loss at step 1 - which roundings flip changes with any change of a summation order)
+        assert abs(float(l_ref.detach()) - float(l_fus.detach())) <= (1e-6 if step == 0 else 1e-3) * abs(float(l_ref.detach())), f"step {step}: losses diverged"
         assert abs(float(gn_ref) - float(opt_fus.grad_norm)) <= (1e-5 if step == 0 else 2e-3) * float(gn_ref)
         if step == 0:
             # identical weights and (deterministic) gradients went in: the updated masters must agree to fp32 rounding.

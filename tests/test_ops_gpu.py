@@ -652,13 +652,21 @@ HALO_CASES = [
     ("gn_16x16_w80_split4", 1, 16, 16, 640, 0, 320, 0, 0, True, 4, 80),
     ("gn_n128_w64_vae", 1, 32, 32, 128, 0, 128, 128, 0, True, 1, 64),
     ("gn_16x16_w64_split8", 1, 16, 16, 640, 640, 128, 0, 0, True, 8, 64),
-    # the 16-wave lock-step instances (160 / 128 columns, splits 1 / 2 / 4) and the 8-wave ping-pong instances of the same tiles
-    ("gn_64x64_320_16w_split2", 2, 64, 64, 320, 0, 320, 0, 0, True, 2, 160, 16),
-    ("gn_32x32_concat_sc_16w_split4", 1, 32, 32, 640, 320, 320, 640, 320, True, 4, 160, 16),
-    ("gn_32x32_16w_split1", 1, 32, 32, 320, 0, 320, 320, 0, True, 1, 160, 16),
-    ("gn_n128_16w_vae", 1, 64, 64, 128, 0, 256, 128, 0, True, 0, 128, 16),
+    # the warp-specialised instances of the wide tiles (last field: 4 = four 64 x 160 / 128 compute waves + four loader waves, 12 = eight
+    # 64 x 80 / 64 compute waves + four loader waves) and the 8-wave ping-pong instances of the same tiles
+    ("gn_64x64_320_ws4_split2", 2, 64, 64, 320, 0, 320, 0, 0, True, 2, 160, 4),
+    ("gn_32x32_concat_sc_ws4_split4", 1, 32, 32, 640, 320, 320, 640, 320, True, 4, 160, 4),
+    ("gn_32x32_ws4_split1", 1, 32, 32, 320, 0, 320, 320, 0, True, 1, 160, 4),
+    ("gn_n128_ws4_vae", 1, 64, 64, 128, 0, 256, 128, 0, True, 0, 128, 4),
+    ("plain_ws4_sc_only", 1, 16, 32, 64, 64, 160, 64, 64, False, 2, 160, 4),
+    ("gn_16x16_ws4_split8", 1, 16, 16, 640, 640, 160, 0, 0, True, 8, 160, 4),
+    ("gn_64x64_320_ws12_split2", 2, 64, 64, 320, 0, 320, 0, 0, True, 2, 160, 12),
+    ("gn_32x32_concat_sc_ws12_split4", 1, 32, 32, 640, 320, 320, 640, 320, True, 4, 160, 12),
+    ("gn_32x32_ws12_split1", 1, 32, 32, 320, 0, 320, 320, 0, True, 1, 160, 12),
+    ("gn_n128_ws12_vae", 1, 64, 64, 128, 0, 256, 128, 0, True, 0, 128, 12),
+    ("plain_ws12_sc_only", 1, 16, 32, 64, 64, 160, 64, 64, False, 2, 160, 12),
+    ("gn_16x16_ws12_split8", 1, 16, 16, 640, 640, 160, 0, 0, True, 8, 160, 12),
     ("gn_64x64_320_8w_split2", 2, 64, 64, 320, 0, 320, 0, 0, True, 2, 160, 8),
-    ("plain_16w_sc_only", 1, 16, 32, 64, 64, 160, 64, 64, False, 2, 160, 16),
     ("gn_32x32_concat_sc_8w_split4", 2, 32, 32, 640, 320, 640, 640, 320, True, 4, 160, 8),
     ("gn_64x64_320", 2, 64, 64, 320, 0, 320, 0, 0, True, 0),
     ("gn_32x32_concat_sc", 2, 32, 32, 640, 320, 640, 640, 320, True, 0),
