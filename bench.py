@@ -36,8 +36,10 @@ GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2, false, 32>"), ("gemm_12
              ("streamk_256x160x64", "<8, 5, 64, 3, 1, 0, 1, true, 32>"), ("retired_13", ""),
              ("streamk_256x128x64", "<8, 4, 64, 3, 1, 0, 1, true, 32>"), ("streamk_256x160x64_mf16", "<4, 5, 64, 3, 4, 0, 2, true, 16>")]
 KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % (t[:-1] + ", false>" if t else t) for n, t in GEMM_CFGS}      # (+ CS = false: the plain twin)
-KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true, 1, 4>(AttnArgs)"
-KERNEL_NAMES["conv3x3_gn_halo"] = "void (anonymous namespace)::dmx_conv_halo_kernel<5, 4, 2>(HaloConvArgs)"
+KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true, 1, 4, 0>(AttnArgs)"
+# (the class covers the instances the planner picks per shape: warp-specialised <10, 4, 1, true> at the 64x64 level, two-group ping-pong
+#  <5, 4, 2, false> / <5, 8, 1, false> at the 32x32 level; the name - and the PMC traffic looked up by it - is the first one's)
+KERNEL_NAMES["conv3x3_gn_halo"] = "void (anonymous namespace)::dmx_conv_halo_kernel<10, 4, 1, true>(HaloConvArgs)"
 PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
                 "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS] + ["xf_chain", "conv3x3_gn_halo"]
 MFMA_BF16_PEAK_TFLOPS = 2500.0
