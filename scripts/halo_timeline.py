@@ -35,8 +35,8 @@ for gi, gname in ((0, "wave 0 (group A)"), (1, "wave 4 (group B)")):
     print(f"  {gname}: shader cycles per pipeline step (mean over blocks): DMA phase %.0f  barrier X %.0f  MFMA phase %.0f  barrier Y %.0f   (sum %.0f)" %
           tuple((v[:, k] / 27.0).mean().item() if False else (v[:, k].mean().item() / max(1.0, 1.0)) for k in range(4)) + (0,)) if False else None
     steps = (v[:, 4] - 0).clamp_min(1)
-    per = v[:, :4] / 27.0
-    print(f"  {gname}: cycles per pipeline step: DMA phase {per[:,0].mean():.0f}  barrier X {per[:,1].mean():.0f}  MFMA phase {per[:,2].mean():.0f}  barrier Y {per[:,3].mean():.0f}  sum {per.sum(1).mean():.0f}   (per 27 steps: x 27 / steps for other step counts)")
+    per = v[:, :4] / tall[:4096][tall[:4096][:, 0] > 0][: len(v), 7:8].double().clamp_min(1)      # per tap of the block's own slice
+    print(f"  {gname}: cycles per pipeline step: DMA phase {per[:,0].mean():.0f}  barrier X {per[:,1].mean():.0f}  MFMA phase {per[:,2].mean():.0f}  barrier Y {per[:,3].mean():.0f}  sum {per.sum(1).mean():.0f}   (waves 0 / 4 of the warp-specialised instances: compute / loader - stream | barrier ; issue | barrier | normalise | end waits)")
 t0 = t[:, 0].min()
 t = t[:, [0, 1, 2, 3, 4, 6, 5, 7]]          # (stamp 6 = items done, before the statistics fold; 5 = end)
 us = (t[:, :7] - t0).double() / 100.0
