@@ -60,7 +60,22 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   constexpr int KTB = DMA ? 64 * 128 : KT_BYTES, VTB = DMA ? 64 * 128 : VT_BYTES;     // DMA tiles: unpadded, swizzled
   constexpr int NBUF = 2;                             // (a third slot with tiles requested two iterations ahead measured the same: 141.3 vs 141.4 us)
   __shared__ __attribute__((aligned(16))) char smem[NBUF * (KTB + VTB)];
+  __shared__ __attribute__((aligned(16))) char pf_dump[DMA ? 1024 : 16];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if constexpr (DMA) {
+    // weight prefetch for the next kernel (AttnArgs.pf): 1-KB units dealt over (block, wave); LDS-DMA into a dump slot - no registers, and
+    // the loop's own vmcnt waits cover it
+    const int nblk = gridDim.x * gridDim.y * gridDim.z, blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nb = p.pf_bytes[r];
+      if (nb <= 0) continue;
+      for (int u = blk * NW + wave; u * 1024 < nb; u += nblk * NW) {
+        int off = u * 1024 + (t & 63) * 16; if (off > nb - 16) off = nb - 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.pf[r] + off), (lptr_t)pf_dump, 16, 0, 0);
+      }
+    }
+  }
   const int lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (32 * R * NW) + wave * (32 * R);

@@ -170,6 +170,9 @@ class Exec {
   bool chain_gn_fold(const Tn& x) const;              // mode-2 chain: normalise the raw x in its operand load (x carries statistics records)
   void chain_stats(XfChainArgs& a, Tn& y);            // mode-1 chain: also emit the statistics records of its output y (when a fused GroupNorm -> conv can use them)
   // fused attention core; V row-major (LDS transpose-read path)
+  // prefetch hint for the next attention() launch: byte ranges (weights of the kernel that follows it) its blocks touch at their start
+  struct Prefetch { const void* p[4] = {nullptr, nullptr, nullptr, nullptr}; int n[4] = {0, 0, 0, 0}; };
+  Prefetch pf_next;
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                  bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale);
  private:

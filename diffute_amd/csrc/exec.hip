@@ -419,6 +419,8 @@ void Exec::xf_chain(int mode, XfChainArgs& a) {
   rc = dmx_xf_chain_launch(a, mode, stream);
 }
 
+static int g_attn_prefetch = 1;
+extern "C" int dmx_set_attn_prefetch(int on) { const int old = g_attn_prefetch; g_attn_prefetch = on; return old; }
 void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                      bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale) {
   if (dry || rc) return;
@@ -429,6 +431,8 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
   AttnArgs a{};
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.v = v; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  if (g_attn_prefetch) for (int r = 0; r < 4; ++r) { a.pf[r] = pf_next.p[r]; a.pf_bytes[r] = pf_next.p[r] ? pf_next.n[r] : 0; }
+  pf_next = Prefetch{};
   char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
   ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv), tag);
   rc = dmx_attention_launch(a, stream);

@@ -217,6 +217,9 @@ struct AttnArgs {
   int B, H, Sq, Skv;
   float scale;
   float* lse;                    // optional [B][H][Sq]: log2-sum-exp of the scaled scores (kept for the backward pass)
+  // optional: up to four byte ranges (the weights of the kernel that runs NEXT) every block touches a slice of at its start, so that they
+  // sit in the memory-side cache when that kernel's blocks - which walk them in lock step - ask for them (row-major-V path only)
+  const void* pf[4]; int pf_bytes[4];
 };
 int dmx_attention_launch(const AttnArgs& a, hipStream_t stream);
 

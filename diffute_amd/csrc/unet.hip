@@ -316,6 +316,10 @@ struct Fwd {
       ex.drop(st1.buf);
     }
     Tn a = ex.make(x.B, x.H, x.W, C);
+    // (the kernels that follow - the chain, or the to_out / to_q GEMMs - walk these weights in lock step on every CU: the attention blocks
+    // touch them at their start so that they sit in the memory-side cache by then)
+    ex.pf_next.p[0] = u->at<bf16>(w.wo1); ex.pf_next.n[0] = C * C * 2;
+    ex.pf_next.p[1] = u->at<bf16>(w.wq2); ex.pf_next.n[1] = C * C * 2;
     ex.attention(qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, S, a.p, C, x.B, w.heads, S, S, 0.125f);
     ex.drop(qkv);
     const int sp = ctx_pad(ctx_len);
@@ -331,6 +335,10 @@ struct Fwd {
       ex.xf_chain(0, c);
       ex.drop(a); ex.drop(h);
       a = ex.make(x.B, x.H, x.W, C);
+      ex.pf_next.p[0] = u->at<bf16>(w.wo2); ex.pf_next.n[0] = C * C * 2;
+      ex.pf_next.p[1] = u->at<bf16>(w.wf1); ex.pf_next.n[1] = 8 * C * C * 2;
+      ex.pf_next.p[2] = u->at<bf16>(w.wf2); ex.pf_next.n[2] = 4 * C * C * 2;
+      ex.pf_next.p[3] = u->at<bf16>(w.wpo); ex.pf_next.n[3] = C * C * 2;
       ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
       ex.drop(q);
       Tn h3 = ex.make(x.B, x.H, x.W, C), y = ex.make(x.B, x.H, x.W, C);
@@ -353,6 +361,11 @@ struct Fwd {
     Tn q = ex.linear(h2, u->at<bf16>(w.wq2), C, nullptr, nullptr, false, nullptr, &ln2);
     ex.drop(st2.buf);
     a = ex.make(x.B, x.H, x.W, C);
+    {   // to_out, and the first megabytes of the feed-forward weights (a few DMA instructions per wave: more would cost the attention launch)
+      const int cap = 4 << 20;
+      ex.pf_next.p[0] = u->at<bf16>(w.wo2); ex.pf_next.n[0] = C * C * 2;
+      ex.pf_next.p[1] = u->at<bf16>(w.wf1); ex.pf_next.n[1] = 8 * C * C * 2 < cap ? 8 * C * C * 2 : cap;
+    }
     ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
     ex.drop(q);
     Tn h3 = ex.linear(a, u->at<bf16>(w.wo2), C, u->at<float>(w.bo2), &h2, false, &st3);
