@@ -90,7 +90,7 @@ _PROTOS = {
     "dmx_xf_chain_ok": (c_int, [c_int, c_int]),
     "dmx_xf_chain": (c_int, [POINTER(XfChainDesc), c_int, _P]),
     "dmx_set_xf_chain": (c_int, [c_int]),
-    "dmx_set_attn_prefetch": (c_int, [c_int]),
+    "dmx_set_weight_prefetch": (c_int, [c_int]),
     "dmx_groupnorm_from_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, _P, _P, c_int, _P]),
     "dmx_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(GemmDesc), c_int]),
     "dmx_conv_wgrad": (c_int, [POINTER(GemmDesc), _P, c_int, _P, c_int, _P, c_size_t, _P]),

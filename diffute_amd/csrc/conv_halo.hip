@@ -75,7 +75,8 @@ template <int NF, int WMW, int WNW, bool WS_ = false> struct HaloLds {
   static constexpr int GB = PATCH1 + HB_PATCH;        // gamma | beta of a chunk, two 1-KB slots (lanes 32..63 of the DMA land in the second half)
   static constexpr int COEF = GB + 2048;              // (a, s) of the 64 channels of a chunk, 512 B
   static constexpr int GST = COEF + 512;              // (mean, rstd) of the 32 groups, 256 B (+ 256 spare)
-  static constexpr int TOTAL = GST + 512;
+  static constexpr int DUMP = GST + 512;              // 1 KB the weight prefetch for the NEXT launches lands in (HaloConvArgs.pf)
+  static constexpr int TOTAL = DUMP + 1024;
   // epilogue: fp32 staging of 128 rows + the statistics fold
   static constexpr int LDT = BN + 4;
   static constexpr int EPI_FOLD = 128 * LDT * 4;
@@ -414,6 +415,16 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
     nrm_store(pb);
   };
 
+  // ---- weight prefetch for the launches that follow (HaloConvArgs.pf): 1-KB units dealt over (block, wave), the oldest requests of
+  // every wave (the prologue's vmcnt(0) covers them)
+#pragma unroll
+  for (int r_ = 0; r_ < 2; ++r_) {
+    const int nb_ = p.pf_bytes[r_];
+    for (int u_ = blockIdx.x * (HB_NT / 64) + wave; u_ * 1024 < nb_; u_ += gridDim.x * (HB_NT / 64)) {
+      int off_ = u_ * 1024 + lane * 16; if (off_ > nb_ - 16) off_ = nb_ - 16;
+      dma((const char*)p.pf[r_] + off_, L::DUMP);
+    }
+  }
   // ---- prologue: the first patch and weight tile are requested FIRST (their latency covers the statistics), then the group statistics
   // of this block's sample
   int cur = ch_first, seq = 0;

@@ -170,9 +170,13 @@ class Exec {
   bool chain_gn_fold(const Tn& x) const;              // mode-2 chain: normalise the raw x in its operand load (x carries statistics records)
   void chain_stats(XfChainArgs& a, Tn& y);            // mode-1 chain: also emit the statistics records of its output y (when a fused GroupNorm -> conv can use them)
   // fused attention core; V row-major (LDS transpose-read path)
-  // prefetch hint for the next attention() launch: byte ranges (weights of the kernel that follows it) its blocks touch at their start
-  struct Prefetch { const void* p[4] = {nullptr, nullptr, nullptr, nullptr}; int n[4] = {0, 0, 0, 0}; };
-  Prefetch pf_next;
+  // Weight prefetch plan: a dry walk of the graph records the weight ranges of its launches in order (note()); in the real walk a
+  // launch asks for the ranges of the launches that FOLLOW it (peek()) and its blocks touch them at their start, so that they sit in
+  // the memory-side cache when the next kernel's blocks - which walk them in lock step - ask for them (gemm.hip / attention.hip)
+  struct PfPlan { std::vector<std::pair<const void*, long>> w; };
+  PfPlan* plan = nullptr; bool plan_rec = false; int plan_i = 0;
+  void note(const void* w, long bytes);
+  void peek(const void** p, int* n, int slots);
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                  bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale);
  private:

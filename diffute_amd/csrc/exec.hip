@@ -153,8 +153,27 @@ void Exec::want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B) {
   y.cst = a.colstats;
 }
 
+static int g_weight_prefetch = 1;
+extern "C" int dmx_set_weight_prefetch(int on) { const int old = g_weight_prefetch; g_weight_prefetch = on; return old; }
+void Exec::note(const void* w, long bytes) {
+  if (!plan) return;
+  if (plan_rec) plan->w.push_back({w, bytes});
+  ++plan_i;
+}
+void Exec::peek(const void** p, int* n, int slots) {
+  for (int i = 0; i < slots; ++i) { p[i] = nullptr; n[i] = 0; }
+  if (!plan || plan_rec || !g_weight_prefetch) return;
+  long left = 4L << 20;                                // per launch: a few DMA instructions per wave, not a second weight stream
+  for (int i = 0, k = plan_i; i < slots && k < (int)plan->w.size() && left > 0; ++k) {
+    if (!plan->w[k].first || plan->w[k].second <= 0) continue;
+    const long nb = plan->w[k].second < left ? plan->w[k].second : left;
+    p[i] = plan->w[k].first; n[i] = (int)nb; left -= nb; ++i;
+  }
+}
 void Exec::run_gemm(GemmArgs& a) {
   if (rc) return;
+  note(a.w, (long)a.N * a.ldw * 2 * (a.ups2 ? 4 : 1));
+  peek(a.pf, a.pf_bytes, 2);
   if (const int pg = dmx_gemm_persist_blocks(a)) {
     constexpr size_t POOL = 64 * 1024;                 // ints: 256 launches of 256 blocks
     if (!flag_pool) {
@@ -319,6 +338,8 @@ Tn Exec::conv_gn(const Tn& x0, const Tn* x1, const float* gamma, const float* be
   }
   const size_t wsb = dmx_conv_halo_workspace_bytes(a);
   void* wsp = wsb ? raw(wsb) : nullptr;
+  note(a.w, (long)a.N * a.ldw * 2);
+  peek(a.pf, a.pf_bytes, 2);
   if (!dry && !rc) rc = dmx_conv_halo_launch(a, wsp, wsb, stream);
   if (wsp) ws.release(wsp);
   return y;
@@ -415,12 +436,16 @@ void Exec::chain_stats(XfChainArgs& a, Tn& y) {
   a.cs_rows = y.H * y.W; y.cst = a.colstats;
 }
 void Exec::xf_chain(int mode, XfChainArgs& a) {
+  const long cc = (long)a.C * a.C * 2;
+  note(a.w0, cc);
+  if (mode == 0) note(a.w1, cc);
+  else if (mode == 2) note(a.w1, 3 * cc);
+  else { note(a.wf1, 8 * cc); note(a.wf2, 4 * cc); note(a.wpo, cc); }
+  peek(a.pf, a.pf_bytes, 2);
   if (dry || rc) return;
   rc = dmx_xf_chain_launch(a, mode, stream);
 }
 
-static int g_attn_prefetch = 1;
-extern "C" int dmx_set_attn_prefetch(int on) { const int old = g_attn_prefetch; g_attn_prefetch = on; return old; }
 void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                      bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale) {
   if (dry || rc) return;
@@ -431,8 +456,7 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
   AttnArgs a{};
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.v = v; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
-  if (g_attn_prefetch) for (int r = 0; r < 4; ++r) { a.pf[r] = pf_next.p[r]; a.pf_bytes[r] = pf_next.p[r] ? pf_next.n[r] : 0; }
-  pf_next = Prefetch{};
+  peek(a.pf, a.pf_bytes, 4);
   char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
   ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv), tag);
   rc = dmx_attention_launch(a, stream);

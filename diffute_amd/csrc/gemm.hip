@@ -86,6 +86,20 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
 
   long long tm0 = 0, tm1 = 0, tm2 = 0;
   if (p.timing) tm0 = dmx_now(p.dbg);
+  if (p.pf_dump_off > 0) {
+    // weight prefetch for the next launches (GemmArgs.pf): 1-KB units dealt over (block, wave); they are the oldest requests of the
+    // wave, so every counted vmcnt wait of the K loop covers them
+    const int nblk_ = gridDim.x * gridDim.y, blk_ = blockIdx.y * gridDim.x + blockIdx.x, wv_ = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int nb = p.pf_bytes[r];
+      for (int u = blk_ * (NT / 64) + wv_; u * 1024 < nb; u += nblk_ * (NT / 64)) {
+        int off = u * 1024 + (threadIdx.x & 63) * 16; if (off > nb - 16) off = nb - 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p.pf[r] + off),
+                                         (__attribute__((address_space(3))) void*)(smem + p.pf_dump_off), 16, 0, 0);
+      }
+    }
+  }
 
   // ---- work items.  Classic launch: one block = one (tile, K-slice) - tile from blockIdx.x, split-K slice from blockIdx.y.
   // Persistent stream-K launch (p.persist; grid = one block per CU): the flattened (tile, K-tile) iteration space is cut
@@ -1297,10 +1311,13 @@ static void launch_cfg_(const GemmArgs& a, dim3 grid, hipStream_t stream) {
   if (lds_epi > lds) lds = lds_epi;
   if (a.ln_stats || TN == 5) lds += (size_t)BM * 2 * sizeof(float);    // (mean, rstd) per row of the folded LayerNorm
   if (TN == 5) lds += (size_t)3 * BN * sizeof(float);                  // the tile's column vectors (160 / 320-column epilogue)
+  GemmArgs ap = a;                                                     // (the prefetch dump slot: 1 KB behind everything else, where it fits)
+  ap.pf_dump_off = 0;
+  if (a.pf_bytes[0] > 0 && lds + 1024 <= 163840 && (PS ? false : true)) { ap.pf_dump_off = (int)align_up(lds, 16); lds = (size_t)ap.pf_dump_off + 1024; }
   static bool attr[64] = {};                          // the dynamic-LDS opt-in is per device
   int dev = 0; (void)hipGetDevice(&dev);
-  if (dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float) > 163840 ? 163840 : lds + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr[dev] = true; }
-  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, CS>), grid, dim3(64 * (NWN * WM + NP)), lds, stream, a);
+  if (dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 1040 + BM * 2 * sizeof(float) + 3 * BN * sizeof(float) > 163840 ? 163840 : lds + 1040 + BM * 2 * sizeof(float) + 3 * BN * sizeof(float))); attr[dev] = true; }
+  hipLaunchKernelGGL((dmx_gemm_kernel<WM, TN, BKT, NST, TM, NP, NWN, PS, MF, CS>), grid, dim3(64 * (NWN * WM + NP)), lds, stream, ap);
 }
 
 // the statistics-emitting twin of an instance is used exactly when GemmArgs.colstats is set (the warp-specialised instance has none)

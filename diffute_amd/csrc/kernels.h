@@ -50,6 +50,9 @@ struct GemmArgs {
   int ln_C; float ln_eps;                      // normalised feature count (= K) and epsilon
   long long* timing;                           // optional per-block timeline (probe builds), normally null
   int dbg;                                     // measurement aid: bit0 skip the MFMA phase, bit1 skip the DMA refills (results invalid)
+  // optional: up to two byte ranges (the weights of the launches that run NEXT) the blocks touch at their start - LDS-DMA into a dump
+  // slot behind the instance's LDS (pf_dump_off, filled by the launcher; prefetch dropped where the slot does not fit)
+  const void* pf[2]; int pf_bytes[2]; int pf_dump_off;
   float* partial; int splitk, kt_per_split;   // filled by the launcher
   // persistent stream-K launch (filled by the launcher): grid = one block per CU walking (tile, K-range) items; `partial` holds
   // one accumulator slab per block, `flags` one int per block, all zero at launch (see the kernel's work-item loop)
@@ -97,6 +100,7 @@ struct HaloConvArgs {
   int force_bn;                                      // 0 = automatic column tile (160 / 128 / 80 / 64)
   int force_waves;                                   // 0 = automatic; 8 / 16 waves per block (16: the 160 / 128-column tiles only)
   int dbg; long long* timing;                        // measurement aids (0 / null in the product path)
+  const void* pf[2]; int pf_bytes[2];                // optional: byte ranges (the next launches' weights) the blocks touch at their start (Exec::peek)
   // filled by the launcher
   int TH, TW, splits, xcd_tile_major; float* slabs; int* flags; const bf16* zeros;
   // (the block decode of the kernel without integer divisions: x / d = (x * magic) >> 32 for the dividends that occur, all < 2^20)
@@ -196,6 +200,7 @@ struct XfChainArgs {
   // mode 1: DmxStat records of the block output y for the GroupNorm that reads it next ([M / cs_rows][C][4], added to; cs_rows = rows per
   // sample, a multiple of 64), or null
   long long* colstats; int cs_rows;
+  const void* pf[2]; int pf_bytes[2];      // optional: byte ranges (the next launches' weights) the blocks touch at their start (Exec::peek)
   // mode 2: x is the RAW tensor and the block normalises its rows on the way into the fragments: GroupNorm (no activation) from the DmxStat
   // records of x ([M / gn_rows][C][4]; gn_rows = rows per sample, a multiple of 64) - the same arithmetic, to the bit, as dmx_groupnorm's
   // apply pass followed by the plain mode 2.  Null gn_st: x is already normalised

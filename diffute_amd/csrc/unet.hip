@@ -316,10 +316,6 @@ struct Fwd {
       ex.drop(st1.buf);
     }
     Tn a = ex.make(x.B, x.H, x.W, C);
-    // (the kernels that follow - the chain, or the to_out / to_q GEMMs - walk these weights in lock step on every CU: the attention blocks
-    // touch them at their start so that they sit in the memory-side cache by then)
-    ex.pf_next.p[0] = u->at<bf16>(w.wo1); ex.pf_next.n[0] = C * C * 2;
-    ex.pf_next.p[1] = u->at<bf16>(w.wq2); ex.pf_next.n[1] = C * C * 2;
     ex.attention(qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, S, a.p, C, x.B, w.heads, S, S, 0.125f);
     ex.drop(qkv);
     const int sp = ctx_pad(ctx_len);
@@ -335,10 +331,6 @@ struct Fwd {
       ex.xf_chain(0, c);
       ex.drop(a); ex.drop(h);
       a = ex.make(x.B, x.H, x.W, C);
-      ex.pf_next.p[0] = u->at<bf16>(w.wo2); ex.pf_next.n[0] = C * C * 2;
-      ex.pf_next.p[1] = u->at<bf16>(w.wf1); ex.pf_next.n[1] = 8 * C * C * 2;
-      ex.pf_next.p[2] = u->at<bf16>(w.wf2); ex.pf_next.n[2] = 4 * C * C * 2;
-      ex.pf_next.p[3] = u->at<bf16>(w.wpo); ex.pf_next.n[3] = C * C * 2;
       ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
       ex.drop(q);
       Tn h3 = ex.make(x.B, x.H, x.W, C), y = ex.make(x.B, x.H, x.W, C);
@@ -361,11 +353,6 @@ struct Fwd {
     Tn q = ex.linear(h2, u->at<bf16>(w.wq2), C, nullptr, nullptr, false, nullptr, &ln2);
     ex.drop(st2.buf);
     a = ex.make(x.B, x.H, x.W, C);
-    {   // to_out, and the first megabytes of the feed-forward weights (a few DMA instructions per wave: more would cost the attention launch)
-      const int cap = 4 << 20;
-      ex.pf_next.p[0] = u->at<bf16>(w.wo2); ex.pf_next.n[0] = C * C * 2;
-      ex.pf_next.p[1] = u->at<bf16>(w.wf1); ex.pf_next.n[1] = 8 * C * C * 2 < cap ? 8 * C * C * 2 : cap;
-    }
     ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
     ex.drop(q);
     Tn h3 = ex.linear(a, u->at<bf16>(w.wo2), C, u->at<float>(w.bo2), &h2, false, &st3);
@@ -565,6 +552,22 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
   return ex.rc;
 }
 
+// the product walk with the weight prefetch plan (Exec::note / peek): a dry walk of the same graph lists the weight ranges in launch
+// order, the real walk hands every launch the ranges of the launches that follow it
+int unet_run_planned(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, int c1, const float* f2, int c2,
+                     const long long* timesteps, int t_count, const void* cache, int ctx_len, float* out, int B, int H, int W) {
+  Exec::PfPlan plan;
+  {
+    Exec dr; dr.dry = true; dr.ws.reset(nullptr, 0, true); dr.plan = &plan; dr.plan_rec = true;
+    unet_run(u, dr, nullptr, c0, nullptr, c1, nullptr, c2, nullptr, t_count, cache, ctx_len, nullptr, B, H, W);
+  }
+  ex.plan = &plan; ex.plan_rec = false; ex.plan_i = 0;
+  int rc = unet_run(u, ex, f0, c0, f1, c1, f2, c2, timesteps, t_count, cache, ctx_len, out, B, H, W);
+  if (!rc && ex.plan_i != (int)plan.w.size()) { dmx_set_error("unet: the prefetch plan of the dry walk (%d launches) does not match the real walk (%d)", (int)plan.w.size(), ex.plan_i); rc = DMX_ERR_ARG; }
+  ex.plan = nullptr;
+  return rc;
+}
+
 }  // namespace
 
 extern "C" size_t dmx_unet_workspace_bytes(dmx_unet* u, int B, int H, int W, int ctx_len) {
@@ -590,7 +593,7 @@ extern "C" int dmx_unet_forward(dmx_unet* u, const float* f0, int c0, const floa
   DMX_REQUIRE(c0 + c1 + c2 == u->cfg.in_channels, "unet_forward: c0+c1+c2=%d != in_channels=%d", c0 + c1 + c2, u->cfg.in_channels);
   DMX_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "unet_forward: H=%d W=%d must be positive multiples of 8", H, W);
   Exec ex; ex.stream = (hipStream_t)stream; ex.ws.reset(workspace, workspace_bytes, false);
-  return unet_run(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
+  return unet_run_planned(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
 }
 
 // dmx_unet_forward + debug taps: the block outputs conv_in, down0..3, mid, up0..3 (the oracle's tap points) are copied out as
@@ -656,7 +659,7 @@ extern "C" int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, cons
   DMX_REQUIRE(f0 && out && timesteps && cache && workspace, "unet_forward_graph: null argument");
   DMX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   Exec ex; ex.stream = s; ex.ws.reset(workspace, workspace_bytes, false);
-  const int rc = unet_run(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
+  const int rc = unet_run_planned(u, ex, f0, c0, f1, c1, f2, c2, (const long long*)timesteps, t_count, cache, ctx_len, out, B, H, W);
   hipGraph_t g = nullptr;
   const hipError_t ce = hipStreamEndCapture(s, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }

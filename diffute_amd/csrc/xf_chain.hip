@@ -40,7 +40,8 @@ constexpr int XFF_OFF = 3 * XSLOT;
 constexpr int XST_OFF = XFF_OFF + XBM * XFF_LD;          // row statistics partials [64][4 column waves][2] floats
 constexpr int XVEC_OFF = XST_OFF + XBM * 4 * 2 * 4;      // three fp32 [320] column vectors of the 320-wide epilogues (loaded once per block)
 constexpr int XFFV_OFF = XVEC_OFF + 3 * XC * 4;          // c1 | c2 of the running feed-forward chunk (320 floats each, 3 KB with padding) + 1 KB the idle waves' lanes write
-constexpr int XLDS = XFFV_OFF + 4096;                    // 157 440 bytes
+constexpr int XDUMP = XFFV_OFF + 4096;                   // 1 KB the weight prefetch for the next launches lands in (XfChainArgs.pf)
+constexpr int XLDS = XDUMP + 1024;                       // 158 464 bytes
 constexpr int XCHUNK = 160;                    // hidden columns per feed-forward chunk (= 320 packed FF1 rows)
 }  // namespace
 
@@ -331,6 +332,15 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
   long long* tmo = p.timing ? p.timing + (size_t)blockIdx.x * 8 : nullptr;      // measurement aid: s_memrealtime (10 ns) at the phase boundaries
   auto stamp = [&](int i) { if (tmo && t == 0) tmo[i] = (long long)__builtin_amdgcn_s_memrealtime(); };
   stamp(0);
+  // ---- weight prefetch for the launches that follow (XfChainArgs.pf): 1-KB units over (block, wave), the oldest requests of each wave
+#pragma unroll
+  for (int r_ = 0; r_ < 2; ++r_) {
+    const int nb_ = p.pf_bytes[r_];
+    for (int u_ = blockIdx.x * 8 + w; u_ * 1024 < nb_; u_ += gridDim.x * 8) {
+      int off_ = u_ * 1024 + lane * 16; if (off_ > nb_ - 16) off_ = nb_ - 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.pf[r_] + off_), (lptr_t)(smem + XDUMP), 16, 0, 0);
+    }
+  }
   // ---- start: two tiles in flight, the first operand straight from global into fragments
   prepare_next(); dma_all(); prepare_next(); dma_all();
 #pragma unroll

@@ -220,7 +220,9 @@ typedef struct {
 int dmx_xf_chain_ok(int M, int C);
 int dmx_xf_chain(const dmx_xf_chain_desc* d, int mode, dmx_stream_t stream);
 int dmx_set_xf_chain(int on);
-int dmx_set_attn_prefetch(int on);  /* tuning aid: 0 = the attention launches of the model executors do not prefetch the next kernel's weights; returns the old setting */
+int dmx_set_weight_prefetch(int on); /* tuning aid: 0 = the launches of dmx_unet_forward* do not touch the weights of the launches that follow them
+                                      * (default 1: every GEMM / attention / halo-conv / chain launch prefetches up to 4 MB of them into the memory-side
+                                      * cache - the plan comes from a dry walk of the same graph); returns the old setting */
 
 /* Training (P5 over K3/K4/K8): forward GroupNorm that also keeps (mean, rstd) per (image, group), and the backward
  * kernels of GroupNorm(+SiLU), LayerNorm and the unfused GEGLU.  All deterministic.  `res*` is an optional gradient
