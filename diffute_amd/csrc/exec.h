@@ -178,7 +178,7 @@ class Exec {
   void note(const void* w, long bytes);
   void peek(const void** p, int* n, int slots);
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
-                 bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale);
+                 bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale, bool kv_static = false);
  private:
   void run_gemm(GemmArgs& a);
 };

@@ -163,7 +163,9 @@ void Exec::note(const void* w, long bytes) {
 void Exec::peek(const void** p, int* n, int slots) {
   for (int i = 0; i < slots; ++i) { p[i] = nullptr; n[i] = 0; }
   if (!plan || plan_rec || !g_weight_prefetch) return;
-  long left = 4L << 20;                                // per launch: a few DMA instructions per wave, not a second weight stream
+  static long cap = 0;
+  if (!cap) { const char* e = getenv("DMX_PF_CAP_MB"); cap = e ? atol(e) << 20 : 4L << 20; if (cap <= 0) cap = 4L << 20; }   // (tuning aid)
+  long left = cap;                                     // per launch: a few DMA instructions per wave, not a second weight stream
   for (int i = 0, k = plan_i; i < slots && k < (int)plan->w.size() && left > 0; ++k) {
     if (!plan->w[k].first || plan->w[k].second <= 0) continue;
     const long nb = plan->w[k].second < left ? plan->w[k].second : left;
@@ -447,7 +449,12 @@ void Exec::xf_chain(int mode, XfChainArgs& a) {
 }
 
 void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
-                     bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale) {
+                     bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale, bool kv_static) {
+  // (kv_static: K | V live in the per-image context cache, written long before this launch - cold, and every block of a head walks them
+  // in lock step: they join the prefetch plan like a weight matrix.  One interleaved buffer: ldk elements per key row.)
+  static int kv_pf = -1;
+  if (kv_pf < 0) { const char* e = getenv("DMX_PF_KV"); kv_pf = e ? atoi(e) : 1; }      // (tuning aid)
+  if (kv_static && kv_pf) note(k, (long)B * kv_rows * ldk * 2);
   if (dry || rc) return;
   if (f32) {
     rc = dmx_attention_f32_launch((const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, kv_rows, (float*)o, ldo, B, H, Sq, Skv, scale, stream);

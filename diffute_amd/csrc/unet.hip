@@ -331,7 +331,7 @@ struct Fwd {
       ex.xf_chain(0, c);
       ex.drop(a); ex.drop(h);
       a = ex.make(x.B, x.H, x.W, C);
-      ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
+      ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f, true);
       ex.drop(q);
       Tn h3 = ex.make(x.B, x.H, x.W, C), y = ex.make(x.B, x.H, x.W, C);
       XfChainArgs d{};
@@ -353,7 +353,7 @@ struct Fwd {
     Tn q = ex.linear(h2, u->at<bf16>(w.wq2), C, nullptr, nullptr, false, nullptr, &ln2);
     ex.drop(st2.buf);
     a = ex.make(x.B, x.H, x.W, C);
-    ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f);
+    ex.attention(q.p, C, kvc, 2 * C, kvc + C, 2 * C, sp, a.p, C, x.B, w.heads, S, ctx_len, 0.125f, true);
     ex.drop(q);
     Tn h3 = ex.linear(a, u->at<bf16>(w.wo2), C, u->at<float>(w.bo2), &h2, false, &st3);
     ex.drop(a); ex.drop(h2);
