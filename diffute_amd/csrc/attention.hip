@@ -62,20 +62,6 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   __shared__ __attribute__((aligned(16))) char smem[NBUF * (KTB + VTB)];
   __shared__ __attribute__((aligned(16))) char pf_dump[DMA ? 1024 : 16];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  if constexpr (DMA) {
-    // weight prefetch for the next kernel (AttnArgs.pf): 1-KB units dealt over (block, wave); LDS-DMA into a dump slot - no registers, and
-    // the loop's own vmcnt waits cover it
-    const int nblk = gridDim.x * gridDim.y * gridDim.z, blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int nb = p.pf_bytes[r];
-      if (nb <= 0) continue;
-      for (int u = blk * NW + wave; u * 1024 < nb; u += nblk * NW) {
-        int off = u * 1024 + (t & 63) * 16; if (off > nb - 16) off = nb - 16;
-        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.pf[r] + off), (lptr_t)pf_dump, 16, 0, 0);
-      }
-    }
-  }
   const int lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (32 * R * NW) + wave * (32 * R);
@@ -178,7 +164,28 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   }
 
   const int ntiles = (p.Skv + 63) / 64;
-  if (DMA) { stage(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  if (DMA) {
+    stage(0, 0);
+    // weight prefetch for the launches that follow (AttnArgs.pf): 1-KB units dealt over (block, wave), at most three per wave, LDS-DMA
+    // into a dump slot.  Requested BEHIND the first K / V tile and left in flight by a counted wait: cold weights come from HBM, the
+    // tile from L2 - the first wait that covers them is the one at the end of the first iteration
+    int npf = 0;
+    {
+      const int nblk = gridDim.x * gridDim.y * gridDim.z, blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nb = p.pf_bytes[r];
+        for (int u = blk * NW + wave; u * 1024 < nb && npf < 3; u += nblk * NW, ++npf) {
+          int off = u * 1024 + lane * 16; if (off > nb - 16) off = nb - 16;
+          __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.pf[r] + off), (lptr_t)pf_dump, 16, 0, 0);
+        }
+      }
+    }
+    if (npf == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (npf == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (npf == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  }
   else { load_tile(0); write_tile(0); }
   // The Q fragments come from plain global loads issued before the loop.  hipcc's waitcnt pass cannot prove them complete
   // at the loop header (the back edge merges with the entry state), so it re-waits for them INSIDE the loop with

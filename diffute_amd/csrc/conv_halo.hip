@@ -417,10 +417,11 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
 
   // ---- weight prefetch for the launches that follow (HaloConvArgs.pf): 1-KB units dealt over (block, wave), the oldest requests of
   // every wave (the prologue's vmcnt(0) covers them)
+  int pf_left = 4;                                     // (at most four units per wave)
 #pragma unroll
   for (int r_ = 0; r_ < 2; ++r_) {
     const int nb_ = p.pf_bytes[r_];
-    for (int u_ = blockIdx.x * (HB_NT / 64) + wave; u_ * 1024 < nb_; u_ += gridDim.x * (HB_NT / 64)) {
+    for (int u_ = blockIdx.x * (HB_NT / 64) + wave; u_ * 1024 < nb_ && pf_left > 0; u_ += gridDim.x * (HB_NT / 64), --pf_left) {
       int off_ = u_ * 1024 + lane * 16; if (off_ > nb_ - 16) off_ = nb_ - 16;
       dma((const char*)p.pf[r_] + off_, L::DUMP);
     }

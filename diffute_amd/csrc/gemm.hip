@@ -90,10 +90,11 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
     // weight prefetch for the next launches (GemmArgs.pf): 1-KB units dealt over (block, wave); they are the oldest requests of the
     // wave, so every counted vmcnt wait of the K loop covers them
     const int nblk_ = gridDim.x * gridDim.y, blk_ = blockIdx.y * gridDim.x + blockIdx.x, wv_ = threadIdx.x >> 6;
+    int left_ = 4;                                     // at most four units per wave: a launch of few blocks (batch 1) must not turn into a weight stream
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int nb = p.pf_bytes[r];
-      for (int u = blk_ * (NT / 64) + wv_; u * 1024 < nb; u += nblk_ * (NT / 64)) {
+      for (int u = blk_ * (NT / 64) + wv_; u * 1024 < nb && left_ > 0; u += nblk_ * (NT / 64), --left_) {
         int off = u * 1024 + (threadIdx.x & 63) * 16; if (off > nb - 16) off = nb - 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p.pf[r] + off),
                                          (__attribute__((address_space(3))) void*)(smem + p.pf_dump_off), 16, 0, 0);

@@ -333,10 +333,11 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
   auto stamp = [&](int i) { if (tmo && t == 0) tmo[i] = (long long)__builtin_amdgcn_s_memrealtime(); };
   stamp(0);
   // ---- weight prefetch for the launches that follow (XfChainArgs.pf): 1-KB units over (block, wave), the oldest requests of each wave
+  int pf_left = 4;                                     // (at most four units per wave)
 #pragma unroll
   for (int r_ = 0; r_ < 2; ++r_) {
     const int nb_ = p.pf_bytes[r_];
-    for (int u_ = blockIdx.x * 8 + w; u_ * 1024 < nb_; u_ += gridDim.x * 8) {
+    for (int u_ = blockIdx.x * 8 + w; u_ * 1024 < nb_ && pf_left > 0; u_ += gridDim.x * 8, --pf_left) {
       int off_ = u_ * 1024 + lane * 16; if (off_ > nb_ - 16) off_ = nb_ - 16;
       __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.pf[r_] + off_), (lptr_t)(smem + XDUMP), 16, 0, 0);
     }
