@@ -164,28 +164,8 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   }
 
   const int ntiles = (p.Skv + 63) / 64;
-  if (DMA) {
-    stage(0, 0);
-    // weight prefetch for the launches that follow (AttnArgs.pf): 1-KB units dealt over (block, wave), at most three per wave, LDS-DMA
-    // into a dump slot.  Requested BEHIND the first K / V tile and left in flight by a counted wait: cold weights come from HBM, the
-    // tile from L2 - the first wait that covers them is the one at the end of the first iteration
-    int npf = 0;
-    {
-      const int nblk = gridDim.x * gridDim.y * gridDim.z, blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nb = p.pf_bytes[r];
-        for (int u = blk * NW + wave; u * 1024 < nb && npf < 3; u += nblk * NW, ++npf) {
-          int off = u * 1024 + lane * 16; if (off > nb - 16) off = nb - 16;
-          __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.pf[r] + off), (lptr_t)pf_dump, 16, 0, 0);
-        }
-      }
-    }
-    if (npf == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (npf == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (npf == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  }
+  int npf = 0;                                         // prefetch units this wave has in flight (first iteration only)
+  if (DMA) { stage(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   else { load_tile(0); write_tile(0); }
   // The Q fragments come from plain global loads issued before the loop.  hipcc's waitcnt pass cannot prove them complete
   // at the loop header (the back edge merges with the entry state), so it re-waits for them INSIDE the loop with
@@ -200,6 +180,20 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
   for (int it = 0; it < ntiles; ++it) {
     const int kv0 = it * 64;
     if (it + 1 < ntiles && !(PROBE & 32)) { if (DMA) stage((it + 1) & 1, kv0 + 64); else load_tile(kv0 + 64); }
+    if (DMA && it == 0) {
+      // weight prefetch for the launches that follow (AttnArgs.pf): 1-KB units dealt over (block, wave), at most three per wave, LDS-DMA
+      // into a dump slot.  Requested BEHIND the second K / V tile and left in flight by this iteration's counted wait: cold weights come
+      // from HBM, the tiles from L2 - the first wait that covers them is the one at the end of the second iteration
+      const int nblk = gridDim.x * gridDim.y * gridDim.z, blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nb = p.pf_bytes[r];
+        for (int u = blk * NW + wave; u * 1024 < nb && npf < 3; u += nblk * NW, ++npf) {
+          int off = u * 1024 + lane * 16; if (off > nb - 16) off = nb - 16;
+          __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.pf[r] + off), (lptr_t)pf_dump, 16, 0, 0);
+        }
+      }
+    }
     const char* ks = smem + ((PROBE & 32) ? 0 : (it & 1)) * (KTB + VTB);
     const char* vs = ks + KTB;
 
@@ -326,7 +320,12 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
         }
     }
 
-    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile it+1 has landed (requested a whole iteration ago)
+    if (DMA) {                                                      // tile it+1 has landed (requested a whole iteration ago)
+      if (it > 0 || npf == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (npf == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if (npf == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    }
     else if (it + 1 < ntiles && !(PROBE & 32)) write_tile((it + 1) & 1);
     if (!(PROBE & 64)) __syncthreads();
   }
