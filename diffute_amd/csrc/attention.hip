@@ -330,6 +330,7 @@ __global__ __launch_bounds__(64 * NW, R == 2 ? 2 : (NW == 4 ? 2 : 3)) void dmx_a
     if (!(PROBE & 64)) __syncthreads();
   }
 
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (a single-tile stream leaves the prefetch units in flight behind its only wait: nothing may outlive the block)
   // ---- normalise and store: lane holds query 32j + lr, d = 32dt + 8g + 4lh + e
 #pragma unroll
   for (int j = 0; j < R; ++j) {

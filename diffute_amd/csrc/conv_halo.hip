@@ -1046,8 +1046,15 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
   // (eight-way): 58.8 - 70.0 - 77.6: the warp-specialised K loop is ~10 % faster per tap (1.02 vs 1.13 us), its epilogue with four / eight
   // slabs per row in flight has fewer registers to hide them in -> 4 + 4 up to two-way splits, the ping-pong beyond
   P.waves = 8;
+#ifndef DMX_F16
+  // (bf16 build only: in the fp16 build the compiler spills an accumulator of the 160-column instance INSIDE the tap loop, which the
+  // asm MFMAs make a correctness bug - non-deterministic results at 768 px, EXPERIMENTS.md round 4 item 1b; tests/test_build_cpu.py
+  // checks the ISA of both builds)
   if (P.bn >= 128 && P.splits <= 2 && g_halo_ws) P.waves = 4;
   if (P.bn >= 128 && (a.force_waves == 4 || a.force_waves == 12 || a.force_waves == 8)) P.waves = a.force_waves;
+#else
+  if (a.force_waves == 8) P.waves = 8;
+#endif
   if (a.force_waves && a.force_waves != P.waves) P.splits = 0;
   return P;
 }
@@ -1132,8 +1139,10 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
   char tag[96];
   snprintf(tag, sizeof(tag), "M=%d N=%d K=%d halo gn=%d bn=%d sk=%d", a.B * a.H * a.W, a.N, 9 * a.Cin + a.Csc, a.gn, P.bn, a.splits);
   ProfScope ps(PROF_HALO, stream, flops, bytes, tag);
+#ifndef DMX_F16
   if (P.waves == 4) return P.nf == 5 ? halo_launch_<10, 4, 1, true>(a, blocks, stream) : halo_launch_<8, 4, 1, true>(a, blocks, stream);
   if (P.waves == 12) return P.nf == 5 ? halo_launch_<5, 4, 2, true>(a, blocks, stream) : halo_launch_<4, 4, 2, true>(a, blocks, stream);
+#endif
   if (P.nf == 5 && P.wmw == 4) return halo_launch_<5, 4, 2>(a, blocks, stream);
   if (P.nf == 4 && P.wmw == 4) return halo_launch_<4, 4, 2>(a, blocks, stream);
   if (P.nf == 5 && P.wmw == 8) return halo_launch_<5, 8, 1>(a, blocks, stream);

@@ -86,9 +86,10 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
 
   long long tm0 = 0, tm1 = 0, tm2 = 0;
   if (p.timing) tm0 = dmx_now(p.dbg);
-  if (p.pf_dump_off > 0) {
+  if (p.pf_dump_off > 0 && (NP == 0 || (int)(threadIdx.x >> 6) >= NC)) {
     // weight prefetch for the next launches (GemmArgs.pf): 1-KB units dealt over (block, wave); they are the oldest requests of the
-    // wave, so every counted vmcnt wait of the K loop covers them
+    // wave, so every counted vmcnt wait of the K loop covers them.  Only waves that stage tiles issue them (the consumer waves of the
+    // warp-specialised instance never wait on vmcnt: a request of theirs could still be writing the dump slot after the block has gone)
     const int nblk_ = gridDim.x * gridDim.y, blk_ = blockIdx.y * gridDim.x + blockIdx.x, wv_ = threadIdx.x >> 6;
     int left_ = 4;                                     // at most four units per wave: a launch of few blocks (batch 1) must not turn into a weight stream
 #pragma unroll

@@ -22,11 +22,14 @@ def _regs(tok):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_no_accumulator_spill_behind_an_asm_mfma(tmp_path):
+@pytest.mark.parametrize("build", ["bf16", "fp16"])
+def test_no_accumulator_spill_behind_an_asm_mfma(tmp_path, build):
+    """both builds of the library: the register allocation differs between them (the fp16 build of the 160-column warp-specialised
+    instance spilled an accumulator inside the tap where the bf16 build did not: non-deterministic results at 768 px)"""
     src = os.path.join(ROOT, "diffute_amd", "csrc", "conv_halo.hip")
     out = tmp_path / "conv_halo.s"
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", src, "-o", str(out)],
-                   check=True, capture_output=True, cwd=os.path.dirname(src))
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"] + (["-DDMX_F16"] if build == "fp16" else []) +
+                   ["-S", "--cuda-device-only", src, "-o", str(out)], check=True, capture_output=True, cwd=os.path.dirname(src))
     lines = [l.strip() for l in open(out)]
     WINDOW = 12                                        # instructions; an MFMA's result is due well within that many issue slots
     recent = []                                        # (instruction index, registers written by an MFMA)
