@@ -520,13 +520,15 @@ bool dmx_xf_chain_supported(int M, int C) { return C == XC && M > 0 && M % XBM =
 // A block owns 64 rows, one block per CU, so the time of a launch goes with the number of ROUNDS of M / 64 blocks over the CUs,
 // while the separate full-chip GEMMs go with M.  Measured (scripts/ab_pass.py xf_chain --batch b [--latent 96]; chains forced on
 // vs off, ms per 50-step pass): 64 blocks 236 vs 224, 128 blocks 293 vs 293, 192 blocks 340 vs 346, 256 blocks 349 vs 359,
-// 288 blocks (768 px, batch 2) 457 vs 442 - the model executors take the chains when the last round is at least 3/4 full.
+// 288 blocks (768 px, batch 2) 457 vs 442 - (round 3, before the prefetch plan) - see below.
 bool dmx_xf_chain_pays(int M, int C) {
   if (!dmx_xf_chain_supported(M, C)) return false;
   static int n_cu = 0;
   if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-  const int blocks = M / XBM, rounds = (blocks + n_cu - 1) / n_cu;
-  return 4 * blocks >= 3 * rounds * n_cu;
+  // (round 4, with the weight prefetch plan - the chains no longer wait for cold weights: 64 blocks (B = 1) 239.1 vs 231.4, 128 blocks (B = 2)
+  // 286.8 vs 296.6, 192 blocks (B = 3) 328.6 vs 346.0, 288 blocks (768 px, batch 2) 484.2 vs 479.0 -> the LAST round at least half full)
+  const int blocks = M / XBM, rounds = (blocks + n_cu - 1) / n_cu, last = blocks - (rounds - 1) * n_cu;
+  return 2 * last >= n_cu;
 }
 
 int dmx_xf_chain_launch(const XfChainArgs& a, int mode, hipStream_t stream) {

@@ -192,7 +192,7 @@ int dmx_set_halo_ws(int on);        /* tuning aid: 0 keeps dmx_conv3x3_gn's plan
  *            y = h3 wpo^T + bpo + xres     (attn2.to_out.0 + residual, ff.net, proj_out + the block residual; wf1 [8C][C] in
  *            the packed GEGLU order of dmx_pack_geglu_weight with c1 / c2 [8C] in the same order; wf2 [C][4C])
  * All 16-bit operands in the build's element type, biases / c1 / c2 fp32.  dmx_xf_chain_supported: 1 for (M, C) it takes.
- * The UNet executor takes the chains when the M / 64 row blocks fill their last round of CUs to at least 3/4; dmx_set_xf_chain(0) makes it use the separate
+ * The UNet executor takes the chains when the M / 64 row blocks fill their last round of CUs at least half; dmx_set_xf_chain(0) makes it use the separate
  * GEMMs always, 2 the chains at every supported size (A/B runs in one process); returns the old setting. */
 typedef struct {
   int M, C;
