@@ -169,6 +169,7 @@ void Exec::peek(const void** p, int* n, int slots) {
   for (int i = 0, k = plan_i; i < slots && k < (int)plan->w.size() && left > 0; ++k) {
     if (!plan->w[k].first || plan->w[k].second <= 0) continue;
     const long nb = plan->w[k].second < left ? plan->w[k].second : left;
+    if (nb < 1024) break;                              // (the kernels clamp the last unit to nb - 16: never a range shorter than a unit)
     p[i] = plan->w[k].first; n[i] = (int)nb; left -= nb; ++i;
   }
 }
