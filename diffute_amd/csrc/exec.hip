@@ -444,7 +444,7 @@ void Exec::xf_chain(int mode, XfChainArgs& a) {
   if (mode == 0) note(a.w1, cc);
   else if (mode == 2) note(a.w1, 3 * cc);
   else { note(a.wf1, 8 * cc); note(a.wf2, 4 * cc); note(a.wpo, cc); }
-  peek(a.pf, a.pf_bytes, 2);
+  peek(a.pf, a.pf_bytes, 4);
   if (dry || rc) return;
   rc = dmx_xf_chain_launch(a, mode, stream);
 }
@@ -464,7 +464,11 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
   AttnArgs a{};
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.v = v; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
-  peek(a.pf, a.pf_bytes, 4);
+  {   // (tuning aid DMX_PF_ATTN=0: the attention launches issue no prefetch units - the launches in front of them already cover the next ranges)
+    static int attn_pf = -1;
+    if (attn_pf < 0) { const char* e = getenv("DMX_PF_ATTN"); attn_pf = e ? atoi(e) : 1; }
+    if (attn_pf) peek(a.pf, a.pf_bytes, 4);
+  }
   char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
   ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv), tag);
   rc = dmx_attention_launch(a, stream);

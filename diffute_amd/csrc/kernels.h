@@ -200,7 +200,7 @@ struct XfChainArgs {
   // mode 1: DmxStat records of the block output y for the GroupNorm that reads it next ([M / cs_rows][C][4], added to; cs_rows = rows per
   // sample, a multiple of 64), or null
   long long* colstats; int cs_rows;
-  const void* pf[2]; int pf_bytes[2];      // optional: byte ranges (the next launches' weights) the blocks touch at their start (Exec::peek)
+  const void* pf[4]; int pf_bytes[4];      // optional: byte ranges (the next launches' weights) the blocks touch at their start (Exec::peek)
   // mode 2: x is the RAW tensor and the block normalises its rows on the way into the fragments: GroupNorm (no activation) from the DmxStat
   // records of x ([M / gn_rows][C][4]; gn_rows = rows per sample, a multiple of 64) - the same arithmetic, to the bit, as dmx_groupnorm's
   // apply pass followed by the plain mode 2.  Null gn_st: x is already normalised

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void dmx_xf_chain_kernel(const XfChainArgs 
   // ---- weight prefetch for the launches that follow (XfChainArgs.pf): 1-KB units over (block, wave), the oldest requests of each wave
   int pf_left = 4;                                     // (at most four units per wave)
 #pragma unroll
-  for (int r_ = 0; r_ < 2; ++r_) {
+  for (int r_ = 0; r_ < 4; ++r_) {
     const int nb_ = p.pf_bytes[r_];
     for (int u_ = blockIdx.x * 8 + w; u_ * 1024 < nb_ && pf_left > 0; u_ += gridDim.x * 8, --pf_left) {
       int off_ = u_ * 1024 + lane * 16; if (off_ > nb_ - 16) off_ = nb_ - 16;
