@@ -139,6 +139,37 @@ def test_tiny_unet_on_the_160_column_tiles(cuda):
     assert rel_l2(y, ref) < 2e-2 and not torch.equal(y, ref), "the override must have changed at least one GEMM's tile plan"
 
 
+def test_weight_prefetch_plan_changes_no_result(cuda):
+    """The weight prefetch plan (every launch of dmx_unet_forward* touches the weights of the launches that follow it, Exec::note / peek)
+    only moves data into the memory-side cache: eps with the plan on and off is bit-identical - at the tiny configuration and at a
+    full-size one (256 px, every kernel family of the headline pass: chains off at this size, fused GroupNorm -> conv on), eager and
+    through the captured graph.  The dry walk and the real walk must also agree on the launch list (the library checks that itself)."""
+    import diffute_amd as D
+    from diffute_amd import _cabi
+    from diffute_amd.synthetic import synth_inputs
+    lib = _cabi.lib()
+    cases = [(D.UNet2DConditionModel(**TINY_UNET).cuda().requires_grad_(False), synth_inputs(2, 16, 32, 40, 128, device=cuda, seed=7)),
+             (D.UNet2DConditionModel(device=cuda).requires_grad_(False), synth_inputs(2, 32, 32, 577, 1024, device=cuda, seed=8))]
+    try:
+        for unet, (lat, mask, mlat, ctx) in cases:
+            t = torch.tensor([437], device=cuda)
+            outs = {}
+            for on in (1, 0, 1):
+                lib.dmx_set_weight_prefetch(on)
+                unet.set_context(ctx)
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    e = unet.forward_parts([lat, mask, mlat], t).clone()
+                    g = unet.forward_parts([lat, mask, mlat], t, graph=True).clone()
+                    _cabi.check(unet._lib.dmx_unet_refresh_derived(unet._h, None), "refresh")      # drop the captured graph: it embeds the setting
+                torch.cuda.synchronize()
+                assert torch.equal(e, g), "graph replay differs from the eager launch"
+                outs.setdefault(on, []).append(e)
+            assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][0], outs[1][1]), "the prefetch plan changed a result"
+    finally:
+        lib.dmx_set_weight_prefetch(1)
+
+
 def test_fused_groupnorm_conv_inside_the_models(cuda):
     """conv_halo.hip inside whole models: the executors fuse GroupNorm -> SiLU -> conv3x3 of every ResnetBlock2D only at the levels
     where it pays at the bench batch (>= 32 x 32 pixels), which the tiny configurations barely reach - so here the fused launch is
