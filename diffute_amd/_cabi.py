@@ -75,6 +75,9 @@ _P = c_void_p
 _PROTOS = {
     "dmx_version": (c_int, []),
     "dmx_last_error": (c_char_p, []),
+    "dmx_device_error": (c_int, []),
+    "dmx_test_raise_device_error": (c_int, [c_int, c_void_p]),
+    "dmx_test_occupy_cus": (c_int, [c_int, c_int64, c_void_p]),
     "dmx_element_type": (c_char_p, []),
     "dmx_conv_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "dmx_conv_gemm": (c_int, [POINTER(GemmDesc), _P, c_size_t, _P]),
@@ -286,6 +289,13 @@ def check(rc, what="", l=None):
             l = _lib_f16 if (_last_elem == "fp16" and _lib_f16 is not None) else lib()
         msg = l.dmx_last_error()
         raise RuntimeError(f"diffute_amd: {what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def poll_device_error(l=None):
+    """raise if a kernel of an EARLIER launch gave up on an in-kernel wait (include/diffute_hip.h dmx_device_error): no synchronisation, so
+    call it after your own synchronize() to cover the launches in flight"""
+    for lb in ([l] if l is not None else [x for x in (_lib, _lib_f16) if x is not None]):
+        check(lb.dmx_device_error(), "device error poll", lb)
 
 
 def ptr(t):

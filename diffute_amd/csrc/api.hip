@@ -336,3 +336,33 @@ extern "C" int dmx_gaussian_sample(const float* moments, const float* noise, flo
   return dmx_gaussian_sample_launch(moments, noise, out, B, C, HW, scale, (hipStream_t)stream);
 }
 extern "C" size_t dmx_groupnorm_workspace_bytes(int B, int HW, int groups) { return dmx_gn_workspace_bytes(B, HW, groups); }
+
+// ---- test support (tests/test_ops_gpu.py: the device -> host error channel).  dmx_test_raise_device_error launches one thread that raises
+// `code` like a kernel that gave up on a wait; dmx_test_occupy_cus keeps `blocks` CUs busy for `ticks` x 10 ns with a block that fills the CU's
+// LDS (nothing else becomes resident next to it) - the "another stream holds the CUs" situation in which the peers of a K-split tile are not
+// co-resident.
+__global__ void dmx_test_raise_kernel(int* err, int code, int d0, int d1, int d2) { dmx_dev_raise(err, code, (int)blockIdx.x, d0, d1, d2); }
+extern "C" int dmx_test_raise_device_error(int code, dmx_stream_t stream) {
+  int* e = dmx_dev_err_words();
+  DMX_REQUIRE(e != nullptr, "test_raise_device_error: no pinned error words");
+  hipLaunchKernelGGL(dmx_test_raise_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e, code, 11, 22, 33);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { dmx_set_error("launch of dmx_test_raise_kernel failed: %s", hipGetErrorString(le)); return DMX_ERR_HIP; }
+  return DMX_OK;
+}
+__global__ __launch_bounds__(64) void dmx_test_occupy_kernel(long long ticks, int* sink) {
+  extern __shared__ char hog[];
+  hog[threadIdx.x] = (char)threadIdx.x;
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (hog[(threadIdx.x + 1) & 63] == 77 && sink) *sink = 1;
+}
+extern "C" int dmx_test_occupy_cus(int blocks, long long ticks, dmx_stream_t stream) {
+  constexpr int LDS = 160 * 1024;
+  DMX_REQUIRE(blocks > 0 && ticks > 0 && ticks <= 50000000, "test_occupy_cus: blocks > 0, 0 < ticks <= 5e7 (0.5 s)");
+  DMX_LDS_OPT_IN(dmx_test_occupy_kernel, LDS);
+  hipLaunchKernelGGL(dmx_test_occupy_kernel, dim3(blocks), dim3(64), LDS, (hipStream_t)stream, ticks, (int*)nullptr);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { dmx_set_error("launch of dmx_test_occupy_kernel failed: %s", hipGetErrorString(le)); return DMX_ERR_HIP; }
+  return DMX_OK;
+}

@@ -34,9 +34,30 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define DMX_ERR_HIP (-2)
 #define DMX_ERR_UNSUPPORTED (-3)
 #define DMX_ERR_WORKSPACE (-4)
+#define DMX_ERR_DEVICE (-5)            // a kernel gave up on an in-kernel wait (a peer block never published): the result of that launch is invalid
 
 void dmx_set_error(const char* fmt, ...);
 int dmx_check_launch(const char* what);
+
+// ---- device -> host error channel.  Eight ints of pinned host memory mapped into the device address space (one set per process):
+// [0] code (the DmxDevKernel that raised, 0 = none), [1] claim word, [2] block, [3..5] kernel-specific detail.  A kernel that gives up on a
+// bounded in-kernel wait RAISES here (first raiser wins) and goes on, so the GPU never hangs; every later launch check (dmx_check_launch),
+// hipGraph replay and dmx_device_error() reads word 0 from the host side - no synchronisation - and returns DMX_ERR_DEVICE with the
+// detail in dmx_last_error().  The failing launch itself has returned by then: the error surfaces at the NEXT C-ABI call or poll.
+enum DmxDevKernel { DMX_DEVK_HALO_PEER = 1, DMX_DEVK_STREAMK_HELPER = 2 };
+int* dmx_dev_err_words();              // device-visible pointer (nullptr when the pinned allocation failed: kernels then do not raise)
+int dmx_poll_device_error();           // DMX_OK, or DMX_ERR_DEVICE + dmx_set_error(...) and the words cleared
+#ifdef __HIPCC__
+__device__ __forceinline__ void dmx_dev_raise(int* err, int kernel, int block, int d0, int d1, int d2) {
+  if (!err) return;
+  int expect = 0;
+  if (__hip_atomic_compare_exchange_strong(err + 1, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+    err[2] = block; err[3] = d0; err[4] = d1; err[5] = d2;
+    __atomic_thread_fence(__ATOMIC_RELEASE);                       // (system scope: the detail is in host memory before the code)
+    __hip_atomic_store(err, kernel, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+#endif
 
 #define DMX_REQUIRE(cond, ...)                \
   do {                                        \

@@ -465,7 +465,7 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
       double var = dmx_stat_sumsq(qh, ql) / n - mean * mean;
       var = var < 0.0 ? 0.0 : var;
       float* gs = (float*)(smem + L::GST);
-      gs[2 * g] = (float)mean; gs[2 * g + 1] = rsqrtf((float)var + p.eps);
+      gs[2 * g] = (float)mean; gs[2 * g + 1] = (float)(1.0 / __builtin_sqrt(var + (double)p.eps));      // (as dmx_gn_apply_kernel and the chain's folded GroupNorm: same bits on every path)
     }
   }
   if (TIMING) tp[1] = __builtin_amdgcn_s_memrealtime();
@@ -906,13 +906,14 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
     // one pass: after the staging the accumulators are dead, so every row of a thread is in flight at once (8-wave instances)
     stage(own0);
     if (t == 0) {
-      // peers' slabs: bounded spin (a lost peer must never hang the GPU: after ~40 ms the block goes on with what is there)
+      // peers' slabs: bounded spin.  A lost peer must never hang the GPU, and never pass silently either: after ~40 ms the block RAISES
+      // the device error (common.h dmx_dev_raise -> DMX_ERR_DEVICE at the next launch check / dmx_device_error()) and goes on
       const long long t0 = __builtin_amdgcn_s_memrealtime();
       for (int s = 0; s < S; ++s) {
         if (s == r) continue;
         while (__hip_atomic_load(p.flags + tile_slot + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
           __builtin_amdgcn_s_sleep(2);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > 4000000) break;
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 4000000) { dmx_dev_raise(p.err, DMX_DEVK_HALO_PEER, (int)blockIdx.x, tile_slot, s, S); break; }
         }
       }
     }
@@ -1003,10 +1004,12 @@ __global__ __launch_bounds__(512) void dmx_colstats_kernel(const bf16* x, int ld
   }
 }
 
-int n_cus() {
-  static int n_cu = 0;
-  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-  return n_cu;
+int n_cus() {                                          // of the CURRENT device (the K-split plans need a tile's blocks co-resident on it)
+  static int n_cu[64] = {};
+  int dev = 0; (void)hipGetDevice(&dev);
+  int& n = n_cu[dev & 63];
+  if (!n) { (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); if (n <= 0) n = 256; }
+  return n;
 }
 
 // Plan: tile geometry, column width BN (160 / 128: 4 x 2 waves; 80 / 64: 8 x 1 waves) and K split.  A K split costs an exchange of fp32
@@ -1071,12 +1074,23 @@ bool dmx_conv_halo_pays(const HaloConvArgs& a) {
   return (long)a.H * a.W >= 1024;
 }
 
+static long halo_blocks(const HaloConvArgs& a, const HaloPlan& P);
+// the block decode divides by multiplication (hb_div: magic = 2^32 / d + 1), exact only while x * d < 2^32 for every dividend x
+// (block index, channel, patch row) and divisor d of the decode
+static bool halo_decode_ok(const HaloConvArgs& a, const HaloPlan& P) {
+  const long tiles_x = a.W / P.TW, tiles_img = tiles_x * (a.H / P.TH), tiles_m = (long)a.B * tiles_img, ncombo = (long)(a.N / P.bn) * P.splits;
+  long dmax = tiles_m; for (long d : {ncombo, tiles_img, tiles_x, (long)P.TW + 2, (long)(a.gn ? a.Cin / a.groups : 1)}) if (d > dmax) dmax = d;
+  long xmax = halo_blocks(a, P); for (long x : {(long)a.Cin, (long)(P.TH + 2) * (P.TW + 2) * 8}) if (x > xmax) xmax = x;
+  return xmax < (1l << 31) && dmax < (1l << 31) && (unsigned long long)xmax * (unsigned long long)dmax < (1ull << 32);
+}
+
 bool dmx_conv_halo_supported(const HaloConvArgs& a) {
   if (a.Cin <= 0 || a.Cin % 64 || a.cx0 % 64 || a.cx0 > a.Cin || a.Csc % 64 || (a.Csc && a.cs0 % 64) || a.N % 8 || a.ldo % 8) return false;
   if (a.ldx0 % 8 || (a.x1 && a.ldx1 % 8) || a.ldw % 8 || (a.res && a.ldres % 8)) return false;
   if (a.gn && (a.groups != 32 || a.Cin % a.groups)) return false;
   if (a.force_split && (a.force_split & (a.force_split - 1) || a.force_split > 8)) return false;
-  return halo_plan(a).splits > 0;
+  const HaloPlan P = halo_plan(a);
+  return P.splits > 0 && halo_decode_ok(a, P);         // (larger problems: GroupNorm + the implicit GEMM, whose decode is 64-bit)
 }
 
 static long halo_blocks(const HaloConvArgs& a, const HaloPlan& P) {
@@ -1113,12 +1127,13 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
   if (!a.s1) { a.s1 = a.s0; a.lds1 = a.lds0; }
   int rc = dmx_zero_page(&a.zeros);
   if (rc) return rc;
+  a.err = dmx_dev_err_words();
   const HaloPlan P = halo_plan(a);
   a.TH = P.TH; a.TW = P.TW; a.splits = P.splits;
   const int blocks = (int)halo_blocks(a, P);
   a.tiles_x = a.W / P.TW; a.tiles_img = a.tiles_x * (a.H / P.TH); a.tiles_m = a.B * a.tiles_img; a.ncombo = (a.N / P.bn) * P.splits;
   a.cpg = a.gn ? a.Cin / a.groups : 1;
-  DMX_REQUIRE(blocks < (1 << 20) && a.Cin < (1 << 20), "conv_halo: problem too large for the block decode (%d blocks)", blocks);
+  DMX_REQUIRE(halo_decode_ok(a, P), "conv_halo: problem too large for the block decode (%d blocks, %d pixel tiles)", blocks, a.tiles_m);
   a.mg_tiles_x = halo_magic(a.tiles_x); a.mg_tiles_img = halo_magic(a.tiles_img); a.mg_tiles_m = halo_magic(a.tiles_m);
   a.mg_ncombo = halo_magic(a.ncombo); a.mg_pw = halo_magic(P.TW + 2); a.mg_cpg = halo_magic(a.cpg);
   // block -> XCD dealing: weights-major when the weight slab is the larger stream of an XCD, pixel-tile-major otherwise
@@ -1132,7 +1147,7 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
     const size_t fb = halo_flag_bytes(blocks), need = fb + (size_t)blocks * 256 * P.bn * sizeof(float);
     if (!workspace || workspace_bytes < need) { dmx_set_error("conv_halo: the K split needs %zu bytes of workspace, got %zu", need, workspace_bytes); return DMX_ERR_WORKSPACE; }
     a.slabs = (float*)((char*)workspace + fb);
-    if (!a.flags) { a.flags = (int*)workspace; DMX_HIP(hipMemsetAsync(a.flags, 0, fb, stream)); }
+    if (!a.flags) { a.flags = (int*)workspace; if (const int zr = dmx_zero16_launch(a.flags, fb, stream)) return zr; }      // a kernel node, not a memset node: exec.hip Exec::zero_pool
   }
   const double flops = 2.0 * a.B * a.H * a.W * (double)a.N * (9.0 * a.Cin + a.Csc);
   const double bytes = 2.0 * ((double)a.B * a.H * a.W * (a.Cin + a.Csc + a.N) + (double)a.N * (9.0 * a.Cin + a.Csc));

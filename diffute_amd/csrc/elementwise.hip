@@ -200,6 +200,20 @@ int dmx_zero_insert2_launch(const bf16* dy, int lddy, bf16* z, int B, int OH, in
   hipLaunchKernelGGL(dmx_zero_insert2_kernel, dim3(blocks), dim3(256), 0, stream, dy, lddy, z, B, OH, OW, C);
   return dmx_check_launch("dmx_zero_insert2_kernel");
 }
+// zero `bytes` (a multiple of 16, 16-byte aligned) of device memory as an ordinary KERNEL node: the per-forward flag / statistics pools of the
+// executors (exec.hip).  Not hipMemsetAsync: see Exec::zero_pool.
+__global__ __launch_bounds__(256) void dmx_zero16_kernel(u32x4* p, size_t n16) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+}
+int dmx_zero16_launch(void* p, size_t bytes, hipStream_t stream) {
+  DMX_REQUIRE(bytes % 16 == 0 && ((size_t)p & 15) == 0, "zero16: %zu bytes at %p are not 16-byte units", bytes, p);
+  if (!bytes) return DMX_OK;
+  const size_t n16 = bytes / 16;
+  int blocks = (int)((n16 + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dmx_zero16_kernel, dim3(blocks), dim3(256), 0, stream, (u32x4*)p, n16);
+  return dmx_check_launch("dmx_zero16_kernel");
+}
 // nearest x2 upsample backward: dx[b][y][x] (+)= sum of the 2x2 block of du (bf16 or fp32 in; fp32 sum, one rounding)
 template <bool F32IN>
 __global__ __launch_bounds__(256) void dmx_sumpool2_kernel(const void* du_, int lddu, bf16* dx, int lddx, int B, int H, int W, int C, int accumulate) {

@@ -135,6 +135,7 @@ class Exec {
   int* flag_pool = nullptr; size_t flag_cap = 0, flag_used = 0;
   // Statistics slices (Tn::cst) come from a pool zeroed once per forward as well (the producers ADD into them).
   long long* cs_pool = nullptr; size_t cs_cap = 0, cs_used = 0;
+  bool zero_pool(void* p, size_t bytes, int which);
   void want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B);
   long long* stat_slice(int B, int C);
   // statistics records of a tensor whose producer emitted none (one streaming pass, conv_halo.hip dmx_colstats_launch); no-op when
@@ -174,7 +175,7 @@ class Exec {
   // launch asks for the ranges of the launches that FOLLOW it (peek()) and its blocks touch them at their start, so that they sit in
   // the memory-side cache when the next kernel's blocks - which walk them in lock step - ask for them (gemm.hip / attention.hip)
   struct PfPlan { std::vector<std::pair<const void*, long>> w; };
-  PfPlan* plan = nullptr; bool plan_rec = false; int plan_i = 0;
+  PfPlan* plan = nullptr; bool plan_rec = false, plan_bad = false; int plan_i = 0;
   void note(const void* w, long bytes);
   void peek(const void** p, int* n, int slots);
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,

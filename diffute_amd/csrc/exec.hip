@@ -10,10 +10,37 @@ void dmx_set_error(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 const char* dmx_get_error() { return g_err; }
+static int* g_dev_err = nullptr;        // pinned + mapped (hipHostMalloc): host and device use the same address
+int* dmx_dev_err_words() {
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && p) { memset(p, 0, 64); g_dev_err = (int*)p; }
+    else (void)hipGetLastError();
+  }
+  return g_dev_err;
+}
+int dmx_poll_device_error() {
+  volatile int* e = g_dev_err;
+  if (!e || !e[0]) return DMX_OK;
+  const int k = e[0], blk = e[2], d0 = e[3], d1 = e[4], d2 = e[5];
+  if (k == DMX_DEVK_HALO_PEER)
+    dmx_set_error("device error: conv3x3_gn (halo conv) block %d gave up after 40 ms waiting for the K-split slab of peer %d of tile slot %d (splits %d) - "
+                  "the blocks of a tile were not co-resident (CUs taken by another stream?); the result of that launch is invalid", blk, d1, d0, d2);
+  else if (k == DMX_DEVK_STREAMK_HELPER)
+    dmx_set_error("device error: stream-K GEMM block %d (tile %d) gave up after 40 ms waiting for the partial sums of helper block %d - "
+                  "the blocks of the launch were not co-resident; the result of that launch is invalid", blk, d0, d1);
+  else
+    dmx_set_error("device error %d raised by block %d (%d, %d, %d)", k, blk, d0, d1, d2);
+  for (int i = 7; i >= 0; --i) e[i] = 0;                        // cleared: the process may go on after handling it
+  return DMX_ERR_DEVICE;
+}
+extern "C" int dmx_device_error(void) { return dmx_poll_device_error(); }
 int dmx_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dmx_set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return DMX_ERR_HIP; }
-  return DMX_OK;
+  return dmx_poll_device_error();
 }
 
 // --------------------------------------------------------------------------- profiler
@@ -130,13 +157,55 @@ static int g_halo_conv = 1;
 extern "C" int dmx_set_halo_conv(int on) { const int old = g_halo_conv; g_halo_conv = on; return old; }
 bool dmx_halo_conv_enabled() { return g_halo_conv != 0; }
 
+// The per-forward pools (statistics records, stream-K / halo flags) are zeroed by a KERNEL node (dmx_zero16_launch), never by
+// hipMemsetAsync: a memset node of a captured hipGraph is not safe to replay on this runtime (ROCm 7.2, gfx950).  Measured in round 5
+// (EXPERIMENTS.md "non-finite latents"): when a pass replays a graph that an EARLIER pass captured (the loop's buffers alternate between
+// two address sets, so two instantiated graphs take turns), the memset node fills the whole 8-MB statistics pool with a 64-bit POINTER
+// value (0x73ebd9840000: the address of the loop's latents buffer) instead of zeros - its fill arguments are not owned by the graph
+// instance.  The producers then add onto garbage: wrong GroupNorm statistics, negative variances, NaN (BENCH_r04).
+#ifdef DMX_PROBES
+// probe builds only: dmx_set_pool_memset_nodes(1) goes back to memset nodes; with (3) a counting kernel before and after each memset
+// node records the non-zero 16-byte units it found and a sample of what the node wrote (scripts/soak.py --pool-counts)
+static int g_pool_memset_nodes = 0;
+static unsigned long long* g_pool_counts = nullptr;    // [stats, flags][before, after], [4..7] sample values
+extern "C" int dmx_set_pool_memset_nodes(int mode) { const int old = g_pool_memset_nodes; g_pool_memset_nodes = mode; return old; }
+__global__ __launch_bounds__(256) void dmx_probe_count_nonzero_kernel(const u32x4* p, size_t n16, unsigned long long* dst) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { const u32x4 v = p[i]; c += (v.x | v.y | v.z | v.w) != 0u; }
+  if (c) atomicAdd(dst, c);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && p[n16 - 1].x != 0u) { dst[4] = p[n16 - 1].x | ((unsigned long long)p[n16 - 1].y << 32); dst[5] = p[n16 / 2].x | ((unsigned long long)p[n16 / 2].y << 32); }   // units no producer ever adds to
+}
+extern "C" int dmx_probe_pool_counts(unsigned long long* host8, int reset) {
+  if (!g_pool_counts) { DMX_HIP(hipMalloc(&g_pool_counts, 128)); DMX_HIP(hipMemset(g_pool_counts, 0, 128)); }
+  DMX_HIP(hipDeviceSynchronize());
+  if (host8) DMX_HIP(hipMemcpy(host8, g_pool_counts, 64, hipMemcpyDeviceToHost));
+  if (reset) DMX_HIP(hipMemset(g_pool_counts, 0, 128));
+  return DMX_OK;
+}
+#endif
+bool Exec::zero_pool(void* p, size_t bytes, int which) {
+  if (dry || rc) return !rc;
+#ifdef DMX_PROBES
+  if (g_pool_memset_nodes & 1) {
+    const bool count = (g_pool_memset_nodes & 2) && g_pool_counts;
+    if (count) hipLaunchKernelGGL(dmx_probe_count_nonzero_kernel, dim3(256), dim3(256), 0, stream, (const u32x4*)p, bytes / 16, g_pool_counts + (which - 1) * 2);
+    if (hipMemsetAsync(p, 0, bytes, stream) != hipSuccess) { dmx_set_error("pool memset failed"); rc = DMX_ERR_HIP; return false; }
+    if (count) hipLaunchKernelGGL(dmx_probe_count_nonzero_kernel, dim3(256), dim3(256), 0, stream, (const u32x4*)p, bytes / 16, g_pool_counts + (which - 1) * 2 + 1);
+    return true;
+  }
+#endif
+  (void)which;
+  rc = dmx_zero16_launch(p, bytes, stream);
+  return !rc;
+}
+
 // a zeroed slice of DmxStat records [B][C][4] from the per-forward pool (null when it is exhausted)
 long long* Exec::stat_slice(int B, int C) {
   if (rc) return nullptr;
   if (!cs_pool) {
     cs_cap = (size_t)B * 64 * 1024;                    // 64 k channels per sample over the forward (SD2 UNet: ~42 k)
     cs_pool = (long long*)raw(cs_cap * DMX_STAT_WORDS * sizeof(long long)); cs_used = 0;
-    if (!dry && !rc && hipMemsetAsync(cs_pool, 0, cs_cap * DMX_STAT_WORDS * sizeof(long long), stream) != hipSuccess) { dmx_set_error("statistics pool memset failed"); rc = DMX_ERR_HIP; return nullptr; }
+    if (!zero_pool(cs_pool, cs_cap * DMX_STAT_WORDS * sizeof(long long), 1)) return nullptr;
   }
   const size_t n = (size_t)B * C;
   if (cs_used + n > cs_cap) return nullptr;
@@ -158,13 +227,17 @@ extern "C" int dmx_set_weight_prefetch(int on) { const int old = g_weight_prefet
 void Exec::note(const void* w, long bytes) {
   if (!plan) return;
   if (plan_rec) plan->w.push_back({w, bytes});
+  else if (plan_i >= (int)plan->w.size() || plan->w[plan_i].first != w) plan_bad = true;      // the real walk left the dry walk's launch order: no more ranges by index
   ++plan_i;
 }
 void Exec::peek(const void** p, int* n, int slots) {
   for (int i = 0; i < slots; ++i) { p[i] = nullptr; n[i] = 0; }
-  if (!plan || plan_rec || !g_weight_prefetch) return;
-  static long cap = 0;
-  if (!cap) { const char* e = getenv("DMX_PF_CAP_MB"); cap = e ? atol(e) << 20 : 4L << 20; if (cap <= 0) cap = 4L << 20; }   // (tuning aid)
+  if (!plan || plan_rec || plan_bad || !g_weight_prefetch) return;
+#ifdef DMX_PROBES
+  static const long cap = [] { const char* e = getenv("DMX_PF_CAP_MB"); long c = e ? atol(e) : 4; if (c <= 0 || c > 1024) c = 4; return c << 20; }();   // (probe builds: tuning aid)
+#else
+  constexpr long cap = 4L << 20;
+#endif
   long left = cap;                                     // per launch: a few DMA instructions per wave, not a second weight stream
   for (int i = 0, k = plan_i; i < slots && k < (int)plan->w.size() && left > 0; ++k) {
     if (!plan->w[k].first || plan->w[k].second <= 0) continue;
@@ -181,7 +254,7 @@ void Exec::run_gemm(GemmArgs& a) {
     constexpr size_t POOL = 64 * 1024;                 // ints: 256 launches of 256 blocks
     if (!flag_pool) {
       flag_pool = (int*)raw(POOL * sizeof(int)); flag_cap = POOL; flag_used = 0;
-      if (!dry && !rc && hipMemsetAsync(flag_pool, 0, POOL * sizeof(int), stream) != hipSuccess) { dmx_set_error("flag pool memset failed"); rc = DMX_ERR_HIP; return; }
+      if (!zero_pool(flag_pool, POOL * sizeof(int), 2)) return;
     }
     const size_t n = align_up((size_t)pg, 64);
     if (flag_used + n <= flag_cap) { a.flags = flag_pool + flag_used; flag_used += n; }   // else: the launcher zeroes a slice of its own workspace
@@ -334,7 +407,7 @@ Tn Exec::conv_gn(const Tn& x0, const Tn* x1, const float* gamma, const float* be
     constexpr size_t POOL = 64 * 1024;
     if (!flag_pool) {
       flag_pool = (int*)raw(POOL * sizeof(int)); flag_cap = POOL; flag_used = 0;
-      if (!dry && !rc && hipMemsetAsync(flag_pool, 0, POOL * sizeof(int), stream) != hipSuccess) { dmx_set_error("flag pool memset failed"); rc = DMX_ERR_HIP; return y; }
+      if (!zero_pool(flag_pool, POOL * sizeof(int), 2)) return y;
     }
     const size_t n = align_up((size_t)nflags, 64);
     if (flag_used + n <= flag_cap) { a.flags = flag_pool + flag_used; flag_used += n; }   // else: the launcher zeroes a slice of its own workspace
@@ -453,8 +526,11 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
                      bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale, bool kv_static) {
   // (kv_static: K | V live in the per-image context cache, written long before this launch - cold, and every block of a head walks them
   // in lock step: they join the prefetch plan like a weight matrix.  One interleaved buffer: ldk elements per key row.)
-  static int kv_pf = -1;
-  if (kv_pf < 0) { const char* e = getenv("DMX_PF_KV"); kv_pf = e ? atoi(e) : 1; }      // (tuning aid)
+#ifdef DMX_PROBES
+  static const int kv_pf = [] { const char* e = getenv("DMX_PF_KV"); return e ? atoi(e) : 1; }();      // (probe builds: tuning aid)
+#else
+  constexpr int kv_pf = 1;
+#endif
   if (kv_static && kv_pf) note(k, (long)B * kv_rows * ldk * 2);
   if (dry || rc) return;
   if (f32) {
@@ -464,9 +540,12 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
   AttnArgs a{};
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.v = v; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
-  {   // (tuning aid DMX_PF_ATTN=0: the attention launches issue no prefetch units - the launches in front of them already cover the next ranges)
-    static int attn_pf = -1;
-    if (attn_pf < 0) { const char* e = getenv("DMX_PF_ATTN"); attn_pf = e ? atoi(e) : 1; }
+  {
+#ifdef DMX_PROBES      // (probe builds, DMX_PF_ATTN=0: the attention launches issue no prefetch units - the launches in front of them already cover the next ranges)
+    static const int attn_pf = [] { const char* e = getenv("DMX_PF_ATTN"); return e ? atoi(e) : 1; }();
+#else
+    constexpr int attn_pf = 1;
+#endif
     if (attn_pf) peek(a.pf, a.pf_bytes, 4);
   }
   char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);

@@ -595,8 +595,14 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
     int q_end = pos + 1;
     while (q_end < nblk && bound(q_end) < tile_end_it) ++q_end;
     if (t == 0) {
+      // bounded: a helper that is not resident (the grid is one block per CU, but another stream may hold CUs) must neither hang the GPU
+      // nor pass silently - after ~40 ms the owner raises the device error (common.h) and goes on
+      const long long t0 = __builtin_amdgcn_s_memrealtime();
       for (int q = pos + 1; q < q_end; ++q)
-        while (__hip_atomic_load(p.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+        while (__hip_atomic_load(p.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(4);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 4000000) { dmx_dev_raise(p.err, DMX_DEVK_STREAMK_HELPER, pos, tile_id, q, nblk); break; }
+        }
     }
     __syncthreads();
     if (is_consumer) {
@@ -1362,10 +1368,10 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
       dmx_set_error("gemm: the persistent stream-K plan needs %zu bytes of workspace, got %zu", need, workspace_bytes);
       return DMX_ERR_WORKSPACE;
     }
-    a.persist = 1; a.partial = (float*)((char*)workspace + fb);
+    a.persist = 1; a.partial = (float*)((char*)workspace + fb); a.err = dmx_dev_err_words();
     if (!a.flags) {                                            // standalone call: the executors hand out slices of a pool they zero once per forward
       a.flags = (int*)workspace;
-      DMX_HIP(hipMemsetAsync(a.flags, 0, fb, stream));
+      if (const int zr = dmx_zero16_launch(a.flags, fb, stream)) return zr;      // a kernel node, not a memset node: exec.hip Exec::zero_pool
     }
     grid = dim3(g, 1, 1);
   } else if (sk > 1) {

@@ -56,7 +56,7 @@ struct GemmArgs {
   float* partial; int splitk, kt_per_split;   // filled by the launcher
   // persistent stream-K launch (filled by the launcher): grid = one block per CU walking (tile, K-range) items; `partial` holds
   // one accumulator slab per block, `flags` one int per block, all zero at launch (see the kernel's work-item loop)
-  int persist; int* flags;
+  int persist; int* flags; int* err;      // err: dmx_dev_err_words() (set by the launcher)
   // GroupNorm statistics of the output for its consumer (norm.hip dmx_groupnorm_sums_launch, conv_halo.hip): per (sample, channel) a
   // DmxStat record (common.h; 4 x int64 fixed point) of the rounded outputs, ADDED into colstats[(sample*N + n)*4 ..] (zero before the launch);
   // cs_rows = rows per sample (a tile must not straddle samples: cs_rows % tile rows == 0).  Plans without a reduce pass only
@@ -98,11 +98,11 @@ struct HaloConvArgs {
   long long* colstats;                               // DmxStat records of the OUTPUT [B][N][4], added to (zero before the launch), or null
   int force_split;                                   // 0 = automatic K split (1 / 2 / 4 / 8 blocks per tile)
   int force_bn;                                      // 0 = automatic column tile (160 / 128 / 80 / 64)
-  int force_waves;                                   // 0 = automatic; 8 / 16 waves per block (16: the 160 / 128-column tiles only)
+  int force_waves;                                   // 0 = automatic; 8 = two-group ping-pong; 4 / 12 = warp-specialised, 4 compute + 4 / 8 loader waves (160 / 128-column tiles, bf16 build)
   int dbg; long long* timing;                        // measurement aids (0 / null in the product path)
   const void* pf[2]; int pf_bytes[2];                // optional: byte ranges (the next launches' weights) the blocks touch at their start (Exec::peek)
   // filled by the launcher
-  int TH, TW, splits, xcd_tile_major; float* slabs; int* flags; const bf16* zeros;
+  int TH, TW, splits, xcd_tile_major; float* slabs; int* flags; const bf16* zeros; int* err;      // err: dmx_dev_err_words() (set by the launcher)
   // (the block decode of the kernel without integer divisions: x / d = (x * magic) >> 32 for the dividends that occur, all < 2^20)
   int tiles_x, tiles_img, tiles_m, ncombo, cpg;
   unsigned mg_tiles_x, mg_tiles_img, mg_tiles_m, mg_ncombo, mg_pw, mg_cpg;
@@ -293,6 +293,7 @@ int dmx_pack_geglu_bias_launch(const float* b, float* out, int n, hipStream_t st
 // training: transposed packs for data-gradient GEMMs, stride-2 / upsample adjoints
 int dmx_pack_conv_weight_t_launch(const float* w, bf16* out, int Cout, int Cin, int ks, int ldk, int koff, hipStream_t stream);
 int dmx_pack_rows_t_launch(const float* w, bf16* out, int rows, int cols, int ldo, hipStream_t stream);
+int dmx_zero16_launch(void* p, size_t bytes, hipStream_t stream);
 int dmx_zero_insert2_launch(const bf16* dy, int lddy, bf16* z, int B, int OH, int OW, int C, hipStream_t stream);
 int dmx_sumpool2_launch(const void* du, int lddu, int du_f32, bf16* dx, int lddx, int B, int H, int W, int C, int accumulate, hipStream_t stream);
 int dmx_cast_pad_rows_launch(const void* in, int in_is_bf16, bf16* out, int B, int S, int Spad, int C, hipStream_t stream);

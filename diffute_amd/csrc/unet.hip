@@ -561,9 +561,9 @@ int unet_run_planned(dmx_unet* u, Exec& ex, const float* f0, int c0, const float
     Exec dr; dr.dry = true; dr.ws.reset(nullptr, 0, true); dr.plan = &plan; dr.plan_rec = true;
     unet_run(u, dr, nullptr, c0, nullptr, c1, nullptr, c2, nullptr, t_count, cache, ctx_len, nullptr, B, H, W);
   }
-  ex.plan = &plan; ex.plan_rec = false; ex.plan_i = 0;
+  ex.plan = &plan; ex.plan_rec = false; ex.plan_bad = false; ex.plan_i = 0;
   int rc = unet_run(u, ex, f0, c0, f1, c1, f2, c2, timesteps, t_count, cache, ctx_len, out, B, H, W);
-  if (!rc && ex.plan_i != (int)plan.w.size()) { dmx_set_error("unet: the prefetch plan of the dry walk (%d launches) does not match the real walk (%d)", (int)plan.w.size(), ex.plan_i); rc = DMX_ERR_ARG; }
+  if (!rc && (ex.plan_bad || ex.plan_i != (int)plan.w.size())) { dmx_set_error("unet: the prefetch plan of the dry walk (%d launches) does not match the real walk (%d)", (int)plan.w.size(), ex.plan_i); rc = DMX_ERR_ARG; }
   ex.plan = nullptr;
   return rc;
 }
@@ -652,7 +652,7 @@ extern "C" int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, cons
   dmx_unet::GraphKey key(f0, f1, f2, timesteps, cache, out, workspace, c0, c1, c2, t_count, ctx_len, B, H, W, u->temb_table, u->temb_step);
   dmx_unet::GraphEntry& e = u->graphs[key];
   hipStream_t s = (hipStream_t)stream;
-  if (e.exec) { DMX_HIP(hipGraphLaunch(e.exec, s)); return DMX_OK; }
+  if (e.exec) { DMX_HIP(hipGraphLaunch(e.exec, s)); return dmx_poll_device_error(); }      // (what an earlier replay raised: common.h)
   if (e.seen++ == 0)        // first sight: eager (also runs every one-time hipFuncSetAttribute outside a capture)
     return dmx_unet_forward(u, f0, c0, f1, c1, f2, c2, timesteps, t_count, cache, ctx_len, out, B, H, W, workspace, workspace_bytes, stream);
   if (u->graphs.size() > 64) { u->graphs.erase(key); u->drop_graphs(); }

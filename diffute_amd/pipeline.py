@@ -78,6 +78,7 @@ def denoise(unet, scheduler, latents, mask, masked_image_latents, encoder_hidden
     with its own captured graph: one chain's kernels fill the CUs the other chain's small / draining kernels
     leave idle.  Results are identical to micro_batches=1 up to per-kernel tile-plan rounding."""
     _cabi.require_cuda(latents, mask, masked_image_latents, encoder_hidden_states)
+    _cabi.poll_device_error()            # what a kernel of an EARLIER pass raised (no sync; include/diffute_hip.h dmx_device_error)
     unet._ensure_packed()
     scheduler.set_timesteps(int(num_inference_steps))
     ts_host = [int(t) for t in scheduler.timesteps]

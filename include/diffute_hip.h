@@ -42,6 +42,15 @@ typedef struct dmx_vae dmx_vae;
 
 int dmx_version(void);
 const char* dmx_last_error(void);
+/* Device-side failures.  Kernels that wait for other blocks of their launch (the K-split slab exchange of dmx_conv3x3_gn, the
+ * stream-K fix-up of the persistent GEMMs) bound the wait (~40 ms); a block that gives up writes a record into pinned host memory
+ * and goes on (the GPU never hangs, the launch's result is invalid).  Every later launch of the library, every graph replay and this
+ * poll read the record WITHOUT synchronising and return DMX_ERR_DEVICE (-5) once, with the detail in dmx_last_error().  Call it
+ * after your own stream / device synchronisation to cover the last launches. */
+int dmx_device_error(void);
+/* test support for that channel: one thread raises `code`; `blocks` single-wave blocks that each fill a CU's LDS spin for ticks x 10 ns */
+int dmx_test_raise_device_error(int code, dmx_stream_t stream);
+int dmx_test_occupy_cus(int blocks, long long ticks, dmx_stream_t stream);
 /* The 16-bit storage / MFMA operand type this build of the library computes in: "bf16" (libdiffute_hip.so) or "fp16"
  * (libdiffute_hip_f16.so, the same sources compiled with -DDMX_F16).  Wherever this header says "bf16" for an activation,
  * weight or context buffer it means this element type.  The host mirror loads the fp16 build for a model moved with
@@ -172,7 +181,7 @@ typedef struct dmx_halo_conv_desc {
   long long* colstats;
   int force_split;                  /* 0 = automatic; 1 / 2 / 4 / 8 blocks share the K range of a tile (tests, tuning) */
   int force_bn;                     /* 0 = automatic; 160 / 128 / 80 / 64 output columns per block (tests, tuning) */
-  int force_waves;                  /* 0 = automatic; 8 / 16 waves per block (16: the 160 / 128-column tiles) */
+  int force_waves;                  /* 0 = automatic; 8 = two-group ping-pong; 4 / 12 = warp-specialised, 4 compute + 4 / 8 loader waves (160 / 128-column tiles, bf16 build) */
   int dbg; long long* timing;       /* measurement aids, 0 / NULL */
 } dmx_halo_conv_desc;
 int dmx_conv3x3_gn_supported(const dmx_halo_conv_desc* d);
