@@ -86,22 +86,27 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
 
   long long tm0 = 0, tm1 = 0, tm2 = 0;
   if (p.timing) tm0 = dmx_now(p.dbg);
-  if (p.pf_dump_off > 0 && (NP == 0 || (int)(threadIdx.x >> 6) >= NC)) {
-    // weight prefetch for the next launches (GemmArgs.pf): 1-KB units dealt over (block, wave); they are the oldest requests of the
-    // wave, so every counted vmcnt wait of the K loop covers them.  Only waves that stage tiles issue them (the consumer waves of the
-    // warp-specialised instance never wait on vmcnt: a request of theirs could still be writing the dump slot after the block has gone)
-    const int nblk_ = gridDim.x * gridDim.y, blk_ = blockIdx.y * gridDim.x + blockIdx.x, wv_ = threadIdx.x >> 6;
+  // weight prefetch for the next launches (GemmArgs.pf): 1-KB units dealt over (block, wave); they are the oldest requests of the
+  // wave, so every counted vmcnt wait of the K loop covers them and the vmcnt(0) behind the loop drains them.  Only waves that stage
+  // tiles issue them (the consumer waves of the warp-specialised instance never wait on vmcnt: a request of theirs could still be
+  // writing the dump slot after the block has gone) - in the warp-specialised instance the call sits INSIDE the loader branch, so that
+  // "every path from an LDS-DMA request to s_endpgm passes a vmcnt(0)" holds path by path (scripts/isa_audit.py rule L checks the binary)
+  auto issue_prefetch = [&]() {
+    if (p.pf_dump_off <= 0) return;
+    const int nblk_ = gridDim.x * gridDim.y, blk_ = blockIdx.y * gridDim.x + blockIdx.x, wv_ = (int)(threadIdx.x >> 6) - (NP > 0 ? NC : 0);
+    constexpr int NWV = NP > 0 ? NP : NT / 64;           // issuing waves per block
     int left_ = 4;                                     // at most four units per wave: a launch of few blocks (batch 1) must not turn into a weight stream
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int nb = p.pf_bytes[r];
-      for (int u = blk_ * (NT / 64) + wv_; u * 1024 < nb && left_ > 0; u += nblk_ * (NT / 64), --left_) {
+      for (int u = blk_ * NWV + wv_; u * 1024 < nb && left_ > 0; u += nblk_ * NWV, --left_) {
         int off = u * 1024 + (threadIdx.x & 63) * 16; if (off > nb - 16) off = nb - 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p.pf[r] + off),
                                          (__attribute__((address_space(3))) void*)(smem + p.pf_dump_off), 16, 0, 0);
       }
     }
-  }
+  };
+  if constexpr (NP == 0) issue_prefetch();
 
   // ---- work items.  Classic launch: one block = one (tile, K-slice) - tile from blockIdx.x, split-K slice from blockIdx.y.
   // Persistent stream-K launch (p.persist; grid = one block per CU): the flattened (tile, K-tile) iteration space is cut
@@ -420,6 +425,7 @@ __global__ __launch_bounds__(64 * (NWN * WM + NP), (TN == 5 && NWN == 2) ? 1 : (
     // warp-specialised: loader waves and MFMA waves run separate loops that meet at one s_barrier per K-tile
     // (separate loops keep the loaders' pointer state and the consumers' accumulators out of each other's live ranges)
     if (is_loader) {
+      issue_prefetch();
 #pragma unroll
       for (int s = 0; s < NSTAGE - 1; ++s) { advance_segment(); produce(s); }
       int kt = kt_begin;

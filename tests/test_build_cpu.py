@@ -55,3 +55,88 @@ def test_no_accumulator_spill_behind_an_asm_mfma(tmp_path, build):
                     bad.append(l)
     assert n_mfma > 1000, "the halo kernels were not found in the ISA"
     assert not bad, f"accumulator registers spilled right behind the MFMA that writes them: {bad[:3]}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ISA audit of the SHIPPED binaries (scripts/isa_audit.py): MFMA result hazards (rule M) and LDS-DMA drains (rule L) on every kernel of
+# both builds - VERDICT r4 item 1d.  The rule is calibrated on the compiler's own MFMAs (they must all pass) and on the synthetic streams
+# below (the violations must be seen).
+
+def _audit():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "scripts", "isa_audit.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def _stream(A, text):
+    """assemble-free: objdump-shaped lines -> [Inst]"""
+    out = []
+    for k, l in enumerate(text.strip().splitlines()):
+        mn, _, rest = l.strip().partition(" ")
+        out.append(A.Inst(0x100 + 4 * k, mn, A.split_ops(rest), l.strip(), None))
+    return out
+
+
+def test_isa_audit_rules_see_violations():
+    A = _audit()
+    rep = []
+    # 4-pass MFMA, its result read by a VALU after 2 states: needs 7
+    A.audit_mfma("k", _stream(A, """
+        v_mfma_f32_16x16x32_bf16 v[0:3], v[10:13], v[14:17], v[0:3]
+        s_nop 0
+        v_mov_b32_e32 v20, v21
+        v_add_f32_e32 v30, v1, v31
+        s_endpgm"""), rep)
+    assert len(rep) == 1 and "after 2 state(s) (need 7)" in rep[0]
+    rep = []
+    # the same with the pad inside (s_nop 6 = 7 states), an accumulate chain behind the MFMA (0 states) and a scratch spill of D after 11
+    A.audit_mfma("k", _stream(A, """
+        v_mfma_f32_32x32x16_bf16 v[0:15], v[20:23], v[24:27], v[0:15]
+        v_mfma_f32_32x32x16_bf16 v[0:15], v[28:31], v[32:35], v[0:15]
+        s_nop 10
+        scratch_store_dwordx4 off, v[0:3], s0
+        s_endpgm"""), rep)
+    assert rep == []
+    A.audit_mfma("k", _stream(A, """
+        v_mfma_f32_32x32x16_bf16 v[0:15], v[20:23], v[24:27], v[0:15]
+        s_nop 7
+        scratch_store_dwordx4 off, v[0:3], s0
+        s_endpgm"""), rep)
+    assert len(rep) == 1 and "need 11" in rep[0]
+    rep = []
+    # the result used as the A operand of the next MFMA without the pad
+    A.audit_mfma("k", _stream(A, """
+        v_mfma_f32_16x16x32_bf16 v[0:3], v[10:13], v[14:17], v[0:3]
+        v_mfma_f32_16x16x32_bf16 v[4:7], v[0:3], v[14:17], v[4:7]
+        s_endpgm"""), rep)
+    assert len(rep) == 1
+    # rule L: an LDS-DMA request that can reach s_endpgm without vmcnt(0) - and the same with the drain
+    rep = []
+    A.audit_lds_dma("k", _stream(A, """
+        global_load_lds_dwordx4 v[6:7], off
+        s_waitcnt vmcnt(1)
+        s_barrier
+        s_endpgm"""), rep)
+    assert len(rep) == 1 and rep[0].startswith("L ")
+    rep = []
+    A.audit_lds_dma("k", _stream(A, """
+        global_load_lds_dwordx4 v[6:7], off
+        s_waitcnt vmcnt(0) lgkmcnt(0)
+        s_barrier
+        s_endpgm"""), rep)
+    assert rep == []
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="llvm-objdump not available")
+@pytest.mark.parametrize("lib", ["libdiffute_hip.so", "libdiffute_hip_f16.so"])
+def test_isa_audit_of_the_built_library(lib):
+    """every kernel of the built library: no instruction touches an MFMA's result inside its software wait-state window (the asm MFMAs of
+    conv_halo.hip are invisible to LLVM's hazard recogniser), and every kernel that issues LDS-DMA drains it on every path to s_endpgm"""
+    path = os.path.join(ROOT, "diffute_amd", "lib", lib)
+    if not os.path.exists(path):
+        pytest.skip(f"{lib} not built")
+    A = _audit()
+    report, stats = A.audit_library(path)
+    assert stats["mfma"] > 2000 and stats["lds_dma_kernels"] > 20, f"the audit did not find the kernels: {stats}"
+    assert not report, "ISA audit violations:\n" + "\n".join(report[:10])
