@@ -24,9 +24,6 @@ if ROOT not in sys.path:
 
 # profile classes of the library (diffute_amd/csrc/kernels.h ProfClass); classes 10.. = one per GEMM tile config, named
 # after the rocprofv3 kernel name of that template instance dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP>
-# hipEvent bracketing costs about this much per launch in the profiled pass (measured: sum of bracketed launch times minus the
-# un-profiled pass time, divided by the launch count; round 1: (387 - 365) ms / 16 k launches); subtracted when ranking kernels
-EVENT_OVERHEAD_US = 1.4
 # plan id -> (class name, template arguments of dmx_gemm_kernel<WM, TN, BKT, NSTAGE, TM, NP, NWN, PS, MF>); ids 3-5 and 13 are retired
 GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2, false, 32>"), ("gemm_128x64x32", "<2, 1, 32, 4, 2, 0, 2, false, 32>"),
              ("gemm_256x128x64", "<4, 2, 64, 3, 2, 0, 2, false, 32>"), ("retired_3", ""), ("retired_4", ""), ("retired_5", ""),
@@ -35,11 +32,6 @@ GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2, false, 32>"), ("gemm_12
              ("gemm_128x160x64", "<4, 5, 64, 2, 1, 0, 1, false, 32>"), ("gemm_128x320x64", "<4, 5, 64, 2, 1, 0, 2, false, 32>"),
              ("streamk_256x160x64", "<8, 5, 64, 3, 1, 0, 1, true, 32>"), ("retired_13", ""),
              ("streamk_256x128x64", "<8, 4, 64, 3, 1, 0, 1, true, 32>"), ("streamk_256x160x64_mf16", "<4, 5, 64, 3, 4, 0, 2, true, 16>")]
-KERNEL_NAMES = {n: "void dmx_gemm_kernel%s(GemmArgs)" % (t[:-1] + ", false>" if t else t) for n, t in GEMM_CFGS}      # (+ CS = false: the plain twin)
-KERNEL_NAMES["attention_d64"] = "void dmx_attn_d64_kernel<true, 1, 4, 0>(AttnArgs)"
-# (the class covers the instances the planner picks per shape: warp-specialised <10, 4, 1, true> at the 64x64 level, two-group ping-pong
-#  <5, 4, 2, false> / <5, 8, 1, false> at the 32x32 level; the name - and the PMC traffic looked up by it - is the first one's)
-KERNEL_NAMES["conv3x3_gn_halo"] = "void (anonymous namespace)::dmx_conv_halo_kernel<10, 4, 1, true>(HaloConvArgs)"
 PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
                 "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS] + ["xf_chain", "conv3x3_gn_halo"]
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -49,7 +41,7 @@ def pmc_traffic(kernel_name):
     """bytes per launch of `kernel_name` from the committed PMC summary (scripts/rocprof_to_profiles.py), or None"""
     import csv
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(here, f) for f in ("r04_pmc_traffic.csv", "r03_pmc_traffic.csv", "r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if os.path.exists(os.path.join(here, f))), None)
+    path = next((os.path.join(here, f) for f in ("r05_pmc_traffic.csv", "r04_pmc_traffic.csv", "r03_pmc_traffic.csv", "r02_pmc_traffic.csv", "r01_pmc_traffic.csv") if os.path.exists(os.path.join(here, f))), None)
     if path is None:
         return None
     for r in csv.DictReader(open(path)):
@@ -262,6 +254,7 @@ def main():
                    "weights": "random-init SD2-inpainting shapes (865,925,124 params), bf16 packed"},
         "loop_tflops_per_gpu": round(loop_flops * args.steps / elapsed / 1e12, 2),
         "loop_mfma_frac": round(loop_flops * args.steps / elapsed / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+        "passes_checked": {"n": n_pass, "all_finite": True, "all_bit_equal_to_pass0": True},
     }
 
     if rank == 0 and not args.no_profile:
@@ -281,25 +274,51 @@ def main():
                 classes[name] = {"launches": int(n), "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / n, 2),
                                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if fl > 0 and ms > 0 else None,
                                  "gbps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-        # dominant kernel = the MFMA kernel (a GEMM template instance or the attention kernel) with the most time in the pass,
-        # ranked and rated on event-overhead-corrected times (each bracketed launch carries ~EVENT_OVERHEAD_US of hipEvent cost,
-        # which would otherwise penalise the classes with many short launches)
-        def corrected_ms(k):
-            return max(classes[k]["total_ms"] - classes[k]["launches"] * EVENT_OVERHEAD_US * 1e-3, 1e-6)
-        dom = max((k for k in classes if k.startswith("gemm") or k.startswith("streamk") or k in ("attention_d64", "conv3x3_gn_halo")), key=corrected_ms)
-        n, ms, fl, by = buf[4 * PROF_CLASSES.index(dom):4 * PROF_CLASSES.index(dom) + 4]
-        ms = corrected_ms(dom)
-        ach = fl / (ms * 1e-3) / 1e12
+        # per kernel SYMBOL (the launch helpers note rocprofv3's spelling of the instance they launch): one class can span several
+        # template instances (the halo conv: warp-specialised / ping-pong / narrow tiles; every GEMM tile config: with and without
+        # the column-statistics epilogue), so the roofline is quoted for the dominant SYMBOL, with its class total beside it
+        sbuf = ctypes.create_string_buffer(1 << 16)
+        nb = lib.dmx_profile_symbols(sbuf, len(sbuf))
+        symbols = []
+        for line in sbuf.raw[:nb].decode().splitlines():
+            c, n_, ms_, fl_, by_, sym = line.split("\t", 5)
+            symbols.append({"symbol": sym, "class": PROF_CLASSES[int(c)], "launches": int(float(n_)), "ms": float(ms_), "flops": float(fl_), "bytes": float(by_)})
         profiled_total = sum(c["total_ms"] for c in classes.values())
-        result["profile_overhead_ms"] = round(profiled_total - ms_per_step, 3)      # > 0: hipEvent bracketing of ~17 k launches (the classes sum to more than the timed pass)
+        n_launch = sum(c["launches"] for c in classes.values())
+        # hipEvent cost per bracketed launch, derived in this run: the bracketed times of the profiled pass sum to more than the timed
+        # (un-profiled, graph-replayed) pass by the event records inside the brackets
+        ev_us = max(0.0, 1e3 * (profiled_total - ms_per_step) / max(n_launch, 1))
+        result["profile_overhead_ms"] = round(profiled_total - ms_per_step, 3)
+        result["event_overhead_us_per_launch"] = round(ev_us, 3)
+        mfma_syms = [q for q in symbols if q["flops"] > 0]
+        for q in mfma_syms:
+            q["ms_corrected"] = max(q["ms"] - q["launches"] * ev_us * 1e-3, 1e-6)
+        dom = max(mfma_syms, key=lambda q: q["ms_corrected"])
+        ach = dom["flops"] / (dom["ms_corrected"] * 1e-3) / 1e12
+        cls = classes[dom["class"]]
+        cls_syms = [q for q in mfma_syms if q["class"] == dom["class"]]
+        cls_ms = sum(q["ms_corrected"] for q in cls_syms)
+        cls_tr = [pmc_traffic(q["symbol"]) for q in cls_syms]
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(KERNEL_NAMES[dom]),
-                              "kernel": KERNEL_NAMES[dom],
-                              "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
-                              "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
-                              "algorithmic_bytes_per_launch": round(by / n),      # launch-weighted activations + weights + output of this class: compare with `traffic`
+                              "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom["symbol"]),
+                              "kernel": dom["symbol"],
+                              "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms_corrected"] / dom["launches"], 2),
+                              "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
+                              "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),      # activations + weights + output of this symbol's launches: compare with `traffic`
+                              "class": {"name": dom["class"], "symbols": len(cls_syms), "launches": cls["launches"], "total_ms": round(cls_ms, 3),
+                                        "tflops": round(sum(q["flops"] for q in cls_syms) / (cls_ms * 1e-3) / 1e12, 1),
+                                        "frac": round(sum(q["flops"] for q in cls_syms) / (cls_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                        # launch-weighted PMC traffic over the symbols of the class that the committed profile lists
+                                        "traffic_launch_weighted": (round(sum(t * q["launches"] for t, q in zip(cls_tr, cls_syms) if t is not None) /
+                                                                          max(sum(q["launches"] for t, q in zip(cls_tr, cls_syms) if t is not None), 1))
+                                                                    if any(t is not None for t in cls_tr) else None)},
                               "whole_loop_frac": result["loop_mfma_frac"],
-                              "note": "hipEvent-bracketed launches over one 50-step pass, minus %.1f us of event overhead per launch; whole_loop_frac = algorithmic FLOPs of the whole 50-step loop / timed pass / peak; traffic = HBM bytes per launch of this kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ (FETCH x2 per the gfx950 note), null if absent" % EVENT_OVERHEAD_US}
+                              "note": "dominant kernel SYMBOL of one hipEvent-bracketed 50-step pass (event cost per launch derived in-run: bracketed sum minus the timed pass, "
+                                      "over the launch count); class = all template instances of that kernel family; whole_loop_frac = algorithmic FLOPs of the whole loop / timed pass / peak; "
+                                      "traffic = HBM bytes per launch of this symbol from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ "
+                                      "(FETCH x2 per the gfx950 note), null if that symbol is absent there"}
+        result["kernel_symbols"] = sorted(({"symbol": q["symbol"], "class": q["class"], "launches": q["launches"], "total_ms": round(q["ms_corrected"], 3),
+                                            "tflops": round(q["flops"] / (q["ms_corrected"] * 1e-3) / 1e12, 1)} for q in mfma_syms), key=lambda q: -q["total_ms"])[:12]
         result["kernel_classes"] = classes
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -213,6 +213,7 @@ _PROTOS = {
     "dmx_profile_begin": (c_int, []),
     "dmx_profile_end": (c_int, [POINTER(ctypes.c_double), c_int]),
     "dmx_profile_dump_path": (c_int, [c_char_p]),
+    "dmx_profile_symbols": (c_size_t, [c_char_p, c_size_t]),
     "dmx_vae_create": (_P, [POINTER(VAEConfig)]),
     "dmx_vae_destroy": (None, [_P]),
     "dmx_vae_param_count": (c_int, [_P]),

@@ -370,6 +370,7 @@ int dmx_attention_launch(const AttnArgs& a, hipStream_t stream) {
 #else
     hipLaunchKernelGGL((dmx_attn_d64_kernel<true, 1, 4>), grid, dim3(256), 0, stream, a);
 #endif
+    dmx_profile_note_symbol("void dmx_attn_d64_kernel<true, 1, 4, 0>(AttnArgs)");
   } else {
     grid = dim3(cdiv(a.Sq, 128), a.H, a.B);
     DMX_REQUIRE(a.vt && a.ldvt % 8 == 0 && a.skv_stride % 8 == 0, "attention: V^T strides must be multiples of 8 (ldvt=%d skv_stride=%d)", a.ldvt, a.skv_stride);

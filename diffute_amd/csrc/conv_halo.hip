@@ -1113,6 +1113,11 @@ size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a) {
 
 template <int NF, int WMW, int WNW, bool WS = false> static int halo_launch_(const HaloConvArgs& a, int blocks, hipStream_t stream) {
   DMX_LDS_OPT_IN((dmx_conv_halo_kernel<NF, WMW, WNW, WS>), (HaloLds<NF, WMW, WNW, WS>::TOTAL));
+  {
+    char sym[112];
+    snprintf(sym, sizeof(sym), "void (anonymous namespace)::dmx_conv_halo_kernel<%d, %d, %d, %s>(HaloConvArgs)", NF, WMW, WNW, WS ? "true" : "false");
+    dmx_profile_note_symbol(sym);
+  }
   hipLaunchKernelGGL((dmx_conv_halo_kernel<NF, WMW, WNW, WS>), dim3(blocks), dim3(HaloLds<NF, WMW, WNW, WS>::NT), (HaloLds<NF, WMW, WNW, WS>::TOTAL), stream, a);
   return dmx_check_launch("dmx_conv_halo_kernel");
 }

@@ -45,14 +45,16 @@ int dmx_check_launch(const char* what) {
 
 // --------------------------------------------------------------------------- profiler
 namespace {
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char tag[96]; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; char tag[96]; char sym[112]; };
+struct ProfSym { char sym[112]; int cls; double n, ms, flops, bytes; };
+std::vector<ProfSym> g_prof_syms;                     // per kernel symbol, filled by dmx_profile_end
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 char g_prof_path[512] = "";
 }
 ProfScope::ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag) {
   if (!g_prof_on) return;
-  ProfRec r; r.cls = c; r.flops = flops; r.bytes = bytes; r.tag[0] = 0;
+  ProfRec r; r.cls = c; r.flops = flops; r.bytes = bytes; r.tag[0] = 0; r.sym[0] = 0;
   if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); r.tag[sizeof(r.tag) - 1] = 0; }
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   (void)hipEventRecord(r.a, s);
@@ -62,6 +64,12 @@ ProfScope::ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, con
 ProfScope::~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream_); }
 
 bool dmx_profile_active() { return g_prof_on; }
+// the kernel symbol (rocprofv3's spelling) of the launch the innermost open ProfScope brackets: called by the launch helpers, which know
+// their template arguments.  The last note of a scope wins.
+void dmx_profile_note_symbol(const char* sym) {
+  if (!g_prof_on || g_prof.empty() || !sym) return;
+  strncpy(g_prof.back().sym, sym, sizeof(g_prof.back().sym) - 1); g_prof.back().sym[sizeof(g_prof.back().sym) - 1] = 0;
+}
 extern "C" int dmx_profile_begin(void) {
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear(); g_prof_on = true; return DMX_OK;
@@ -72,16 +80,34 @@ extern "C" int dmx_profile_end(double* out, int n_out) {
   DMX_HIP(hipDeviceSynchronize());
   for (int i = 0; i < n_out; ++i) out[i] = 0.0;
   FILE* f = g_prof_path[0] ? fopen(g_prof_path, "w") : nullptr;
-  if (f) fprintf(f, "class,ms,flops,bytes,tag\n");
+  if (f) fprintf(f, "class,ms,flops,bytes,tag,symbol\n");
+  g_prof_syms.clear();
   for (auto& r : g_prof) {
     float ms = 0.f; (void)hipEventElapsedTime(&ms, r.a, r.b);
-    if (f) fprintf(f, "%d,%.6f,%.0f,%.0f,%s\n", r.cls, ms, r.flops, r.bytes, r.tag);
+    if (f) fprintf(f, "%d,%.6f,%.0f,%.0f,%s,\"%s\"\n", r.cls, ms, r.flops, r.bytes, r.tag, r.sym);
+    if (r.sym[0]) {
+      ProfSym* e = nullptr;
+      for (auto& q : g_prof_syms) if (!strcmp(q.sym, r.sym)) { e = &q; break; }
+      if (!e) { ProfSym q{}; strcpy(q.sym, r.sym); q.cls = r.cls; g_prof_syms.push_back(q); e = &g_prof_syms.back(); }
+      e->n += 1; e->ms += ms; e->flops += r.flops; e->bytes += r.bytes;
+    }
     if (r.cls * 4 + 3 < n_out) { out[r.cls * 4] += 1; out[r.cls * 4 + 1] += ms; out[r.cls * 4 + 2] += r.flops; out[r.cls * 4 + 3] += r.bytes; }
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   if (f) fclose(f);
   g_prof.clear();
   return DMX_OK;
+}
+// per kernel SYMBOL of the profiled region that dmx_profile_end closed last: one line "class<TAB>launches<TAB>ms<TAB>flops<TAB>bytes<TAB>symbol" each
+// (launches whose helper notes its symbol: the GEMM, halo-conv, chain and attention instances); returns the bytes written (0: buffer too small)
+extern "C" size_t dmx_profile_symbols(char* buf, size_t cap) {
+  size_t n = 0;
+  for (auto& q : g_prof_syms) {
+    const int w = snprintf(buf + n, n < cap ? cap - n : 0, "%d\t%.0f\t%.6f\t%.0f\t%.0f\t%s\n", q.cls, q.n, q.ms, q.flops, q.bytes, q.sym);
+    if (w < 0 || n + (size_t)w >= cap) return 0;
+    n += (size_t)w;
+  }
+  return n;
 }
 // optional: per-launch CSV written by the next dmx_profile_end (empty path disables)
 extern "C" int dmx_profile_dump_path(const char* path) {

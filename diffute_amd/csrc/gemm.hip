@@ -1325,6 +1325,11 @@ static void launch_cfg_(const GemmArgs& a, dim3 grid, hipStream_t stream) {
   if (lds_epi > lds) lds = lds_epi;
   if (a.ln_stats || TN == 5) lds += (size_t)BM * 2 * sizeof(float);    // (mean, rstd) per row of the folded LayerNorm
   if (TN == 5) lds += (size_t)3 * BN * sizeof(float);                  // the tile's column vectors (160 / 320-column epilogue)
+  {
+    char sym[112];
+    snprintf(sym, sizeof(sym), "void dmx_gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d, %s>(GemmArgs)", WM, TN, BKT, NST, TM, NP, NWN, PS ? "true" : "false", MF, CS ? "true" : "false");
+    dmx_profile_note_symbol(sym);
+  }
   GemmArgs ap = a;                                                     // (the prefetch dump slot: 1 KB behind everything else, where it fits)
   ap.pf_dump_off = 0;
   if (a.pf_bytes[0] > 0 && lds + 1024 <= 163840 && (PS ? false : true)) { ap.pf_dump_off = (int)align_up(lds, 16); lds = (size_t)ap.pf_dump_off + 1024; }

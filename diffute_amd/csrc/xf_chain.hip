@@ -551,6 +551,7 @@ int dmx_xf_chain_launch(const XfChainArgs& a, int mode, hipStream_t stream) {
   {                                                                                                \
     DMX_LDS_OPT_IN((dmx_xf_chain_kernel<MODE_, ABL_>), XLDS);                                      \
     hipLaunchKernelGGL((dmx_xf_chain_kernel<MODE_, ABL_>), grid, block, XLDS, stream, a);          \
+    dmx_profile_note_symbol("void dmx_xf_chain_kernel<" #MODE_ ", " #ABL_ ">(XfChainArgs)");       \
   }
 #ifdef DMX_PROBES
   if (a.dbg & 3) {

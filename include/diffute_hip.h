@@ -564,6 +564,7 @@ int dmx_profile_begin(void);
 int dmx_profile_end(double* h_out, int n_out);
 /* optional: write one CSV row per launch (class, ms, flops, bytes, shape tag) at the next dmx_profile_end */
 int dmx_profile_dump_path(const char* h_path);
+size_t dmx_profile_symbols(char* buf, size_t cap);   /* per kernel SYMBOL of the region dmx_profile_end closed last: lines "class\tlaunches\tms\tflops\tbytes\tsymbol" (rocprofv3's spelling of the name); returns bytes written, 0 = buffer too small */
 
 #ifdef __cplusplus
 }
