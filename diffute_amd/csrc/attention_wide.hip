@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256, 1) void dmx_attn_wide_kernel(const AttnWideArg
       const unsigned rc = (unsigned)min(r, last);
       const unsigned kc = (unsigned)(dchk ^ (r & 15));                             // K: chunk XOR (row & 15)
       const unsigned vc = (unsigned)((((dchk >> 2) ^ (r & 3)) << 2) | (dchk & 3));  // V: 64-byte slot XOR (row & 3)
-      __builtin_amdgcn_global_load_lds((gptr_t)(kt + (rc * ldkb + kc * 16u)), (lptr_t)(ks + r0 * RS), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vt + (rc * ldvb + vc * 16u)), (lptr_t)(vs + r0 * RS), 16, 0, 0);
+      dmx_dma16(kt + (rc * ldkb + kc * 16u), DMX_LDS_ADDR(ks + r0 * RS));      // (asm, not the builtin: common.h dmx_dma16)
+      dmx_dma16(vt + (rc * ldvb + vc * 16u), DMX_LDS_ADDR(vs + r0 * RS));
     }
   };
   const int ntiles = (p.Skv + 31) / 32;

@@ -168,6 +168,22 @@ __device__ __forceinline__ void dmx_stat_add(long long* dst, float sum, float su
 __device__ __forceinline__ double dmx_stat_sum(long long s) { return (double)s * (1.0 / 1048576.0); }
 __device__ __forceinline__ double dmx_stat_sumsq(long long qh, long long ql) { return (double)qh * (1.0 / 256.0) + (double)ql * (1.0 / 1099511627776.0); }
 
+#ifdef __HIPCC__
+// LDS-DMA as an asm statement (16 bytes per lane -> lds_addr + 16 lane).  NOT __builtin_amdgcn_global_load_lds: hipcc knows that the builtin
+// writes LDS and, unable to prove that the tile it fills is not the tile being read, puts `s_waitcnt vmcnt(0)` in front of the next ds_read -
+// the prefetch of the NEXT K / V tile (and, in the first iteration, the weight prefetch units that come from HBM) was waited for right
+// after it had been issued, in every iteration (found in the ISA in round 5: the loop ran at half the speed its instruction mix allows).
+// The asm statement is invisible to that pass; the loops wait with their own counted `s_waitcnt vmcnt(N)` + barrier before a tile is read,
+// and scripts/isa_audit.py rule L checks the drain before s_endpgm.  M0 (the LDS base of the DMA) is saved and restored inside the statement.
+__device__ __forceinline__ void dmx_dma16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+#define DMX_LDS_ADDR(p) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(p))
+
+#endif
+
 // dynamic-LDS opt-in above 64 KB: a per-DEVICE function attribute, so it is set once per (kernel, device), result checked
 #define DMX_LDS_OPT_IN(kernel, bytes)                                                                        \
   do {                                                                                                       \
