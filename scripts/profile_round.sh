@@ -1,9 +1,9 @@
-# Regenerates profiles/rNN_* (default r04): rocprofv3 kernel stats of one bench pass + separate PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy),
+# Regenerates profiles/rNN_* (default r05): rocprofv3 kernel stats of one bench pass + separate PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy),
 # plus kernel-stat summaries of the secondary configurations (cfg3 VAE 32 x 512 px, cfg5 768 px loop, cfg4 per-GPU training step).
 # Run on the GPU box from the repo root: bash scripts/profile_round.sh ; outputs land in gpurun_out/ (copy the CSVs to profiles/).
 # Counter passes are separate runs with --pmc only (never combined with trace domains).
 R=$PWD
-P=${1:-r04}
+P=${1:-r05}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write /tmp/rp_mfma /tmp/rp_extra /tmp/rp_train
