@@ -90,6 +90,7 @@ _PROTOS = {
     "dmx_colstats": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "dmx_set_halo_conv": (c_int, [c_int]),
     "dmx_set_halo_ws": (c_int, [c_int]),
+    "dmx_set_exclusive_device": (c_int, [c_int]),
     "dmx_xf_chain_ok": (c_int, [c_int, c_int]),
     "dmx_xf_chain": (c_int, [POINTER(XfChainDesc), c_int, _P]),
     "dmx_set_xf_chain": (c_int, [c_int]),
@@ -297,6 +298,14 @@ def poll_device_error(l=None):
     call it after your own synchronize() to cover the launches in flight"""
     for lb in ([l] if l is not None else [x for x in (_lib, _lib_f16) if x is not None]):
         check(lb.dmx_device_error(), "device error poll", lb)
+
+
+def exclusive_device(l):
+    """current dmx_set_exclusive_device setting of library `l` (the setter returns the old value: read = set + restore)"""
+    old = l.dmx_set_exclusive_device(1)
+    if not old:
+        l.dmx_set_exclusive_device(0)
+    return int(old)
 
 
 def ptr(t):

@@ -34,6 +34,22 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+int n_cus() {                                          // of the CURRENT device (the K-split plans need a tile's blocks co-resident on it)
+  static int n_cu[64] = {};
+  int dev = 0; (void)hipGetDevice(&dev);
+  int& n = n_cu[dev & 63];
+  if (!n) { (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); if (n <= 0) n = 256; }
+  return n;
+}
+
+// dmx_set_exclusive_device(0): other streams / other kernels may hold CUs while a launch of the library runs (micro-batches on several streams,
+// a collective on a side stream).  The in-kernel K-split exchange needs the S blocks of a tile co-resident - symmetric peers wait for each
+// other - so without the device to itself the planner takes no split: shapes that need one fall back to GroupNorm + the implicit GEMM.
+// (The stream-K GEMMs are not affected: an owner only ever waits for blocks dispatched AFTER it, which start as soon as any block retires.)
+int g_exclusive_device = 1;
+extern "C" int dmx_set_exclusive_device(int on) { const int old = g_exclusive_device; g_exclusive_device = on ? 1 : 0; return old; }
+int dmx_exclusive_device() { return g_exclusive_device; }
+
 namespace {
 
 // x / d for x < 2^20, 2 <= d < 2^12 with magic = 2^32 / d + 1; d = 1: magic 0 (host: halo_magic)
@@ -1004,13 +1020,6 @@ __global__ __launch_bounds__(512) void dmx_colstats_kernel(const bf16* x, int ld
   }
 }
 
-int n_cus() {                                          // of the CURRENT device (the K-split plans need a tile's blocks co-resident on it)
-  static int n_cu[64] = {};
-  int dev = 0; (void)hipGetDevice(&dev);
-  int& n = n_cu[dev & 63];
-  if (!n) { (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); if (n <= 0) n = 256; }
-  return n;
-}
 
 // Plan: tile geometry, column width BN (160 / 128: 4 x 2 waves; 80 / 64: 8 x 1 waves) and K split.  A K split costs an exchange of fp32
 // slabs through memory ((S - 1) / S x 256 x BN x 4 bytes per block, written and read back) and the co-residency of a tile's blocks, so the
@@ -1034,7 +1043,7 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
     const long tiles = tiles_m * (a.N / bn);
     for (int s = 1; s <= 8; s *= 2) {
       if (a.force_split && s != a.force_split) continue;
-      if (s > 1 && (tiles * s > n_cus() || T / s < 3)) continue;
+      if (s > 1 && (!g_exclusive_device || tiles * s > n_cus() || T / s < 3)) continue;
       const double rounds = (double)((tiles * s + n_cus() - 1) / n_cus());
       const double step = bn >= 128 ? 1.45 : 0.96;                         // us per tap and block (measured, B = 4 64x64x320: K = 2880 / 5760 / 8640)
       double cost = rounds * ((double)((T + s - 1) / s) * step + 13.0);    // + prologue / epilogue of a block

@@ -1174,8 +1174,7 @@ static bool cfg_persistent(int c) { return c >= 12; }
 // number of blocks of a persistent launch: one per CU, fewer when the iteration space is small (>= 4 K-tiles per block),
 // a multiple of 8 so the XCD-contiguous remap applies
 static int persist_grid(const GemmArgs& a, int c) {
-  static int n_cu = 0;
-  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+  const int n_cu = n_cus();                            // of the current device (conv_halo.hip)
   const TileCfg& T = kCfg[c];
   const long tiles = (long)(a.ups2 ? 4 * cdiv(a.M4, T.bm) : cdiv(a.M, T.bm)) * cdiv(a.N, T.bn);
   const long total = tiles * (a.K / T.bk);

@@ -8,6 +8,8 @@
 enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN = 3, PROF_GNORM = 4, PROF_LNORM = 5,
                  PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_WGRAD = 8, PROF_GEMM256WS = 9,
                  PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_HALO = 27 /* conv_halo.hip */, PROF_NCLASS = 28 };
+int n_cus();                                           // compute units of the CURRENT device (conv_halo.hip)
+int dmx_exclusive_device();                            // dmx_set_exclusive_device (conv_halo.hip): 0 = plans that need co-resident blocks are off
 void dmx_profile_note_symbol(const char* sym);         // kernel symbol of the launch inside the innermost open ProfScope (exec.hip)
 struct ProfScope {
   ProfScope(ProfClass c, hipStream_t s, double flops, double bytes, const char* tag = nullptr);

@@ -412,7 +412,7 @@ class UNet2DConditionModel(_HipModel):
         ps = [(p, p.shape[1]) for p in parts] + [(None, 0)] * (3 - len(parts))
         if out is None:
             out = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=x0.device)
-        key = (B, H, W, sl["ctx_shape"][1])
+        key = (B, H, W, sl["ctx_shape"][1], _cabi.exclusive_device(lib))     # (the setting changes the plans, hence the workspace the walk needs)
         if sl["ws_need"] is None or sl["ws_need"][0] != key:
             sl["ws_need"] = (key, lib.dmx_unet_workspace_bytes(self._h, B, H, W, sl["ctx_shape"][1]))
         ws = self._slot_workspace(sl, sl["ws_need"][1])

@@ -95,6 +95,20 @@ def denoise(unet, scheduler, latents, mask, masked_image_latents, encoder_hidden
     temb_table = unet.temb_table(ts_dev) if (ts_host and TEMB_TABLE) else None
     ts_dev = (ts_dev, torch.arange(len(ts_host), dtype=torch.int32, device=dev))
     streams = _side_streams(dev, n)             # the loop runs on side streams: graph capture needs a non-default stream
+    # several chains at once share the CUs: plans whose blocks wait for co-resident peers are off while they are enqueued (the plans are
+    # chosen - and baked into the captured graphs, which are keyed on the setting - at enqueue time)
+    lib_ = unet._lib
+    old_exclusive = lib_.dmx_set_exclusive_device(0) if n > 1 else None
+    try:
+        return _denoise_enqueue(unet, scheduler, bounds, streams, main, n, latents, mask, masked_image_latents, encoder_hidden_states,
+                                ts_host, ts_dev, temb_table, is_ddim, vpred, eta, variance_noise, callback, use_graph)
+    finally:
+        if old_exclusive is not None:
+            lib_.dmx_set_exclusive_device(old_exclusive)
+
+
+def _denoise_enqueue(unet, scheduler, bounds, streams, main, n, latents, mask, masked_image_latents, encoder_hidden_states,
+                     ts_host, ts_dev, temb_table, is_ddim, vpred, eta, variance_noise, callback, use_graph):
     runs = []
     for j, (lo, hi) in enumerate(bounds):
         streams[j].wait_stream(main)

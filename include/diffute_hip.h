@@ -189,6 +189,10 @@ size_t dmx_conv3x3_gn_workspace_bytes(const dmx_halo_conv_desc* d);
 int dmx_conv3x3_gn(const dmx_halo_conv_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
 int dmx_colstats(const void* x, int ldx, int B, int HW, int C, long long* st, dmx_stream_t stream);
 int dmx_set_halo_conv(int on);      /* tuning aid: 0 makes the model executors use GroupNorm + dmx_conv_gemm everywhere; returns the old setting */
+int dmx_set_exclusive_device(int on); /* 1 (default): the library's launches have the GPU to themselves, one stream at a time.  0: other streams or other kernels (micro-batches on
+                                       * several streams, a collective on a side stream) may hold CUs while a launch runs: dmx_conv3x3_gn then takes no in-kernel K split (its peers
+                                       * must be co-resident; a starved launch raises DMX_ERR_DEVICE) and the executors use GroupNorm + dmx_conv_gemm where a split would be needed.
+                                       * Returns the old setting; captured UNet steps are keyed on it. */
 int dmx_set_halo_ws(int on);        /* tuning aid: 0 keeps dmx_conv3x3_gn's planner off the warp-specialised instances (4 compute + 4 loader waves); returns the old setting */
 
 /* The row-local chains of diffusers' BasicTransformerBlock + Transformer2DModel.proj_out (the unet(...) call at

@@ -95,3 +95,24 @@ def test_cfg3_vae_soak(cuda):
         with torch.no_grad():
             return vae.decode(vae.encode(img).latent_dist.mode()).sample
     check(soak(one, 3, hold=True, sync=False), "cfg3 VAE encode + decode B=32 512 px")
+
+
+def test_micro_batches_on_two_streams(cuda, full_unet):
+    """denoise(micro_batches=2): two chains on two streams share the CUs.  The in-kernel K-split exchange of the halo conv needs a tile's blocks
+    co-resident, so it is switched off for the duration (dmx_set_exclusive_device(0): GroupNorm + implicit GEMM where a split would be needed) -
+    before round 5 this combination starved the peers (40-ms spins, garbage results); now a starved launch would raise DMX_ERR_DEVICE.
+    Result: finite, deterministic, equal to the single-stream result up to the tile-plan rounding of the batch-2 GEMMs."""
+    import diffute_amd as D
+    from diffute_amd import _cabi
+    from diffute_amd.synthetic import synth_inputs
+    lat, mask, mlat, ctx = synth_inputs(4, 64, 64, 577, 1024, device=cuda)
+    ref = D.denoise(full_unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 10).clone()
+    outs = [D.denoise(full_unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 10, micro_batches=2).clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    _cabi.poll_device_error()
+    check(outs, "DDIM-10 B=4 as two micro-batches")
+    err = float((outs[0] - ref).norm() / ref.norm())
+    assert err < 2e-2, f"micro-batched result differs from the single-stream result by rel-L2 {err:.2e}"
+    assert _cabi.exclusive_device(_cabi.lib()) == 1, "the exclusive-device setting is restored"
+    again = D.denoise(full_unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 10)
+    assert torch.equal(again, ref), "the single-stream plans (and their captured graphs) are back"
