@@ -12,8 +12,9 @@ from diffute_amd import ops  # noqa: E402
 
 dev = torch.device("cuda")
 GEO = {1: (128, 64, 32), 2: (128, 128, 32), 8: (128, 64, 64), 9: (128, 128, 32), 10: (128, 128, 64), 11: (128, 160, 64)}
-TNS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 10, 11]
-for (M, N, K) in [(16384, 320, 320), (16384, 320, 1280), (16384, 960, 320), (4096, 640, 640)]:
+TNS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 and sys.argv[1][0].isdigit() else [8, 10, 11]
+SHAPES = [(4096, 640, 640), (1024, 1280, 1280), (256, 1280, 1280)] if '--low' in sys.argv else [(16384, 320, 320), (16384, 320, 1280), (16384, 960, 320), (4096, 640, 640)]
+for (M, N, K) in SHAPES:
     src = torch.randn(1, 1, M, K, device=dev).to(torch.bfloat16)
     x = torch.empty_like(src)
     w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
