@@ -1,4 +1,4 @@
-DIFFUTE_HIP_LIB=ab/lib_cur.so python3 scripts/attn_ab.py dump /tmp/attn_base.pt 2>/dev/null
-DIFFUTE_HIP_LIB=ab/lib_split.so python3 scripts/attn_ab.py cmp /tmp/attn_base.pt 2>/dev/null | head -3
-DIFFUTE_HIP_LIB=ab/lib_cur.so python3 scripts/attn_ab.py dump /tmp/attn_base.pt 2>/dev/null
-DIFFUTE_HIP_LIB=ab/lib_split.so python3 scripts/attn_ab.py cmp /tmp/attn_base.pt 2>/dev/null | head -1
+for i in 1 2 3; do
+python3 scripts/ab_libs.py ab/lib_gm8.so 2>&1 | tail -1
+python3 scripts/ab_libs.py - 2>&1 | tail -1
+done

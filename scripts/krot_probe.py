@@ -1,4 +1,4 @@
-"""K rotation of the GEMM walk (GemmArgs.krot: block t starts at K-tile (t krot) mod nkt and wraps): per-block timeline and in-graph time per
+"""NEEDS the krot patch of EXPERIMENTS.md round 5 item 3 (reverted in the tree: GemmArgs.krot, api.hip dbg >> 3).  K rotation of the GEMM walk (GemmArgs.krot: block t starts at K-tile (t krot) mod nkt and wraps): per-block timeline and in-graph time per
 launch for the K = C linears and a few other unsplit shapes of the pass, against krot = 0.  Measurement aid (dbg bits 3.. carry krot)."""
 import math, os, sys
 import torch
