@@ -521,6 +521,11 @@ class UNet2DConditionModel(_HipModel):
             raise ValueError(f"set_gradient_sync: unknown mode {mode!r}")
         self._sync = None if dist is None else dict(dist=dist, group=group, world=dist.get_world_size(group), stream=None, mode=mode,
                                                     exposed=None)
+        # the exchange runs collective kernels on a side stream while the library's launches run: those hold CUs, so plans whose blocks need
+        # co-resident peers (the in-kernel K split of dmx_conv3x3_gn, e.g. in the VAE encodes of the training step) are off for this process
+        shared = self._sync is not None and self._sync["world"] > 1
+        for lb in {id(x): x for x in (self._lib, _cabi.lib())}.values():
+            lb.dmx_set_exclusive_device(0 if shared else 1)
 
     def exposed_exchange_ms(self):
         """how long the last backward's main stream sat waiting for the gradient exchange after its own kernels were done
