@@ -909,3 +909,36 @@ def test_tiny_vae_fp32_validation_path(cuda, tiny_vae):
     e1 = assert_close(tiny_vae.encode_fp32(img), torch.from_numpy(g["moments_fp32"]), 1e-3, "tiny vae fp32 path, moments")
     e2 = assert_close(tiny_vae.decode_fp32(z), torch.from_numpy(g["image_fp32"]), 1e-3, "tiny vae fp32 path, image")
     print(f"tiny vae fp32 validation path rel-L2: moments {e1:.2e}, image {e2:.2e}")
+
+
+def test_profile_by_kernel_symbol(cuda):
+    """bench.py's roofline leg: dmx_profile_symbols lists the bracketed launches by kernel SYMBOL (the launch helpers note the template instance they
+    launch, in rocprofv3's spelling); the symbols of a class sum to the class total of dmx_profile_end."""
+    import ctypes
+    import diffute_amd as D
+    from diffute_amd import _cabi
+    from diffute_amd.synthetic import synth_inputs
+    lib = _cabi.lib()
+    unet = D.UNet2DConditionModel(**TINY_UNET).cuda().requires_grad_(False)
+    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, 128, device=cuda)
+    D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 2)
+    torch.cuda.synchronize()
+    lib.dmx_profile_begin()
+    D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 2)
+    buf = (ctypes.c_double * (4 * 28))()
+    _cabi.check(lib.dmx_profile_end(buf, len(buf)), "profile_end")
+    sbuf = ctypes.create_string_buffer(1 << 16)
+    nb = lib.dmx_profile_symbols(sbuf, len(sbuf))
+    assert nb > 0
+    rows = [l.split("\t", 5) for l in sbuf.raw[:nb].decode().splitlines()]
+    assert rows and all(len(r) == 6 for r in rows)
+    syms = [r[5] for r in rows]
+    assert any(s.startswith("void dmx_gemm_kernel<") and s.endswith("(GemmArgs)") for s in syms), syms
+    assert any("dmx_attn_d64_kernel" in s for s in syms), syms
+    by_class = {}
+    for c, n, ms, fl, by, _ in rows:
+        e = by_class.setdefault(int(c), [0.0, 0.0]); e[0] += float(n); e[1] += float(ms)
+    for c, (n, ms) in by_class.items():
+        if c in (3,) or c >= 10:                          # attention and the GEMM / chain / halo classes: every launch of the class notes its symbol
+            assert n == buf[4 * c] and abs(ms - buf[4 * c + 1]) <= 1e-3 * max(1.0, buf[4 * c + 1]), (c, n, ms, buf[4 * c], buf[4 * c + 1])
+    assert lib.dmx_profile_symbols(sbuf, 8) == 0           # buffer too small: nothing written, 0 returned
