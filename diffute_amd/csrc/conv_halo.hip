@@ -1078,9 +1078,16 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
 // 119 vs 129 us; 32x32 level 63 vs 66, 89 vs 98, 124 vs 125; 16x16 level 64 vs 61, 85 vs 77, 48 vs 44 - the blocks of the deep levels
 // are 8-way K splits whose fp32 slab exchange costs what the fusion saves.
 extern "C" int dmx_set_halo_ws(int on) { const int old = g_halo_ws; g_halo_ws = on; return old; }
+// ONE place for "could a fused GroupNorm -> conv launch consume statistics records of an H x W tensor": the tile geometries of halo_plan and the
+// level rule of dmx_conv_halo_pays.  The executors ask this before they spend a statistics pass / a statistics epilogue on a tensor
+// (Exec::ensure_stats, Exec::chain_stats); `everywhere` = dmx_set_halo_conv(2): wherever the kernel takes the problem.
+bool dmx_conv_halo_wants_stats(int H, int W, bool everywhere) {
+  const bool geometry = (W % 32 == 0 && H % 8 == 0) || (W % 16 == 0 && H % 16 == 0);
+  return geometry && (everywhere || (long)H * W >= 1024);
+}
 bool dmx_conv_halo_pays(const HaloConvArgs& a) {
   if (!dmx_conv_halo_supported(a)) return false;
-  return (long)a.H * a.W >= 1024;
+  return dmx_conv_halo_wants_stats(a.H, a.W, false);
 }
 
 static long halo_blocks(const HaloConvArgs& a, const HaloPlan& P);

@@ -394,7 +394,7 @@ bool dmx_halo_conv_enabled();
 void Exec::ensure_stats(Tn& t) {
   if (rc || f32 || t.cst || !dmx_halo_conv_enabled() || !g_gn_producer_stats || (t.C & 7) || (t.ld & 7)) return;
   // only where a fused GroupNorm -> conv launch can consume them (the tile geometries of conv_halo.hip, levels where it pays)
-  if (!((t.W % 32 == 0 && t.H % 8 == 0) || (t.W % 16 == 0 && t.H % 16 == 0)) || (g_halo_conv == 1 && (long)t.H * t.W < 1024)) return;
+  if (!dmx_conv_halo_wants_stats(t.H, t.W, g_halo_conv != 1)) return;
   long long* st = stat_slice(t.B, t.C);
   if (!st) return;
   if (!dry && !rc) rc = dmx_colstats_launch(t.p, t.ld, t.B, t.H * t.W, t.C, st, stream);
@@ -532,7 +532,7 @@ bool Exec::chain_ok(const Tn& x) const { return (g_xf_chain & 3) && !f32 && x.ld
 bool Exec::chain_gn_fold(const Tn& x) const { return !(g_xf_chain & 4) && !f32 && x.cst != nullptr && (x.H * x.W) % 64 == 0 && x.ld == x.C; }
 void Exec::chain_stats(XfChainArgs& a, Tn& y) {
   if (rc || f32 || !dmx_halo_conv_enabled() || !g_gn_producer_stats || (y.H * y.W) % 64) return;
-  if (!((y.W % 32 == 0 && y.H % 8 == 0) || (y.W % 16 == 0 && y.H % 16 == 0)) || (g_halo_conv == 1 && (long)y.H * y.W < 1024)) return;
+  if (!dmx_conv_halo_wants_stats(y.H, y.W, g_halo_conv != 1)) return;
   a.colstats = stat_slice(y.B, y.C);
   if (!a.colstats) return;
   a.cs_rows = y.H * y.W; y.cst = a.colstats;

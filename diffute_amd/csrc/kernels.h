@@ -113,6 +113,7 @@ struct HaloConvArgs {
 bool dmx_conv_halo_supported(const HaloConvArgs& a);
 bool dmx_conv_halo_pays(const HaloConvArgs& a);        // supported AND at least as fast in situ as GroupNorm + implicit-GEMM conv (what the executors ask)
 size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a);
+bool dmx_conv_halo_wants_stats(int H, int W, bool everywhere);   // geometry + level rule shared by the planner and the executors
 int dmx_conv_halo_flag_count(const HaloConvArgs& a);   // ints of zeroed flags the launch needs (0: none)
 int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // statistics of a tensor nobody emitted them for: one streaming pass, DmxStat records [B][C][4] (zero before the launch)
