@@ -225,6 +225,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed, value = DD.whole_job_throughput(dist, elapsed, B * args.steps, dev)     # max time, total images / it
+    if dist is not None:                        # a bad pass on ANY rank is the job's error: rank 0 reports the element-wise maximum over the ranks
+        dist.all_reduce(health, op=dist.ReduceOp.MAX)
     hh = health.cpu()
     bad = [i for i in range(n_pass) if int(hh[i, 0]) or int(hh[i, 1])]
     if bad:
