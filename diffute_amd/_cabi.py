@@ -90,6 +90,7 @@ _PROTOS = {
     "dmx_colstats": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "dmx_set_halo_conv": (c_int, [c_int]),
     "dmx_set_halo_ws": (c_int, [c_int]),
+    "dmx_set_defer_reduce": (c_int, [c_int]),
     "dmx_set_exclusive_device": (c_int, [c_int]),
     "dmx_xf_chain_ok": (c_int, [c_int, c_int]),
     "dmx_xf_chain": (c_int, [POINTER(XfChainDesc), c_int, _P]),

@@ -82,8 +82,13 @@ struct Tn {                 // NHWC bf16 activation [B*H*W][C] with row stride l
   // GroupNorm statistics of this tensor, written by the epilogue of the GEMM that produced it (GemmArgs.colstats / HaloConvArgs.colstats): [B][C][4]
   // DmxStat records (common.h); null when the producer could not emit them (split-K plans, fp32 mode, ...)
   const long long* cst = nullptr;
+  // >= 0: the tensor is the output of a split-K GEMM whose reduce pass is still pending (Exec::pend_[pend]): its memory is written by the GroupNorm that
+  // reads it first (fused: norm.hip GroupNormArgs.red_*) or by Exec::flush
+  int pend = -1;
   int rows() const { return B * H * W; }
 };
+// a split-K GEMM launched without its reduce pass (ConvOpts.defer): what the reduce needs, and the partial planes in the workspace
+struct PendRed { GemmArgs a; void* wsp = nullptr; bool done = false; };
 
 // Debug taps: block outputs of a forward pass copied out as NCHW fp32 (tests compare them with the oracle's per-block tensors)
 struct TapSink {
@@ -102,6 +107,8 @@ struct ConvOpts {
   const Tn* sc0 = nullptr; const Tn* sc1 = nullptr;   // fused 1x1 shortcut sources
   int out_f32 = 0;
   int stats = 0;            // 1: emit the GroupNorm statistics of the output when the plan allows it (its next consumer is a GroupNorm)
+  int defer = 0;            // 1: the caller promises that the output's FIRST consumer is Exec::groupnorm / conv_gn (as x0): a split-K plan then leaves its
+                            // reduce pass to that GroupNorm (one launch and one round trip of the tensor less); any other consumer must Exec::flush first
 };
 
 class Exec {
@@ -136,6 +143,8 @@ class Exec {
   // Statistics slices (Tn::cst) come from a pool zeroed once per forward as well (the producers ADD into them).
   long long* cs_pool = nullptr; size_t cs_cap = 0, cs_used = 0;
   bool zero_pool(void* p, size_t bytes, int which);
+  std::vector<PendRed> pend_;
+  void flush(const Tn& t);         // run the pending reduce pass of t (no-op when there is none)
   void want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B);
   long long* stat_slice(int B, int C);
   // statistics records of a tensor whose producer emitted none (one streaming pass, conv_halo.hip dmx_colstats_launch); no-op when
@@ -145,7 +154,13 @@ class Exec {
   // kernel takes the problem and both sources carry statistics records; otherwise GroupNorm + conv as two ops
   Tn conv_gn(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, const bf16* w, int Cout, const ConvOpts& o);
   void drop(const void* p) { ws.release(p); }
-  void drop(const Tn& t) { drop((const void*)t.p); }
+  void drop(const Tn& t) {
+    if (t.pend >= 0 && t.pend < (int)pend_.size() && !pend_[t.pend].done) {      // dropped before anybody read it: the partial planes go, no reduce pass needed
+      if (pend_[t.pend].wsp) ws.release(pend_[t.pend].wsp);
+      pend_[t.pend].wsp = nullptr; pend_[t.pend].done = true;
+    }
+    drop((const void*)t.p);
+  }
 
   // y = GroupNorm(x0|x1) [SiLU]
   Tn groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, bool silu);
@@ -181,7 +196,7 @@ class Exec {
   void attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* v, int ldv, int kv_rows,
                  bf16* o, int ldo, int B, int H, int Sq, int Skv, float scale, bool kv_static = false);
  private:
-  void run_gemm(GemmArgs& a);
+  void run_gemm(GemmArgs& a, Tn* defer_to = nullptr);
 };
 
 // ResnetBlock2D weights (offsets into the arena) shared by the UNet and VAE graphs

@@ -179,6 +179,10 @@ void Workspace::release(const void* p) {
 static int g_gn_producer_stats = 1;
 extern "C" int dmx_set_gn_producer_stats(int on) { const int old = g_gn_producer_stats; g_gn_producer_stats = on; return old; }
 
+// tuning aid (A/B inside one process): 0 = split-K convolutions always run their own reduce pass (ConvOpts.defer ignored)
+static int g_defer_reduce = 1;
+extern "C" int dmx_set_defer_reduce(int on) { const int old = g_defer_reduce; g_defer_reduce = on; return old; }
+
 static int g_halo_conv = 1;
 extern "C" int dmx_set_halo_conv(int on) { const int old = g_halo_conv; g_halo_conv = on; return old; }
 bool dmx_halo_conv_enabled() { return g_halo_conv != 0; }
@@ -272,7 +276,14 @@ void Exec::peek(const void** p, int* n, int slots) {
     p[i] = plan->w[k].first; n[i] = (int)nb; left -= nb; ++i;
   }
 }
-void Exec::run_gemm(GemmArgs& a) {
+void Exec::flush(const Tn& t) {
+  if (t.pend < 0 || t.pend >= (int)pend_.size() || pend_[t.pend].done) return;
+  PendRed& P = pend_[t.pend];
+  if (!dry && !rc) rc = dmx_splitk_reduce_launch(P.a, stream);
+  if (P.wsp) ws.release(P.wsp);
+  P.wsp = nullptr; P.done = true;
+}
+void Exec::run_gemm(GemmArgs& a, Tn* defer_to) {
   if (rc) return;
   note(a.w, (long)a.N * a.ldw * 2 * (a.ups2 ? 4 : 1));
   peek(a.pf, a.pf_bytes, 2);
@@ -287,8 +298,16 @@ void Exec::run_gemm(GemmArgs& a) {
   }
   const size_t wsb = dmx_gemm_workspace_bytes(a);
   void* w = wsb ? raw(wsb) : nullptr;
+  int c = 0, sk = 1, ktps = 0;
+  if (defer_to) dmx_gemm_plan(a, &c, &sk, &ktps);
+  const bool defer = defer_to && sk > 1 && !dmx_gemm_persist_blocks(a) && !a.out_f32 && wsb > 0;      // (no pointer values in this decision: the dry walk has none)
+  if (defer) a.defer_reduce = 1;
   if (!dry && !rc) rc = dmx_gemm_launch(a, w, wsb, stream);
-  if (w) ws.release(w);
+  if (defer) {                                         // the partial planes stay in the workspace until the GroupNorm (or a flush) has read them
+    PendRed P; P.a = a; P.a.partial = (float*)w; P.a.splitk = sk; P.a.kt_per_split = ktps; P.wsp = w;
+    defer_to->pend = (int)pend_.size();
+    pend_.push_back(P);
+  } else if (w) ws.release(w);
 }
 
 Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* beta, int groups, float eps, bool silu) {
@@ -301,6 +320,7 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
     return y;
   }
   if (x0.cst && (!x1 || x1->cst)) {                    // statistics came with the tensor(s): one apply-only launch
+    flush(x0);
     if (!dry && !rc) {
       GroupNormArgs a{};
       a.x0 = x0.p; a.ldx0 = x0.ld; a.c0 = x0.C;
@@ -316,19 +336,33 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
   }
   const size_t pb = dmx_gn_workspace_bytes(x0.B, x0.H * x0.W, groups);
   void* part = raw(pb);
+  // x0 may be the output of a split-K GEMM whose reduce pass was left to this GroupNorm (ConvOpts.defer): the slab kernel sums the partial planes in
+  // its load stage where it takes the shape, otherwise the reduce pass runs now
+  PendRed* P = (x0.pend >= 0 && x0.pend < (int)pend_.size() && !pend_[x0.pend].done) ? &pend_[x0.pend] : nullptr;
+  GroupNormArgs a{};
+  a.x0 = x0.p; a.ldx0 = x0.ld; a.c0 = x0.C;
+  a.x1 = x1 ? x1->p : nullptr; a.ldx1 = x1 ? x1->ld : 0;
+  a.C = C; a.groups = groups; a.B = x0.B; a.HW = x0.H * x0.W;
+  a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu ? 1 : 0;
+  a.y = y.p; a.ldy = y.ld; a.partial = (float*)part;
+  if (P) {
+    a.red_partial = P->a.partial ? P->a.partial : (const float*)8;      // (dry walk: no addresses - any non-null value asks the same question)
+    a.red_splitk = P->a.splitk; a.red_mn = (long long)P->a.M * P->a.N;
+    a.red_bias = P->a.bias; a.red_rowbias = P->a.rowbias; a.red_ldrb = P->a.ldrb; a.red_rpg = P->a.rows_per_group;
+    a.red_res = P->a.res; a.red_ldres = P->a.ldres;
+    if (P->a.N != x0.C || P->a.ldo != x0.ld || !dmx_gn_red_ok(a)) {
+      flush(x0); P = nullptr;
+      a.red_partial = nullptr; a.red_splitk = 0;
+    }
+  }
   if (!dry && !rc) {
-    GroupNormArgs a{};
-    a.x0 = x0.p; a.ldx0 = x0.ld; a.c0 = x0.C;
-    a.x1 = x1 ? x1->p : nullptr; a.ldx1 = x1 ? x1->ld : 0;
-    a.C = C; a.groups = groups; a.B = x0.B; a.HW = x0.H * x0.W;
-    a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu ? 1 : 0;
-    a.y = y.p; a.ldy = y.ld; a.partial = (float*)part;
     const bool one = dmx_gn_single_launch(a);
-    char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d%s", x0.rows(), C, one ? " slab" : "");
+    char tag[96]; snprintf(tag, sizeof(tag), "rows=%d C=%d%s%s", x0.rows(), C, one ? " slab" : "", P ? " + split-K reduce" : "");
     // bf16: read x + write y when the slab stays in registers, otherwise x is read twice (stats, apply)
     ProfScope ps(PROF_GNORM, stream, 0.0, (one ? 4.0 : 6.0) * (double)x0.rows() * C, tag);
     if (!rc) rc = dmx_groupnorm_launch(a, stream);
   }
+  if (P) { if (P->wsp) ws.release(P->wsp); P->wsp = nullptr; P->done = true; }
   ws.release(part);
   return y;
 }
@@ -386,7 +420,7 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   if (o.res) { a.res = o.res->p; a.ldres = o.res->ld; }
   a.out = o.out_f32 ? f32_out : (void*)y.p; a.ldo = Cout; a.out_f32 = o.out_f32;
   if (o.stats && !o.out_f32) want_stats(a, y, (o.ups && o.ups2) ? x0.H * x0.W : OH * OW, x0.B);
-  run_gemm(a);
+  run_gemm(a, (o.defer && g_defer_reduce && !o.out_f32 && !a.ups2) ? &y : nullptr);
   return y;
 }
 
@@ -395,6 +429,7 @@ void Exec::ensure_stats(Tn& t) {
   if (rc || f32 || t.cst || !dmx_halo_conv_enabled() || !g_gn_producer_stats || (t.C & 7) || (t.ld & 7)) return;
   // only where a fused GroupNorm -> conv launch can consume them (the tile geometries of conv_halo.hip, levels where it pays)
   if (!dmx_conv_halo_wants_stats(t.H, t.W, g_halo_conv != 1)) return;
+  flush(t);
   long long* st = stat_slice(t.B, t.C);
   if (!st) return;
   if (!dry && !rc) rc = dmx_colstats_launch(t.p, t.ld, t.B, t.H * t.W, t.C, st, stream);
@@ -425,6 +460,7 @@ Tn Exec::conv_gn(const Tn& x0, const Tn* x1, const float* gamma, const float* be
     drop(t);
     return y;
   }
+  flush(x0);
   Tn y = make(x0.B, x0.H, x0.W, Cout);
   a.out = y.p;
   if (o.stats && g_gn_producer_stats) { a.colstats = stat_slice(x0.B, Cout); y.cst = a.colstats; }
@@ -630,6 +666,7 @@ Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn
   auto H = [&](size_t off) { return (const bf16*)(arena + off * (size_t)wmul); };
   // [GroupNorm -> SiLU -> conv3x3] twice; each pair is ONE launch where the halo conv takes it (Exec::conv_gn)
   ConvOpts o1; o1.bias = F(r.b1); o1.stats = 1;        // norm2 reads conv1's output
+  o1.defer = 1;                                        // ... FIRST (and only): a split-K conv1 leaves its reduce pass to norm2
   if (r.temb_off >= 0 && tproj) { o1.rowbias = tproj + r.temb_off; o1.ldrb = tproj_total; }
   Tn t2 = ex.conv_gn(x0, x1, F(r.n1g), F(r.n1b), groups, eps, H(r.w1), r.cout, o1);
   ConvOpts o2; o2.bias = F(r.b2); o2.stats = 1;        // a GroupNorm comes next in every graph (next resnet / transformer / out norm)

@@ -1415,7 +1415,7 @@ int dmx_gemm_launch(GemmArgs a, void* workspace, size_t workspace_bytes, hipStre
   }
   rc = dmx_check_launch("dmx_gemm_kernel");
   if (rc) return rc;
-  if (sk > 1) rc = dmx_splitk_reduce_launch(a, stream);
+  if (sk > 1 && !a.defer_reduce) rc = dmx_splitk_reduce_launch(a, stream);
   return rc;
 }
 

@@ -59,6 +59,7 @@ struct GemmArgs {
   float* partial; int splitk, kt_per_split;   // filled by the launcher
   // persistent stream-K launch (filled by the launcher): grid = one block per CU walking (tile, K-range) items; `partial` holds
   // one accumulator slab per block, `flags` one int per block, all zero at launch (see the kernel's work-item loop)
+  int defer_reduce;        // split-K plans: 1 = the launcher skips the reduce pass (Exec defers it into the GroupNorm that reads the output: exec.hip PendRed)
   int persist; int* flags; int* err;      // err: dmx_dev_err_words() (set by the launcher)
   // GroupNorm statistics of the output for its consumer (norm.hip dmx_groupnorm_sums_launch, conv_halo.hip): per (sample, channel) a
   // DmxStat record (common.h; 4 x int64 fixed point) of the rounded outputs, ADDED into colstats[(sample*N + n)*4 ..] (zero before the launch);
@@ -151,7 +152,12 @@ struct GroupNormArgs {
   // tensor][4] DmxStat records (common.h); dmx_groupnorm_sums_launch only
   const long long* st0; const long long* st1;
   int nchunk, rows_per_chunk;
+  // x0 = the NOT YET WRITTEN output of a split-K GEMM (slab path only): the slab load sums the partial planes in split order, adds bias / row bias /
+  // residual exactly like dmx_splitk_reduce_kernel, writes x0 (its other consumers read it later) and keeps the rounded values for the statistics
+  const float* red_partial; int red_splitk; long long red_mn; const float* red_bias; const float* red_rowbias; int red_ldrb, red_rpg;
+  const bf16* red_res; int red_ldres;
 };
+bool dmx_gn_red_ok(GroupNormArgs a);          // the slab path can take this shape WITH the fused split-K reduce
 size_t dmx_gn_workspace_bytes(int B, int HW, int groups);
 int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream);
 int dmx_groupnorm_sums_launch(GroupNormArgs a, hipStream_t stream);   // statistics from the producers (a.st0 / a.st1): one apply-only launch

@@ -202,7 +202,7 @@ __device__ __forceinline__ float gn_block_sum(float v, float* red, int t, int nw
   return a;
 }
 
-template <int VEC, int NU, bool SILU>
+template <int VEC, int NU, bool SILU, bool RED = false>
 __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p, int SU, int R, int dbg) {
   typedef typename GnVec<VEC>::T V;
   typedef __attribute__((address_space(1))) V GV;   // the opaque running pointers lose their address space: say global again
@@ -229,6 +229,70 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
   const char* const safe = (const char*)src;
   const char* lp = (const char*)(src + (size_t)r * ld);
   const size_t lstep = (size_t)R * ld * 2;
+  bool red_done = false;
+  if constexpr (RED) {
+    // x0 is the output of a split-K GEMM whose reduce pass was deferred to this kernel (GroupNormArgs.red_*): this thread's units of x0 are
+    // SUMMED here - plane 0, + plane 1, ... in split order, + bias + row bias, + residual: the arithmetic of dmx_splitk_reduce_kernel, bit for
+    // bit -, rounded, written to x0 and kept.  A group lies in x0 or in x1 as a whole (launcher), so the branch is block-uniform.
+    if (p.red_partial && c < p.c0) {
+      red_done = true;
+      constexpr int NE = 2 * VEC;                      // channels of a unit
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        const int pr = r + k * R;
+        const bool ok = active && pr < p.HW;
+        V o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gn_set<VEC>(o, i, 0u);
+        if (ok) {
+          const size_t m = (size_t)b * p.HW + pr;
+          const float* q = p.red_partial + m * (size_t)p.c0 + c;
+          // epilogue operands first (their latency overlaps the partial loads), then the planes FOUR at a time - all loads of a batch in flight
+          // before the first add - summed in split order: the pass is latency-bound
+          float bvv[NE], rbv[NE]; unsigned int rw[VEC];
+#pragma unroll
+          for (int e = 0; e < NE; e += 2) {
+            const f32x2 t2 = p.red_bias ? *(const f32x2*)(p.red_bias + c + e) : (f32x2){0.f, 0.f};
+            const f32x2 t3 = p.red_rowbias ? *(const f32x2*)(p.red_rowbias + (size_t)(m / p.red_rpg) * p.red_ldrb + c + e) : (f32x2){0.f, 0.f};
+            bvv[e] = t2.x; bvv[e + 1] = t2.y; rbv[e] = t3.x; rbv[e + 1] = t3.y;
+          }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) rw[i] = p.red_res ? *(const unsigned int*)(p.red_res + m * (size_t)p.red_ldres + c + 2 * i) : 0u;
+          float a[NE];
+#pragma unroll
+          for (int e = 0; e < NE; e += 2) { const f32x2 t2 = *(const f32x2*)(q + e); a[e] = t2.x; a[e + 1] = t2.y; }
+          int j = 1;
+          for (; j + 3 < p.red_splitk; j += 4) {
+            f32x2 tt[4][NE / 2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int e = 0; e < NE / 2; ++e) tt[u][e] = *(const f32x2*)(q + (size_t)(j + u) * (size_t)p.red_mn + 2 * e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int e = 0; e < NE / 2; ++e) { a[2 * e] += tt[u][e].x; a[2 * e + 1] += tt[u][e].y; }
+          }
+          for (; j < p.red_splitk; ++j) {
+            const float* qj = q + (size_t)j * (size_t)p.red_mn;
+#pragma unroll
+            for (int e = 0; e < NE; e += 2) { const f32x2 t2 = *(const f32x2*)(qj + e); a[e] += t2.x; a[e + 1] += t2.y; }
+          }
+#pragma unroll
+          for (int e = 0; e < NE; ++e) a[e] = a[e] + bvv[e] + rbv[e];
+          if (p.red_res) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { a[2 * i] += h2f_lo(rw[i]); a[2 * i + 1] += h2f_hi(rw[i]); }
+          }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) gn_set<VEC>(o, i, pack_bf2(a[2 * i], a[2 * i + 1]));
+          *(GV*)(p.x0 + m * (size_t)p.ldx0 + c) = o;
+        }
+        v[k] = o;
+      }
+    }
+  }
+  if (!red_done) {
 #pragma unroll
   for (int k = 0; k < NU; ++k) {
     const bool ok = active && (r + k * R < p.HW);
@@ -236,6 +300,7 @@ __global__ __launch_bounds__(1024) void dmx_gn_slab_kernel(const GroupNormArgs p
     v[k] = *(const GV*)((ok && !(dbg & 2)) ? lp : safe);
     lp += lstep;
     __builtin_amdgcn_sched_barrier(0);               // issue each load before forming the next address
+  }
   }
 #pragma unroll
   for (int k = 0; k < NU; ++k) {
@@ -327,8 +392,17 @@ static bool gn_slab_launch(const GroupNormArgs& a, hipStream_t stream, bool dry 
 #else
   constexpr int dbg = 0;
 #endif
+  // (the fused split-K reduce, GroupNormArgs.red_partial: instances of up to four units, where the deep levels' slabs live)
 #define GN_SLAB(V_, N_)                                                                                      \
   if (vec == V_ && nu <= N_) {                                                                              \
+    if (a.red_partial) {                                                                                    \
+      if constexpr (N_ <= 4 && V_ >= 2) {                                                                   \
+        if (dry) return true;                                                                               \
+        if (a.silu) hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, true, true>), grid, block, 0, stream, a, SU, R, dbg);   \
+        else hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, false, true>), grid, block, 0, stream, a, SU, R, dbg);         \
+        return true;                                                                                        \
+      } else return false;                                                                                  \
+    }                                                                                                       \
     if (dry) return true;                                                                                   \
     if (a.silu) hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, true>), grid, block, 0, stream, a, SU, R, dbg);    \
     else hipLaunchKernelGGL((dmx_gn_slab_kernel<V_, N_, false>), grid, block, 0, stream, a, SU, R, dbg);          \
@@ -356,6 +430,16 @@ static bool gn_two_pass_forced() {
 bool dmx_gn_single_launch(GroupNormArgs a) {
   if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; }
   return !gn_two_pass_forced() && a.C % a.groups == 0 && gn_slab_launch(a, nullptr, true);
+}
+
+// the slab path takes this shape with the split-K reduce of x0 fused in: a slab instance of <= 4 units with >= 4-channel units exists, every group
+// lies in ONE source, x0 is dense over its c0 channels (the partial planes are [M][c0])
+bool dmx_gn_red_ok(GroupNormArgs a) {
+  if (!a.red_partial || a.red_splitk < 2 || a.C % a.groups) return false;
+  if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; }
+  const int cpg = a.C / a.groups;
+  if (a.c0 % cpg || a.c0 % 8 || a.red_rpg <= 0) return false;
+  return !gn_two_pass_forced() && gn_slab_launch(a, nullptr, true);
 }
 
 #define GN_MAX_CHUNKS 256
@@ -389,6 +473,7 @@ int dmx_groupnorm_launch(GroupNormArgs a, hipStream_t stream) {
   if (a.c0 >= a.C || a.x1 == nullptr) { a.c0 = a.C; a.x1 = a.x0; a.ldx1 = a.ldx0; }
   a.st0 = a.st1 = nullptr;
   if (!gn_two_pass_forced() && gn_slab_launch(a, stream)) return dmx_check_launch("dmx_gn_slab_kernel");
+  DMX_REQUIRE(a.red_partial == nullptr, "groupnorm: the fused split-K reduce needs the slab path (ask dmx_gn_red_ok first)");
   // ---- two-launch path (slabs that do not fit the register budget, e.g. 1024-px images)
   // thread = (row lane r < R, channel octet); wide blocks so each thread walks only a few rows
   const int oc = a.C / 8;

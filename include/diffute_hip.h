@@ -193,6 +193,8 @@ int dmx_set_exclusive_device(int on); /* 1 (default): the library's launches hav
                                        * several streams, a collective on a side stream) may hold CUs while a launch runs: dmx_conv3x3_gn then takes no in-kernel K split (its peers
                                        * must be co-resident; a starved launch raises DMX_ERR_DEVICE) and the executors use GroupNorm + dmx_conv_gemm where a split would be needed.
                                        * Returns the old setting; captured UNet steps are keyed on it. */
+int dmx_set_defer_reduce(int on);   /* tuning aid: 0 = a split-K convolution whose output is read first by a GroupNorm runs its own reduce pass (default 1: the GroupNorm's slab
+                                     * kernel sums the partial planes in its load stage - bit-identical, one launch less); returns the old setting */
 int dmx_set_halo_ws(int on);        /* tuning aid: 0 keeps dmx_conv3x3_gn's planner off the warp-specialised instances (4 compute + 4 loader waves); returns the old setting */
 
 /* The row-local chains of diffusers' BasicTransformerBlock + Transformer2DModel.proj_out (the unet(...) call at

@@ -1,5 +1,5 @@
 """A/B of a library switch inside ONE process and on one box: alternating timed 50-step passes with the switch on / off.
-    python scripts/ab_pass.py gn_stats|xf_chain|xf_gn_fold|halo_ws|weight_prefetch|temb_table|halo|halo_all [--rounds 4] [--batch 4]"""
+    python scripts/ab_pass.py gn_stats|xf_chain|xf_gn_fold|halo_ws|weight_prefetch|temb_table|halo|halo_all|defer_reduce [--rounds 4] [--batch 4]"""
 import sys
 import time
 
@@ -37,6 +37,8 @@ def setting(on):
         lib.dmx_set_weight_prefetch(1 if on else 0)     # every launch touches the weights of the launches that follow it (Exec::note / peek)
     elif what == "halo_ws":
         lib.dmx_set_halo_ws(1 if on else 0)           # the warp-specialised halo instances vs the two-group ping-pong
+    elif what == "defer_reduce":
+        lib.dmx_set_defer_reduce(1 if on else 0)      # split-K conv1 of a resnet leaves its reduce pass to norm2's slab kernel
     elif what == "xf_gn_fold":
         lib.dmx_set_xf_chain(1 if on else 5)          # bit 2: chains without the folded entry GroupNorm
     elif what == "xf_chain":

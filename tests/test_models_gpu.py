@@ -942,3 +942,35 @@ def test_profile_by_kernel_symbol(cuda):
         if c in (3,) or c >= 10:                          # attention and the GEMM / chain / halo classes: every launch of the class notes its symbol
             assert n == buf[4 * c] and abs(ms - buf[4 * c + 1]) <= 1e-3 * max(1.0, buf[4 * c + 1]), (c, n, ms, buf[4 * c], buf[4 * c + 1])
     assert lib.dmx_profile_symbols(sbuf, 8) == 0           # buffer too small: nothing written, 0 returned
+
+
+def test_deferred_splitk_reduce_is_bit_identical(cuda):
+    """ConvOpts.defer (exec.hip): at the 16x16 / 8x8 levels conv1 of a resnet is a split-K GEMM; its reduce pass is left to norm2, whose slab kernel sums
+    the partial planes in its load stage (norm.hip GroupNormArgs.red_*) with the arithmetic of dmx_splitk_reduce_kernel - the same bits, one launch
+    less.  Full-size UNet, batch 4 and batch 1, and the tiny config, with the switch on and off."""
+    import diffute_amd as D
+    from diffute_amd import _cabi
+    from diffute_amd.synthetic import synth_inputs
+    lib = _cabi.lib()
+
+    def fwd(unet, parts, t):
+        for sl in unet._slots.values():
+            sl["ws_need"] = None
+        _cabi.check(lib.dmx_unet_refresh_derived(unet._h, None), "refresh")      # drops the captured graphs
+        return unet.forward_parts(parts, t).clone()
+    full = D.UNet2DConditionModel(device=cuda).requires_grad_(False)
+    tiny = D.UNet2DConditionModel(**TINY_UNET).cuda().requires_grad_(False)
+    t = torch.tensor([501], device=cuda)
+    try:
+        for unet, shp in ((full, (4, 64, 64, 577, 1024)), (full, (1, 64, 64, 577, 1024)), (tiny, (2, 16, 16, 77, 128)), (tiny, (3, 8, 24, 40, 128))):
+            lat, mask, mlat, ctx = synth_inputs(*shp, device=cuda)
+            unet.set_context(ctx)
+            outs = {}
+            for on in (1, 0, 1):
+                lib.dmx_set_defer_reduce(on)
+                outs.setdefault(on, []).append(fwd(unet, [lat, mask, mlat], t))
+            torch.cuda.synchronize()
+            assert torch.isfinite(outs[1][0]).all()
+            assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][0], outs[1][1]), f"deferred reduce changes the result at {shp}"
+    finally:
+        lib.dmx_set_defer_reduce(1)
