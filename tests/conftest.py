@@ -35,6 +35,15 @@ def pytest_sessionstart(session):
     D1_WORLD2["procs"] = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), prefix], env=env,
                                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for r in range(2)]
     D1_WORLD2["prefix"] = prefix
+    # ... and they are given the GPU to themselves: the library's plans assume that nothing else holds CUs while its launches run
+    # (include/diffute_hip.h dmx_set_exclusive_device), and every other GPU test checks results produced under that assumption.  On a slow
+    # host the workers used to be still running - two more processes on the same GPU - when the first model tests started (round 5 saw one
+    # lease with an 8 x slower host produce a different training gradient in test_cfg4; EXPERIMENTS.md round 5 item 6).
+    for p in D1_WORLD2["procs"]:
+        try:
+            p.wait(timeout=900)
+        except subprocess.TimeoutExpired:
+            pass                                   # test_dist_gpu.py reports it
 
 
 def pytest_sessionfinish(session, exitstatus):
