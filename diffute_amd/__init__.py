@@ -8,10 +8,10 @@ from .models import (AutoencoderKL, UNet2DConditionModel, DiagonalGaussianDistri
                      SD2_INPAINT_UNET_CONFIG, SD_VAE_CONFIG, TROCR_LARGE_VIT_CONFIG)
 from .schedulers import DDIMScheduler, DDPMScheduler, SD2_SCHEDULER_CONFIG
 from .pipeline import denoise, edit_latents, mask_to_latent
-from .optim import FusedAdamW
+from .optim import FusedAdamW, GradScaler
 
 __all__ = ["AutoencoderKL", "UNet2DConditionModel", "DDPMScheduler", "DDIMScheduler", "denoise", "edit_latents",
-           "mask_to_latent", "FusedAdamW", "TrOCREncoder", "TROCR_LARGE_VIT_CONFIG", "DiagonalGaussianDistribution", "SD2_INPAINT_UNET_CONFIG", "SD_VAE_CONFIG",
+           "mask_to_latent", "FusedAdamW", "GradScaler", "TrOCREncoder", "TROCR_LARGE_VIT_CONFIG", "DiagonalGaussianDistribution", "SD2_INPAINT_UNET_CONFIG", "SD_VAE_CONFIG",
            "SD2_SCHEDULER_CONFIG"]
 __version__ = "0.1.0"
 from . import prepost  # noqa: E402,F401  (on-device pre/post-processing)

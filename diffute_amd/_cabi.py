@@ -198,6 +198,7 @@ _PROTOS = {
     "dmx_vae_encode_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "dmx_vae_decode_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "dmx_unet_adamw_step": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P, c_size_t, _P, c_float, _P]),
+    "dmx_unet_adamw_step_scaled": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P, c_size_t, _P, c_float, c_float, _P]),
     "dmx_unet_refresh_derived": (c_int, [_P, _P]),
     "dmx_unet_temb_table_floats": (c_size_t, [_P, c_int]),
     "dmx_unet_temb_table_workspace_bytes": (c_size_t, [_P, c_int]),

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void dmx_sqnorm_part_kernel(const OptChunk* ta
   for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-// scal[0] = ||g||, scal[1] = clip coefficient
-__global__ __launch_bounds__(1024) void dmx_clip_coef_kernel(const float* part, int n, float max_norm, float* scal) {
+// scal[0] = ||g|| (of the UNSCALED gradient g * inv_scale), scal[1] = the factor the update multiplies g by (clip coefficient * inv_scale);
+// with `found` (loss-scaled fp16 training, torch GradScaler's contract): scal[2] = 1 when the gradient holds an inf / NaN - the update
+// kernel then leaves every arena untouched - else 0
+__global__ __launch_bounds__(1024) void dmx_clip_coef_kernel(const float* part, int n, float max_norm, float* scal, float inv_scale, int found) {
   __shared__ double red[1024];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) s += (double)part[i];
@@ -69,17 +71,19 @@ __global__ __launch_bounds__(1024) void dmx_clip_coef_kernel(const float* part, 
   __syncthreads();
   for (int k = 512; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
   if (threadIdx.x == 0) {
-    const float norm = (float)sqrt(red[0]);
+    const float norm = (float)sqrt(red[0]) * inv_scale;
     scal[0] = norm;
     float c = 1.0f;
     if (max_norm > 0.f) { c = max_norm / (norm + 1e-6f); if (c > 1.0f) c = 1.0f; }     // torch.nn.utils.clip_grad_norm_
-    scal[1] = c;
+    scal[1] = c * inv_scale;
+    if (found) scal[2] = (norm - norm == 0.f) ? 0.f : 1.f;          // (inf - inf and NaN - NaN are NaN)
   }
 }
 __global__ __launch_bounds__(256) void dmx_adamw_kernel(const OptChunk* tab, float* p, float* m, float* v, const float* g, char* arena,
                                                         const float* scal, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                        float* ema, float ema_omd) {
+                                                        float* ema, float ema_omd, int found) {
   const OptChunk c = tab[blockIdx.x];
+  if (found && scal[2] != 0.f) return;                         // GradScaler.step: an overflowed step is skipped as a whole
   const float clip = scal[1];
   const float step_size = lr / bc1;
   for (unsigned i = threadIdx.x; i < c.count; i += 256) {
@@ -172,26 +176,44 @@ extern "C" int dmx_vae_master_import(const dmx_vae* v, void* masters, const char
 // ema (optional, fp32 arena with the masters' layout): shadow parameters updated in the same pass with
 // ema -= (1 - ema_decay) * (ema - p_new)   (diffusers EMAModel.step, the reference's `ema_unet.step(unet.parameters())`,
 // train_diffute_v1.py:934-935); the caller owns the decay schedule.
-extern "C" int dmx_unet_adamw_step(dmx_unet* u, const void* table_dev, int nchunks, void* masters, void* exp_avg, void* exp_avg_sq, const void* grads,
-                                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_grad_norm,
-                                   float* scalars, void* workspace, size_t workspace_bytes, void* ema, float ema_decay, dmx_stream_t stream) {
+// grad_inv_scale / check_finite (dmx_unet_adamw_step_scaled): the gradient arena holds grad * loss_scale (accelerate's fp16 mixed precision,
+// `--mixed_precision fp16`, train_diffute_v1.py:267,583: GradScaler.scale(loss).backward()); norm, clipping and the update use
+// g * grad_inv_scale, scalars is float[3] and scalars[2] = 1 marks a gradient with inf / NaN - that step changes nothing (GradScaler.step).
+static int adamw_step_(dmx_unet* u, const void* table_dev, int nchunks, void* masters, void* exp_avg, void* exp_avg_sq, const void* grads,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_grad_norm,
+                       float* scalars, void* workspace, size_t workspace_bytes, void* ema, float ema_decay, float grad_inv_scale, int check_finite,
+                       dmx_stream_t stream) {
   DMX_REQUIRE(u && u->arena && table_dev && masters && exp_avg && exp_avg_sq && grads && scalars, "unet_adamw_step: null argument");
   DMX_REQUIRE(nchunks > 0 && step >= 1, "unet_adamw_step: bad chunk count / step");
+  DMX_REQUIRE(grad_inv_scale > 0.f && grad_inv_scale - grad_inv_scale == 0.f, "unet_adamw_step: grad_inv_scale must be positive and finite");
   DMX_REQUIRE(workspace && workspace_bytes >= (size_t)nchunks * sizeof(float), "unet_adamw_step: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const OptChunk* tab = (const OptChunk*)table_dev;
   hipLaunchKernelGGL(dmx_sqnorm_part_kernel, dim3(nchunks), dim3(256), 0, s, tab, (const float*)grads, (float*)workspace);
   int rc = dmx_check_launch("dmx_sqnorm_part_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(dmx_clip_coef_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, nchunks, max_grad_norm, scalars);
+  hipLaunchKernelGGL(dmx_clip_coef_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, nchunks, max_grad_norm, scalars, grad_inv_scale, check_finite);
   rc = dmx_check_launch("dmx_clip_coef_kernel");
   if (rc) return rc;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(dmx_adamw_kernel, dim3(nchunks), dim3(256), 0, s, tab, (float*)masters, (float*)exp_avg, (float*)exp_avg_sq, (const float*)grads,
                      u->arena, (const float*)scalars, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
-                     (float*)ema, 1.0f - ema_decay);
+                     (float*)ema, 1.0f - ema_decay, check_finite);
   rc = dmx_check_launch("dmx_adamw_kernel");
   if (rc) return rc;
   u->drop_graphs();                      // captured inference graphs hold no weights, but folded copies are stale until refreshed
   return DMX_OK;
+}
+extern "C" int dmx_unet_adamw_step(dmx_unet* u, const void* table_dev, int nchunks, void* masters, void* exp_avg, void* exp_avg_sq, const void* grads,
+                                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_grad_norm,
+                                   float* scalars, void* workspace, size_t workspace_bytes, void* ema, float ema_decay, dmx_stream_t stream) {
+  return adamw_step_(u, table_dev, nchunks, masters, exp_avg, exp_avg_sq, grads, lr, beta1, beta2, eps, weight_decay, step, max_grad_norm, scalars,
+                     workspace, workspace_bytes, ema, ema_decay, 1.0f, 0, stream);
+}
+extern "C" int dmx_unet_adamw_step_scaled(dmx_unet* u, const void* table_dev, int nchunks, void* masters, void* exp_avg, void* exp_avg_sq,
+                                          const void* grads, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                          float max_grad_norm, float* scalars, void* workspace, size_t workspace_bytes, void* ema, float ema_decay,
+                                          float grad_inv_scale, dmx_stream_t stream) {
+  return adamw_step_(u, table_dev, nchunks, masters, exp_avg, exp_avg_sq, grads, lr, beta1, beta2, eps, weight_decay, step, max_grad_norm, scalars,
+                     workspace, workspace_bytes, ema, ema_decay, grad_inv_scale, 1, stream);
 }

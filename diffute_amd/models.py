@@ -638,10 +638,9 @@ class UNet2DConditionModel(_HipModel):
             t = timestep.reshape(-1).to(device=sample.device, dtype=torch.int64)
             if t.numel() not in (1, B):
                 raise ValueError(f"timestep must have 1 or {B} elements, got {t.numel()}")
-            if self._elem != "bf16":
-                raise NotImplementedError("UNet2DConditionModel: training runs on the bf16 build only (fp16 gradients need loss "
-                                          "scaling, which this library does not implement); use .to(dtype=torch.bfloat16)")
-            ctx = encoder_hidden_states if encoder_hidden_states.dtype in (torch.float32, torch.bfloat16) else encoder_hidden_states.float()
+            # (the fp16 build trains too - `--mixed_precision fp16`, train_diffute_v1.py:267,583,790: activation gradients are stored in
+            # fp16 there, so run the backward under a loss scale: diffute_amd.GradScaler / torch.amp.GradScaler, training.train_step(scaler=))
+            ctx = encoder_hidden_states if encoder_hidden_states.dtype in (torch.float32, self.compute_dtype) else encoder_hidden_states.float()
             out = _UNetTrainFn.apply(self, sample.detach().to(torch.float32).contiguous(), t, ctx.detach().contiguous(), *self._param_list())
             if self._dtype != torch.float32 and sample.dtype != torch.float32:
                 out = out.to(sample.dtype)
@@ -893,8 +892,7 @@ class AutoencoderKL(_HipModel):
             _cabi.require_cuda(sample)
             if sample.shape[2] % 64 or sample.shape[3] % 64:
                 raise ValueError("AutoencoderKL training: image sides must be multiples of 64")
-            if self._elem != "bf16":
-                raise NotImplementedError("AutoencoderKL: training runs on the bf16 build only; use .to(dtype=torch.bfloat16)")
+            # (fp16 build: run the backward under a loss scale - torch.amp.GradScaler / diffute_amd.GradScaler; train_vae.py's --mixed_precision)
             dec = _VAETrainFn.apply(self, sample.detach().to(torch.float32).contiguous(), *self._param_list())
             return {"sample": dec} if return_dict else (dec,)
         post = self.encode(sample).latent_dist

@@ -33,7 +33,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.ema_use_warmup, self.ema_inv_gamma, self.ema_power = bool(ema_use_warmup), float(ema_inv_gamma), float(ema_power)
         self.max_grad_norm = float(max_grad_norm or 0.0)
         self.t = 0
-        lib = _cabi.lib()
+        lib = unet._lib                        # the build the model computes in writes its 16-bit weights (bf16 / fp16)
         dev = unet.device
         n = lib.dmx_unet_grad_bytes(unet._h) // 4
         self.masters = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -45,7 +45,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self.nchunks = lib.dmx_unet_optim_chunks(unet._h)
         self.table = torch.empty(lib.dmx_unet_optim_table_bytes(unet._h), dtype=torch.uint8, device=dev)
         _cabi.check(lib.dmx_unet_optim_table(unet._h, _cabi.ptr(self.table), self.table.numel(), st), "optim_table")
-        self.scalars = torch.zeros(2, dtype=torch.float32, device=dev)          # (|g| before clipping, clip coefficient)
+        self.scalars = torch.zeros(3, dtype=torch.float32, device=dev)          # (|g| before clipping, clip coefficient [x 1 / loss scale], found_inf)
+        self.found_inf = False                  # the last step(grad_scale=...) met an inf / NaN gradient and changed nothing
         self.ws = torch.empty(self.nchunks, dtype=torch.float32, device=dev)
         self.dirty = False
         self._pending = 0                       # backward passes since the last step() / zero_grad()
@@ -70,8 +71,8 @@ class FusedAdamW(torch.optim.Optimizer):
         return float(self.param_groups[0]["weight_decay"])
 
     def _import_masters(self):
-        lib = _cabi.lib()
         u = self.unet
+        lib = u._lib
         st = _cabi.current_stream()
         for k, p in zip(u._keys, u._param_list()):
             src = p.detach().to(torch.float32).contiguous()
@@ -114,22 +115,35 @@ class FusedAdamW(torch.optim.Optimizer):
         self._pending = 0
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=None):
+        """grad_scale: the loss scale S the backward ran under (fp16 mixed precision; diffute_amd.GradScaler passes it): the arena
+        holds g * S, the step unscales inside its pass.  A gradient with an inf / NaN skips the step as a whole (`found_inf`), like
+        `GradScaler.step` - one host read of a device flag per step, the same synchronisation torch's scaler makes."""
         if closure is not None:
             raise NotImplementedError("FusedAdamW.step: closures are not supported")
         if self._pending == 0:
             raise RuntimeError("FusedAdamW.step() without a backward pass since the last step() / zero_grad()")
-        lib = _cabi.lib()
         u = self.unet
+        lib = u._lib
         tb = u._tb
         self.t += 1
         st = _cabi.current_stream()
-        _cabi.check(lib.dmx_unet_adamw_step(u._h, _cabi.ptr(self.table), self.nchunks, _cabi.ptr(self.masters), _cabi.ptr(self.exp_avg),
-                                            _cabi.ptr(self.exp_avg_sq), _cabi.ptr(tb["grads"]), self.lr, self.betas[0], self.betas[1], self.eps,
-                                            self.weight_decay, self.t, self.max_grad_norm, _cabi.ptr(self.scalars),
-                                            _cabi.ptr(self.ws), self.ws.numel() * 4,
-                                            _cabi.ptr(self.ema) if self.ema is not None else None,
-                                            self.ema_decay_at(self.t) if self.ema is not None else 0.0, st), "adamw_step")
+        head = (u._h, _cabi.ptr(self.table), self.nchunks, _cabi.ptr(self.masters), _cabi.ptr(self.exp_avg),
+                _cabi.ptr(self.exp_avg_sq), _cabi.ptr(tb["grads"]), self.lr, self.betas[0], self.betas[1], self.eps,
+                self.weight_decay, self.t, self.max_grad_norm, _cabi.ptr(self.scalars),
+                _cabi.ptr(self.ws), self.ws.numel() * 4,
+                _cabi.ptr(self.ema) if self.ema is not None else None,
+                self.ema_decay_at(self.t) if self.ema is not None else 0.0)
+        self.found_inf = False
+        if grad_scale is None:
+            _cabi.check(lib.dmx_unet_adamw_step(*head, st), "adamw_step")
+        else:
+            _cabi.check(lib.dmx_unet_adamw_step_scaled(*head, 1.0 / float(grad_scale), st), "adamw_step_scaled")
+            self.found_inf = bool(self.scalars[2].item() != 0.0)
+            if self.found_inf:                                       # nothing was written: the step does not count
+                self.t -= 1
+                self._pending = 0
+                return
         _cabi.check(lib.dmx_unet_refresh_derived(u._h, st), "refresh_derived")
         u._arena_version = getattr(u, "_arena_version", 0) + 1      # transposed weights are refreshed by the next training forward
         for sl in u._slots.values():
@@ -174,8 +188,8 @@ class FusedAdamW(torch.optim.Optimizer):
         """the EMA shadow parameters as fp32 tensors in torch layouts (what `ema_unet.save_pretrained` would store)"""
         if self.ema is None:
             raise RuntimeError("FusedAdamW was built without ema_decay")
-        lib = _cabi.lib()
         u = self.unet
+        lib = u._lib
         st = _cabi.current_stream()
         out = {}
         for k, p in zip(u._keys, u._param_list()):
@@ -188,8 +202,8 @@ class FusedAdamW(torch.optim.Optimizer):
         """master arena -> the torch Parameters (fp32, torch layouts)"""
         if not self.dirty:
             return
-        lib = _cabi.lib()
         u = self.unet
+        lib = u._lib
         st = _cabi.current_stream()
         with torch.no_grad():
             for k, p in zip(u._keys, u._param_list()):
@@ -198,3 +212,94 @@ class FusedAdamW(torch.optim.Optimizer):
                 if dst is not p.data:
                     p.data.copy_(dst)
         self.dirty = False
+
+
+class GradScaler:
+    """Dynamic loss scaling with `torch.cuda.amp.GradScaler`'s contract and defaults - what `Accelerator(mixed_precision="fp16")`
+    (train_diffute_v1.py:267,583) puts around the reference's `accelerator.backward(loss)` / `clip_grad_norm_` / `optimizer.step()`
+    (:925-930): the fp16 build stores activation gradients in fp16, so the backward runs on loss * S, the optimizer sees g / S, a step
+    whose gradient overflowed is skipped and S halves; after `growth_interval` clean steps S doubles.
+
+        scaler.scale(loss).backward(); scaler.unscale_(opt); clip_grad_norm_(...); scaler.step(opt); scaler.update()
+
+    Works with FusedAdamW (unscale, inf check, clipping and update are one HIP pass over the arena: `unscale_` is then a marker)
+    and with any torch optimizer over `unet.parameters()` (the exported `.grad` tensors are unscaled and checked with torch ops)."""
+
+    def __init__(self, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        if growth_factor <= 1.0 or not 0.0 < backoff_factor < 1.0:
+            raise ValueError("GradScaler: growth_factor must be > 1 and backoff_factor in (0, 1)")
+        self._scale, self._growth_factor, self._backoff_factor = float(init_scale), float(growth_factor), float(backoff_factor)
+        self._growth_interval, self._enabled = int(growth_interval), bool(enabled)
+        self._growth_tracker = 0
+        self._found = None                      # found_inf of the step since the last update(): None = no step yet
+        self._unscaled = set()                  # ids of the optimizers whose gradients were unscaled since the last update()
+
+    def is_enabled(self):
+        return self._enabled
+
+    def get_scale(self):
+        return self._scale if self._enabled else 1.0
+
+    def scale(self, loss):
+        return loss * self._scale if self._enabled else loss
+
+    def unscale_(self, optimizer):
+        if not self._enabled:
+            return
+        if id(optimizer) in self._unscaled:
+            raise RuntimeError("unscale_() has already been called on this optimizer since the last update().")
+        self._unscaled.add(id(optimizer))
+        if hasattr(optimizer, "masters"):       # FusedAdamW: unscaled inside step()
+            return
+        grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+        found = False
+        if grads:
+            dev = grads[0].device
+            found_t = torch.zeros(1, dtype=torch.float32, device=dev)
+            inv = torch.full((1,), 1.0 / self._scale, dtype=torch.float32, device=dev)
+            torch._amp_foreach_non_finite_check_and_unscale_(grads, found_t, inv)
+            found = bool(found_t.item() != 0.0)
+        self._found = bool(self._found) or found
+
+    def step(self, optimizer, *args, **kwargs):
+        if not self._enabled:
+            return optimizer.step(*args, **kwargs)
+        if hasattr(optimizer, "masters"):
+            self._unscaled.add(id(optimizer))
+            ret = optimizer.step(*args, grad_scale=self._scale, **kwargs)
+            self._found = bool(self._found) or optimizer.found_inf
+            return ret
+        if id(optimizer) not in self._unscaled:
+            self.unscale_(optimizer)
+        if self._found:
+            return None                         # skipped (GradScaler.step)
+        return optimizer.step(*args, **kwargs)
+
+    def update(self, new_scale=None):
+        if not self._enabled:
+            return
+        if new_scale is not None:
+            self._scale = float(new_scale)
+        else:
+            if self._found is None:
+                raise RuntimeError("No inf checks were recorded prior to update.")
+            if self._found:
+                self._scale *= self._backoff_factor
+                self._growth_tracker = 0
+            else:
+                self._growth_tracker += 1
+                if self._growth_tracker == self._growth_interval:
+                    self._scale *= self._growth_factor
+                    self._growth_tracker = 0
+        self._found = None
+        self._unscaled.clear()
+
+    def state_dict(self):
+        return dict(scale=self._scale, growth_factor=self._growth_factor, backoff_factor=self._backoff_factor,
+                    growth_interval=self._growth_interval, _growth_tracker=self._growth_tracker) if self._enabled else {}
+
+    def load_state_dict(self, sd):
+        if not self._enabled:
+            return
+        self._scale = float(sd["scale"]); self._growth_factor = float(sd["growth_factor"]); self._backoff_factor = float(sd["backoff_factor"])
+        self._growth_interval = int(sd["growth_interval"]); self._growth_tracker = int(sd["_growth_tracker"])

@@ -36,10 +36,12 @@ def training_target(scheduler, latents, noise, timesteps):
 
 
 def train_step(unet, vae, scheduler, optimizer, batch, *, noise=None, timesteps=None, enc_noise=None, enc_noise_masked=None,
-               max_grad_norm=1.0, generator=None):
+               max_grad_norm=1.0, generator=None, scaler=None):
     """One optimizer step.  batch: dict with pixel_values [B,3,H,W], masked_images [B,3,H,W], masks [B,1,H,W] and
     ocr_embeddings [B,S,1024] (the frozen TrOCR encoder's output, train_diffute_v1.py:868-871).  The random draws can be
-    injected (tests); otherwise they come from torch's device RNG like the reference.  Returns loss / grad_norm tensors."""
+    injected (tests); otherwise they come from torch's device RNG like the reference.  Returns loss / grad_norm tensors.
+    scaler: a diffute_amd.GradScaler (or torch.amp.GradScaler with a torch optimizer) - `--mixed_precision fp16` (train_diffute_v1.py:267,583):
+    backward on the scaled loss, unscale before clipping, the step skipped and the scale halved when the gradient overflowed."""
     pv = batch["pixel_values"]
     # both frozen-VAE encodes (train_diffute_v1.py:875,886) as one batch of 2B images: same arithmetic per image, half the launches
     nz = None if enc_noise is None else torch.cat([enc_noise, enc_noise_masked], 0)
@@ -56,24 +58,38 @@ def train_step(unet, vae, scheduler, optimizer, batch, *, noise=None, timesteps=
     target = training_target(scheduler, latents, noise, timesteps)
     pred = unet(torch.cat([noisy, mask, masked_latents], dim=1), timesteps, batch["ocr_embeddings"]).sample
     loss = mse_loss(pred.float(), target.float())
-    loss.backward()
-    if hasattr(optimizer, "masters"):                 # diffute_amd.optim.FusedAdamW: clipping and the update are one HIP pass
-        optimizer.step()
+    (loss if scaler is None else scaler.scale(loss)).backward()
+    if hasattr(optimizer, "masters"):                 # diffute_amd.optim.FusedAdamW: (unscaling,) clipping and the update are one HIP pass
+        if scaler is None:
+            optimizer.step()
+        else:
+            scaler.step(optimizer); scaler.update()
         grad_norm = optimizer.grad_norm
     else:
+        if scaler is not None:
+            scaler.unscale_(optimizer)
         grad_norm = torch.nn.utils.clip_grad_norm_(unet.parameters(), max_grad_norm) if max_grad_norm else None
-        optimizer.step()
+        if scaler is None:
+            optimizer.step()
+        else:
+            scaler.step(optimizer); scaler.update()
         optimizer.zero_grad(set_to_none=True)
     return dict(loss=loss.detach(), grad_norm=grad_norm)
 
 
-def train_vae_step(vae, optimizer, images, target=None, max_grad_norm=None):
+def train_vae_step(vae, optimizer, images, target=None, max_grad_norm=None, scaler=None):
     """One optimizer step of train_vae.py:716-736: pred = vae(x)["sample"] (decode of the posterior mode),
-    loss = mse_loss(pred.float(), target.float()), backward, optimizer step.  `target` defaults to the input images."""
+    loss = mse_loss(pred.float(), target.float()), backward, optimizer step.  `target` defaults to the input images.
+    scaler: loss scaling for the fp16 build (see train_step)."""
     pred = vae(images)["sample"]
     loss = mse_loss(pred.float(), (images if target is None else target).float())
-    loss.backward()
+    (loss if scaler is None else scaler.scale(loss)).backward()
+    if scaler is not None:
+        scaler.unscale_(optimizer)
     grad_norm = torch.nn.utils.clip_grad_norm_(vae.parameters(), max_grad_norm) if max_grad_norm else None
-    optimizer.step()
+    if scaler is None:
+        optimizer.step()
+    else:
+        scaler.step(optimizer); scaler.update()
     optimizer.zero_grad(set_to_none=True)
     return dict(loss=loss.detach(), grad_norm=grad_norm)

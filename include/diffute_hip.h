@@ -488,6 +488,15 @@ int dmx_unet_master_import(const dmx_unet* u, void* masters, const char* name, c
 int dmx_unet_adamw_step(dmx_unet* u, const void* table_dev, int nchunks, void* masters, void* exp_avg, void* exp_avg_sq, const void* grads,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_grad_norm,
                         float* scalars, void* workspace, size_t workspace_bytes, void* ema, float ema_decay, dmx_stream_t stream);
+/* The same step on a LOSS-SCALED gradient (accelerate's `--mixed_precision fp16`, train_diffute_v1.py:267,583,925: GradScaler.scale(loss)
+ * .backward(), then unscale_ -> clip_grad_norm_ -> step inside accelerator.clip_grad_norm_ / optimizer.step()): grads holds g * S and
+ * grad_inv_scale = 1 / S.  Norm, clipping and the update use the unscaled gradient; scalars is device float[3] = (norm of the unscaled
+ * gradient, factor applied to the arena's values, found_inf): when the gradient holds an inf or NaN, found_inf = 1 and the step changes
+ * NOTHING (masters, moments, EMA shadow, weights arena) - the caller then must not count it (GradScaler.step / update). */
+int dmx_unet_adamw_step_scaled(dmx_unet* u, const void* table_dev, int nchunks, void* masters, void* exp_avg, void* exp_avg_sq, const void* grads,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, int step, float max_grad_norm,
+                               float* scalars, void* workspace, size_t workspace_bytes, void* ema, float ema_decay, float grad_inv_scale,
+                               dmx_stream_t stream);
 int dmx_unet_refresh_derived(dmx_unet* u, dmx_stream_t stream);
 size_t dmx_mse_loss_workspace_bytes(void);
 int dmx_mse_loss(const float* pred, const float* target, size_t n, float* loss, float* dpred, float grad_scale,

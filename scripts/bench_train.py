@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="tiny UNet / VAE (plumbing check)")
     ap.add_argument("--exchange", choices=("rs_ag", "all_reduce"), default="rs_ag", help="gradient exchange schedule (SURVEY.md D1)")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW on exported gradients instead of the fused HIP optimizer")
+    ap.add_argument("--mixed-precision", choices=("bf16", "fp16"), default="bf16", help="fp16: the fp16 build + diffute_amd.GradScaler (train_diffute_v1.py:267)")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -39,6 +40,10 @@ def main():
     unet = D.UNet2DConditionModel(**ucfg).to(dev)
     vae = D.AutoencoderKL(**vcfg).to(dev).requires_grad_(False)
     sched = D.DDPMScheduler()
+    scaler = None
+    if a.mixed_precision == "fp16":
+        unet.to(dtype=torch.float16); vae.to(dtype=torch.float16)
+        scaler = D.GradScaler()
     if dist is not None:
         DD.broadcast_parameters(list(unet.parameters()), dist)                      # D3
         unet.set_gradient_sync(dist, mode=a.exchange)                              # D1
@@ -58,11 +63,11 @@ def main():
     exposed = []
     with torch.cuda.stream(stream):
         for _ in range(a.warmup):
-            train_step(unet, vae, sched, opt, batch, generator=g)
+            train_step(unet, vae, sched, opt, batch, generator=g, scaler=scaler)
         DD.barrier_sync(dist, dev)
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            out = train_step(unet, vae, sched, opt, batch, generator=g)
+            out = train_step(unet, vae, sched, opt, batch, generator=g, scaler=scaler)
             losses.append(out["loss"])
         DD.barrier_sync(dist, dev)
         dt = time.perf_counter() - t0
@@ -73,7 +78,8 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "DDP training images/sec (forward + backward + exchange + AdamW)", "value": round(thr, 3), "unit": "images/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 2),
-                          "optimizer": "torch.optim.AdamW" if a.torch_adamw else "FusedAdamW (HIP)", "per_gpu_batch": B, "px": px, "dtype": "bf16", "data": "synthetic", "loss_last": float(losses[-1]),
+                          "optimizer": "torch.optim.AdamW" if a.torch_adamw else "FusedAdamW (HIP)", "per_gpu_batch": B, "px": px, "dtype": a.mixed_precision, "data": "synthetic", "loss_last": float(losses[-1]),
+                          "loss_scale": (scaler.get_scale() if scaler else None),
                           "gradient_exchange": (a.exchange if dist is not None else None),
                           "exposed_exchange_ms_last_step": (round(exposed[-1], 3) if exposed else None),
                           "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}))

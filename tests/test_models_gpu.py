@@ -447,6 +447,116 @@ def test_tiny_unet_train_step(cuda):
         assert errs[0][0] <= 1e-1, f"gradient of {errs[0][1]}: rel-L2 {errs[0][0]:.3e}"
 
 
+def test_tiny_unet_train_step_fp16_build(cuda):
+    """`--mixed_precision fp16` (train_diffute_v1.py:267,583,790): the fp16 build's training step - fp32 master parameters, fp16 compute copies,
+    fp16 activations AND fp16 activation gradients - under a loss scale (diffute_amd.GradScaler.scale(loss).backward()), gradients unscaled and
+    compared with torch autograd on the fp32 oracle.  Same bars as the bf16 build's test (4e-2 whole-gradient rel-L2, 1e-1 worst parameter;
+    fp16 has three more mantissa bits, so it lands well inside).  WITHOUT the scale the small activation gradients go through fp16's subnormal range:
+    finite, but measurably worse - which is why the reference's accelerate wraps the backward in a GradScaler."""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from diffute_amd.synthetic import synth_inputs
+    from oracle import unet as OU
+    model = D.UNet2DConditionModel(**TINY_UNET).cuda().to(dtype=torch.float16)
+    assert model.compute_dtype == torch.float16
+    lat, mask, mlat, ctx = synth_inputs(2, 16, 16, 77, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1)
+    t = torch.tensor([981, 17], device=cuda)
+    g = torch.Generator().manual_seed(11)
+    target = torch.randn(2, 4, 16, 16, generator=g).to(cuda)
+    ref_loss, ref_pred, ref_g = _oracle_train_grads(model, OU.TINY_UNET, x, t, ctx, target, emulate_bf16=False)
+    res = {}
+    for S in (1024.0, 1.0):
+        scaler = D.GradScaler(init_scale=S)
+        model.zero_grad(set_to_none=True)
+        pred = model(x, t, ctx).sample
+        loss = mse_loss(pred, target)
+        scaler.scale(loss).backward()
+        assert_close(pred.detach().float(), ref_pred, 5e-2, "fp16 train forward vs oracle")
+        assert abs(float(loss.detach()) - ref_loss) <= 2e-2 * abs(ref_loss), f"loss {float(loss)} vs oracle {ref_loss}"
+        errs = []
+        num = den = 0.0
+        for k, p in model.named_parameters():
+            assert p.grad is not None and p.grad.dtype == torch.float32, f"no fp32 gradient for {k}"
+            gh = p.grad.detach().float().cpu() / S; gr = ref_g[k]
+            assert torch.isfinite(gh).all(), f"{k}: non-finite gradient at loss scale {S}"
+            errs.append((rel_l2(gh, gr), k))
+            num += float((gh - gr).pow(2).sum()); den += float(gr.pow(2).sum())
+        tot = (num / den) ** 0.5
+        errs.sort(reverse=True)
+        res[S] = tot
+        print(f"tiny fp16 train step, loss scale {S:g}, vs fp32 oracle: loss {float(loss):.6f} (oracle {ref_loss:.6f}); whole-gradient rel-L2 {tot:.2e}; "
+              f"median {errs[len(errs) // 2][0]:.2e}; worst: " + ", ".join(f"{k} {e:.2e}" for e, k in errs[:3]))
+        if S > 1.0:
+            assert tot <= 4e-2, f"whole-gradient rel-L2 {tot:.3e}"
+            assert errs[0][0] <= 1e-1, f"gradient of {errs[0][1]}: rel-L2 {errs[0][0]:.3e}"
+    assert res[1024.0] <= res[1.0] * 1.05, f"the loss scale did not help: {res}"
+
+
+def test_fp16_grad_scaler_with_fused_adamw(cuda):
+    """GradScaler + FusedAdamW on the fp16 build (accelerate's fp16 loop: scale -> backward -> unscale_ -> clip -> step -> update):
+    (a) a step at scale 2^10 lands where torch.optim.AdamW + clip_grad_norm_ puts a twin model fed the same (unscaled, exported) gradients;
+    (b) an overflowing backward (scale 2^40: the scaled dL/dpred does not fit fp16) is SKIPPED - masters, moments, step count, compute copies
+    untouched - and the scale backs off; (c) growth after `growth_interval` clean steps; (d) the torch-optimizer route through the same scaler."""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from diffute_amd.synthetic import synth_inputs
+    lat, mask, mlat, ctx = synth_inputs(1, 8, 8, 20, 128, device=cuda)
+    x = torch.cat([lat, mask, mlat], 1); t = torch.tensor([500], device=cuda); target = torch.zeros(1, 4, 8, 8, device=cuda)
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ref = D.UNet2DConditionModel(**TINY_UNET).cuda().to(dtype=torch.float16)
+    opt_ref = torch.optim.AdamW(ref.parameters(), **hp)
+    sc_ref = D.GradScaler(init_scale=1024.0, growth_interval=2)
+    fus = D.UNet2DConditionModel(**TINY_UNET).cuda().to(dtype=torch.float16)
+    opt_fus = D.FusedAdamW(fus, max_grad_norm=0.05, **hp)
+    sc_fus = D.GradScaler(init_scale=1024.0, growth_interval=2)
+    # (a) + (d)
+    l_ref = mse_loss(ref(x, t, ctx).sample, target); sc_ref.scale(l_ref).backward()
+    sc_ref.unscale_(opt_ref)
+    gn_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+    sc_ref.step(opt_ref); sc_ref.update(); opt_ref.zero_grad(set_to_none=True)
+    l_fus = mse_loss(fus(x, t, ctx).sample, target); sc_fus.scale(l_fus).backward()
+    sc_fus.unscale_(opt_fus); sc_fus.step(opt_fus); sc_fus.update()
+    assert not opt_fus.found_inf and opt_fus.t == 1
+    assert abs(float(l_ref.detach()) - float(l_fus.detach())) <= 1e-6 * abs(float(l_ref.detach()))
+    assert abs(float(gn_ref) - float(opt_fus.grad_norm)) <= 1e-5 * float(gn_ref), f"unscaled gradient norm {float(opt_fus.grad_norm)} vs {float(gn_ref)}"
+    sd_ref = {k: v.clone() for k, v in ref.state_dict().items()}; sd_fus = {k: v.clone() for k, v in fus.state_dict().items()}
+    worst = max(float((sd_ref[k] - sd_fus[k]).abs().max() / (sd_ref[k].abs().max() + 1e-12)) for k in sd_ref)
+    assert worst <= 2e-6, f"parameters after one scaled step differ: {worst:.2e}"
+    # (b) overflow: skipped as a whole
+    before = (opt_fus.masters.clone(), opt_fus.exp_avg.clone(), opt_fus.exp_avg_sq.clone())
+    sc_fus.update(new_scale=2.0 ** 40)
+    l2 = mse_loss(fus(x, t, ctx).sample, target); sc_fus.scale(l2).backward()
+    sc_fus.step(opt_fus)
+    assert opt_fus.found_inf and opt_fus.t == 1, "an overflowed gradient must skip the step"
+    sc_fus.update()
+    assert sc_fus.get_scale() == 2.0 ** 39
+    for a, b, nm in zip(before, (opt_fus.masters, opt_fus.exp_avg, opt_fus.exp_avg_sq), ("masters", "exp_avg", "exp_avg_sq")):
+        assert torch.equal(a, b), f"{nm} changed in a skipped step"
+    l3 = mse_loss(fus(x, t, ctx).sample, target)
+    assert torch.equal(l3.detach(), l2.detach()), "the compute copies changed in a skipped step"
+    l3.backward()                                                   # (gradient dropped below)
+    opt_fus.zero_grad()
+    # the same overflow through the torch-optimizer route: skipped, scale halves
+    sc_ref.update(new_scale=2.0 ** 40)
+    p_before = {k: v.clone() for k, v in ref.state_dict().items()}
+    sc_ref.scale(mse_loss(ref(x, t, ctx).sample, target)).backward()
+    sc_ref.step(opt_ref); sc_ref.update(); opt_ref.zero_grad(set_to_none=True)
+    assert sc_ref.get_scale() == 2.0 ** 39
+    assert all(torch.equal(p_before[k], v) for k, v in ref.state_dict().items())
+    # (c) growth: two clean steps at growth_interval = 2 double the scale
+    sc_fus.update(new_scale=256.0)
+    for i in range(2):
+        sc_fus.scale(mse_loss(fus(x, t, ctx).sample, target)).backward()
+        sc_fus.step(opt_fus); sc_fus.update()
+    assert opt_fus.t == 3 and sc_fus.get_scale() == 512.0
+    st = sc_fus.state_dict(); sc2 = D.GradScaler(); sc2.load_state_dict(st)
+    assert sc2.get_scale() == 512.0
+    with torch.no_grad():
+        out = fus.requires_grad_(False)(x, t, ctx).sample
+    assert torch.isfinite(out).all()
+
+
 def test_train_step_deterministic_and_accumulates(cuda):
     """the backward has no atomics: two identical steps give bit-identical gradients; a second backward accumulates into .grad"""
     import diffute_amd as D
@@ -693,6 +803,47 @@ def test_tiny_vae_train_step(cuda):
         print(f"tiny VAE train step vs {'bf16-emulating' if em else 'fp32'} oracle: loss {float(loss.detach()):.6f} ({rl:.6f}); whole-gradient rel-L2 {tot:.2e}; "
               "worst: " + ", ".join(f"{k} {e:.2e}" for e, k in errs[:4]))
         assert tot <= 5e-2 and errs[0][0] <= 1.5e-1, f"gradient mismatch: whole {tot:.3e}, worst {errs[0]}"
+
+
+def test_tiny_vae_train_step_fp16_build(cuda):
+    """train_vae.py's `--mixed_precision fp16`: the autoencoder training step on the fp16 build under torch's own GradScaler and a torch optimizer
+    (the route accelerate takes); unscaled gradients vs the fp32 oracle at the bf16 test's bars, then one optimizer step through
+    diffute_amd.training.train_vae_step(scaler=...)."""
+    import diffute_amd as D
+    from diffute_amd.models import mse_loss
+    from diffute_amd.training import train_vae_step
+    from oracle import pipeline as OP, vae as OV
+    vae = D.AutoencoderKL(**TINY_VAE).cuda().to(dtype=torch.float16)
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).cuda()
+    tgt = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).cuda()
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    opt = torch.optim.AdamW(vae.parameters(), lr=1e-4)
+    recon = vae(x)["sample"]
+    loss = mse_loss(recon, tgt)
+    scaler.scale(loss).backward()
+    scaler.unscale_(opt)
+    P = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+    rl, rrec, rg = OP.vae_train_grads(P, OV.TINY_VAE, x.cpu(), tgt.cpu(), emulate_bf16=False)
+    assert_close(recon.detach().float(), rrec, 5e-2, "fp16 vae train forward")
+    assert abs(float(loss.detach()) - rl) <= 2e-2 * abs(rl)
+    errs = []; num = den = 0.0
+    for k, p in vae.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        gh = p.grad.float().cpu(); gr = rg[k]
+        num += float((gh - gr).pow(2).sum()); den += float(gr.pow(2).sum())
+        if not k.endswith("to_k.bias"):
+            errs.append((rel_l2(gh, gr), k))
+    errs.sort(reverse=True)
+    tot = (num / den) ** 0.5
+    print(f"tiny fp16 VAE train step vs fp32 oracle: loss {float(loss.detach()):.6f} ({rl:.6f}); whole-gradient rel-L2 {tot:.2e}; worst: " +
+          ", ".join(f"{k} {e:.2e}" for e, k in errs[:3]))
+    assert tot <= 5e-2 and errs[0][0] <= 1.5e-1, f"gradient mismatch: whole {tot:.3e}, worst {errs[0]}"
+    scaler.step(opt); scaler.update(); opt.zero_grad(set_to_none=True)
+    sc = D.GradScaler(init_scale=1024.0)
+    l0 = float(train_vae_step(vae, opt, x, tgt, scaler=sc)["loss"])
+    l1 = float(train_vae_step(vae, opt, x, tgt, scaler=sc)["loss"])
+    assert l1 < l0 < float(loss.detach()), f"loss does not fall over three fp16 steps: {float(loss.detach())} {l0} {l1}"
 
 
 def test_training_loop_reduces_loss(cuda):
