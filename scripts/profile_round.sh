@@ -13,12 +13,13 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -o $
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/rp_mfma -o $P -- python3 $R/bench.py --steps 1 --warmup 0 --denoise-steps 4 --no-cpu-baseline --no-profile --no-secondary > $R/gpurun_out/rp_mfma.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_extra -o $P -- python3 $R/scripts/bench_extra.py --skip-vit > $R/gpurun_out/${P}_cfg3_cfg5.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_train -o $P -- python3 $R/scripts/bench_train.py --steps 2 --warmup 1 > $R/gpurun_out/${P}_train.log 2>&1
+python3 $R/scripts/bench_train.py --steps 3 --warmup 2 --mixed-precision fp16 > $R/gpurun_out/${P}_train_fp16.log 2>&1
 cd $R
 python3 scripts/rocprof_to_profiles.py /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write gpurun_out/$P /tmp/rp_mfma
 cp $(find /tmp/rp_extra -name "*kernel_stats.csv" | head -1) gpurun_out/${P}_cfg3_cfg5_kernel_stats.csv
 cp $(find /tmp/rp_train -name "*kernel_stats.csv" | head -1) gpurun_out/${P}_train_kernel_stats.csv
 grep -h '^{"metric"' gpurun_out/rp_stats.log > gpurun_out/${P}_bench_line_profiled.json
-grep -h '^{' gpurun_out/${P}_cfg3_cfg5.log gpurun_out/${P}_train.log > gpurun_out/${P}_secondary_configs.jsonl
+grep -h '^{' gpurun_out/${P}_cfg3_cfg5.log gpurun_out/${P}_train.log gpurun_out/${P}_train_fp16.log > gpurun_out/${P}_secondary_configs.jsonl
 head -8 gpurun_out/${P}_kernel_stats.csv | cut -c1-160
 head -6 gpurun_out/${P}_pmc_traffic.csv
 head -8 gpurun_out/${P}_pmc_mfma.csv
