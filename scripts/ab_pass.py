@@ -55,16 +55,27 @@ def timed():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
-        D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 50)
+        out = D.denoise(unet, D.DDIMScheduler(), lat, mask, mlat, ctx, 50)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / 3 * 1e3
+    return (time.perf_counter() - t0) / 3 * 1e3, out.clone()
 
 
+# results are compared, not only times: every pass finite, every pass of one setting bit-equal to that setting's first pass,
+# and the two settings against each other (rel-L2; 0 = the switch does not change a bit)
 res = {True: [], False: []}
+first = {}
 for r in range(rounds):
     for on in (True, False):
         setting(on)
-        res[on].append(timed())
+        ms, out = timed()
+        res[on].append(ms)
+        assert torch.isfinite(out).all(), f"{what}={on}: non-finite latents in round {r}"
+        if on not in first:
+            first[on] = out
+        else:
+            assert torch.equal(out, first[on]), f"{what}={on}: round {r} differs from round 0 (max abs {float((out - first[on]).abs().max()):.3e})"
     print(f"round {r}: on {res[True][-1]:.1f} ms, off {res[False][-1]:.1f} ms", flush=True)
 print(f"{what}: on  min {min(res[True]):.1f} median {sorted(res[True])[len(res[True]) // 2]:.1f} ms per pass")
 print(f"{what}: off min {min(res[False]):.1f} median {sorted(res[False])[len(res[False]) // 2]:.1f} ms per pass")
+d = float((first[True].float() - first[False].float()).norm() / first[False].float().norm())
+print(f"{what}: results finite and bit-repeatable in both settings; on vs off rel-L2 {d:.3e}" + (" (bit-equal)" if torch.equal(first[True], first[False]) else ""))

@@ -55,6 +55,17 @@ def main():
         img = synth_images(a.batch, 8 * a.latent, 8 * a.latent, device=dev)
         zlat = torch.randn(a.batch, 4, a.latent, a.latent, device=dev)
 
+    state = {"out": None}                               # the latents of the last denoise pass: candidates are checked, not only timed
+
+    def result_ok(ref):
+        """a candidate plan's pass against the current plan's: finite and within the rounding noise of a different summation order"""
+        out = state["out"]
+        if ref is None or out is None:
+            return True
+        if not torch.isfinite(out).all():
+            return False
+        return float((out.float() - ref.float()).norm() / ref.float().norm()) <= 2e-2
+
     def run_pass():
         if a.vae:
             with torch.no_grad(), torch.cuda.stream(side):
@@ -63,7 +74,7 @@ def main():
             torch.cuda.synchronize()
             return
         if not a.train:
-            D.denoise(unet, sched, lat, mask, mlat, ctx, a.steps)
+            state["out"] = D.denoise(unet, sched, lat, mask, mlat, ctx, a.steps).clone()
             return
         from diffute_amd.models import mse_loss
         with torch.cuda.stream(side):
@@ -107,7 +118,9 @@ def main():
     lib_override = override
     run_pass()                                                 # warm-up (one-time function attributes, context K/V)
     base = profiled_pass()
+    ref_out = state["out"]
     base2 = profiled_pass()
+    assert ref_out is None or torch.equal(ref_out, state["out"]), "two passes of the current plans differ"
     for k in base:
         base[k][1] = min(base[k][1], base2[k][1])
     order = sorted(base, key=lambda k: -base[k][1])[:a.top]
@@ -135,7 +148,11 @@ def main():
         for cfg, sk in cands:
             lib_override(M, N, K, st, ups, cfg, sk)
             got = profiled_pass().get(key)
+            ok = result_ok(ref_out)
             lib_override(M, N, K, st, ups, cfg0, sk0)
+            if not ok:
+                print(f"  cfg {cfg}/sk {sk} on M={M} N={N} K={K}: REJECTED - the pass's result is non-finite or > 2e-2 from the current plans'", flush=True)
+                continue
             if got is None or TN_TO_CFG[got[2]] != cfg or (got[3] != sk and not (sk > 1 and got[3] > 1)):
                 continue                                   # override not applicable to this GEMM (epilogue / alignment)
             res.append((got[1], cfg, got[3]))
