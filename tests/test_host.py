@@ -392,3 +392,48 @@ def test_from_pretrained_diffusers_directory_layout(tmp_path):
     u.save_pretrained(str(tmp_path / "out" / "unet"))
     u2 = D.UNet2DConditionModel.from_pretrained(str(tmp_path / "out"), subfolder="unet")
     assert u2.config.mid_block_type == "UNetMidBlock2DCrossAttn" and all(torch.equal(a, b) for a, b in zip(u.state_dict().values(), u2.state_dict().values()))
+
+
+def test_grad_scaler_follows_torch_amp_contract():
+    """diffute_amd.GradScaler (the loss scaling of `--mixed_precision fp16`, train_diffute_v1.py:267,583) against torch.amp.GradScaler's rules on a CPU
+    torch optimizer: scale / unscale_ / skipped step on inf / backoff / growth after growth_interval clean steps / state_dict, and the guard
+    against a double unscale_."""
+    import pytest
+    import torch
+    import diffute_amd as D
+    w = torch.nn.Parameter(torch.tensor([1.0, -2.0, 3.0]))
+    opt = torch.optim.SGD([w], lr=0.5)
+    sc = D.GradScaler(init_scale=8.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2)
+    assert sc.get_scale() == 8.0 and sc.is_enabled()
+    with pytest.raises(RuntimeError):
+        sc.update()                                                  # no inf check recorded yet (torch: the same error)
+    # a clean step: gradient of sum(w * c) is c, scaled by 8 in .grad, unscaled before the step
+    c = torch.tensor([0.5, 0.25, -1.0])
+    sc.scale((w * c).sum()).backward()
+    assert torch.equal(w.grad, 8.0 * c)
+    sc.unscale_(opt)
+    assert torch.equal(w.grad, c)
+    with pytest.raises(RuntimeError):
+        sc.unscale_(opt)
+    sc.step(opt); sc.update(); opt.zero_grad()
+    assert torch.allclose(w.detach(), torch.tensor([1.0, -2.0, 3.0]) - 0.5 * c) and sc.get_scale() == 8.0
+    # an overflowed gradient: the step is skipped, the scale halves, the growth counter restarts
+    before = w.detach().clone()
+    sc.scale((w * torch.tensor([float("inf"), 1.0, 1.0])).sum()).backward()
+    assert sc.step(opt) is None
+    sc.update(); opt.zero_grad()
+    assert torch.equal(w.detach(), before) and sc.get_scale() == 4.0
+    # growth_interval = 2 clean steps double it
+    for i in range(2):
+        sc.scale((w * c).sum()).backward(); sc.step(opt); sc.update(); opt.zero_grad()
+        assert sc.get_scale() == (4.0 if i == 0 else 8.0)
+    st = sc.state_dict()
+    sc2 = D.GradScaler(); sc2.load_state_dict(st)
+    assert sc2.get_scale() == 8.0 and sc2.state_dict() == st
+    sc.update(new_scale=128.0)
+    assert sc.get_scale() == 128.0
+    # disabled: a pass-through (mixed_precision "no" / "bf16")
+    off = D.GradScaler(enabled=False)
+    loss = (w * c).sum()
+    assert off.scale(loss) is loss and off.get_scale() == 1.0 and off.state_dict() == {}
+    loss.backward(); off.unscale_(opt); off.step(opt); off.update()
