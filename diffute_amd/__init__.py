@@ -9,9 +9,10 @@ from .models import (AutoencoderKL, UNet2DConditionModel, DiagonalGaussianDistri
 from .schedulers import DDIMScheduler, DDPMScheduler, SD2_SCHEDULER_CONFIG
 from .pipeline import denoise, edit_latents, mask_to_latent
 from .optim import FusedAdamW, GradScaler
+from ._cabi import set_exclusive_device, synchronize
 
 __all__ = ["AutoencoderKL", "UNet2DConditionModel", "DDPMScheduler", "DDIMScheduler", "denoise", "edit_latents",
            "mask_to_latent", "FusedAdamW", "GradScaler", "TrOCREncoder", "TROCR_LARGE_VIT_CONFIG", "DiagonalGaussianDistribution", "SD2_INPAINT_UNET_CONFIG", "SD_VAE_CONFIG",
-           "SD2_SCHEDULER_CONFIG"]
+           "SD2_SCHEDULER_CONFIG", "set_exclusive_device", "synchronize"]
 __version__ = "0.1.0"
 from . import prepost  # noqa: E402,F401  (on-device pre/post-processing)

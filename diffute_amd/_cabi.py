@@ -14,6 +14,7 @@ _LIB_PATH = os.environ.get("DIFFUTE_HIP_LIB") or os.path.join(_LIB_DIR, "libdiff
 _LIB_PATH_F16 = os.environ.get("DIFFUTE_HIP_LIB_F16") or os.path.join(_LIB_DIR, "libdiffute_hip_f16.so")
 _lib = None
 _lib_f16 = None
+_exclusive = None        # set_exclusive_device(): None = the library default (1)
 _last_elem = "bf16"      # the build handed out last: check() reads ITS error message (the call that failed went through it)
 
 
@@ -92,6 +93,8 @@ _PROTOS = {
     "dmx_set_halo_ws": (c_int, [c_int]),
     "dmx_set_defer_reduce": (c_int, [c_int]),
     "dmx_set_exclusive_device": (c_int, [c_int]),
+    "dmx_get_exclusive_device": (c_int, []),
+    "dmx_plan_epoch": (c_int, []),
     "dmx_xf_chain_ok": (c_int, [c_int, c_int]),
     "dmx_xf_chain": (c_int, [POINTER(XfChainDesc), c_int, _P]),
     "dmx_set_xf_chain": (c_int, [c_int]),
@@ -249,6 +252,8 @@ def _load(path, want_elem):
     got = l.dmx_element_type().decode()
     if got != want_elem:
         raise RuntimeError(f"diffute_amd: {path} computes in {got}, expected the {want_elem} build")
+    if _exclusive is not None:
+        l.dmx_set_exclusive_device(1 if _exclusive else 0)
     return l
 
 
@@ -303,11 +308,33 @@ def poll_device_error(l=None):
 
 
 def exclusive_device(l):
-    """current dmx_set_exclusive_device setting of library `l` (the setter returns the old value: read = set + restore)"""
-    old = l.dmx_set_exclusive_device(1)
-    if not old:
-        l.dmx_set_exclusive_device(0)
-    return int(old)
+    """current dmx_set_exclusive_device setting of library `l`"""
+    return int(l.dmx_get_exclusive_device())
+
+
+def set_exclusive_device(on):
+    """Tell the library (every loaded build) whether its launches have the GPU to themselves (include/diffute_hip.h dmx_set_exclusive_device).
+    The default, True, lets dmx_conv3x3_gn split the K range of a tile over co-resident blocks; pass False before running ANYTHING else on the
+    same GPU next to the library's launches - a second model on another stream or thread, your own kernels or collectives on a side stream.
+    denoise(micro_batches > 1) and set_gradient_sync(world > 1) switch it themselves.  A starved split launch never passes silently: it raises
+    DMX_ERR_DEVICE (RuntimeError at the next call, or at diffute_amd.synchronize()).  Returns the previous setting."""
+    global _exclusive
+    old = True if _exclusive is None else _exclusive
+    _exclusive = bool(on)                      # (a build loaded later starts from this setting: _load)
+    for lb in (_lib, _lib_f16):
+        if lb is not None:
+            lb.dmx_set_exclusive_device(1 if on else 0)
+    return old
+
+
+def synchronize(device=None):
+    """torch.cuda.synchronize() + the device -> host error poll: the public sync point.  Every launch of the library checks for an error raised by
+    an EARLIER launch, so an error inside a sequence of calls surfaces by itself; only the LAST launches before the host reads results
+    (the end of denoise(), of a training step, of vae.decode) have nobody after them - synchronise through this function (bench.py, the
+    tests and __graft_entry__.smoke() do) and a kernel that gave up on an in-kernel wait raises here instead of handing back a wrong tensor."""
+    import torch
+    torch.cuda.synchronize(device)
+    poll_device_error()
 
 
 def ptr(t):

@@ -8,7 +8,7 @@
 // base plus two per-lane constant offsets), unpadded 128-byte rows made conflict-free by XOR swizzles applied on the DMA
 // SOURCE address (K: 16-byte chunk ^ ((key >> 1) & 7) for the ds_read_b128 fragment reads; V: 64-byte half ^ ((key >> 1) & 1) for
 // the transpose reads).  4 % faster than staging through registers (147.7 -> 141.4 us at S = 4096, B*H = 20) and 16
-// VGPRs / 11 KB of LDS lighter.  scripts/attn_pieces.py (probe build) prices the pieces of the loop: exp 19 %, QK MFMAs
+// VGPRs / 11 KB of LDS lighter.  scripts/attic/attn_pieces.py (probe build) prices the pieces of the loop: exp 19 %, QK MFMAs
 // 17 %, PV MFMAs 10 %, row sum 9 %, row max 5 %, and 34 % for the skeleton (24 LDS fragment reads = 16 KB per wave per
 // tile, the scale fma, bf16 packing) - the costs add up almost exactly, i.e. the three waves of a SIMD hide little of each
 // other: VALU issue, LDS reads and the matrix pipe are each 30-47 % busy and effectively serialised.
@@ -28,7 +28,7 @@
 #define KT_BYTES (64 * KROW * 2)
 #define VT_BYTES (64 * VRS)          // sized for the larger of the two V layouts (V^T needs 64*136)
 
-// ds_read_b64_tr_b16 (gfx950 LDS transpose read; semantics verified by scripts/probes/tr_probe.hip): within each
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read; semantics verified by scripts/attic/probes/tr_probe.hip): within each
 // 16-lane group, lane p supplies the address of 4 contiguous b16 = row (p>>2), columns 4*(p&3).. of a [4][16] block;
 // lane q receives column q of that block, rows 0..3.  Eight reads, one asm statement (the compiler does not count
 // asm LDS ops: the caller waits with s_waitcnt lgkmcnt + sched_barrier before consuming).

@@ -14,7 +14,7 @@
 //     channels of one pixel);
 //   * per 64-channel CHUNK the (TH + 2) x (TW + 2) x 64 input patch is DMA'd ONCE into one of two LDS patch buffers (128-byte rows,
 //     16-byte pieces XOR-swizzled with row & 7 on the SOURCE address: conflict-free ds_read_b128 at every tap shift -
-//     scripts/probes/halo_bank_check.py); the nine taps are nine shifted fragment reads of that patch, and only the [BN][64] weight
+//     scripts/attic/probes/halo_bank_check.py); the nine taps are nine shifted fragment reads of that patch, and only the [BN][64] weight
 //     tiles (20 KB) stream through a three-stage ring: ~25 KB of LDS-DMA per tap instead of 52 KB;
 //   * the patch of chunk c + 1 lands during the first taps of chunk c and is NORMALISED IN PLACE during the others - y = x a + s,
 //     SiLU, one rounding, zero for the padding pixels - one 16-byte piece per thread and tap, riding in the MFMA shadows;
@@ -47,8 +47,9 @@ int n_cus() {                                          // of the CURRENT device 
 // other - so without the device to itself the planner takes no split: shapes that need one fall back to GroupNorm + the implicit GEMM.
 // (The stream-K GEMMs are not affected: an owner only ever waits for blocks dispatched AFTER it, which start as soon as any block retires.)
 int g_exclusive_device = 1;
-extern "C" int dmx_set_exclusive_device(int on) { const int old = g_exclusive_device; g_exclusive_device = on ? 1 : 0; return old; }
+extern "C" int dmx_set_exclusive_device(int on) { const int old = g_exclusive_device; g_exclusive_device = on ? 1 : 0; dmx_plan_switch(DMX_SW_EXCLUSIVE, g_exclusive_device); return old; }
 int dmx_exclusive_device() { return g_exclusive_device; }
+extern "C" int dmx_get_exclusive_device(void) { return g_exclusive_device; }
 
 namespace {
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
   // measurement aids, probe builds only (-DDMX_PROBES; they cost registers in the K loop): HaloConvArgs.dbg ablation switches (results
   // invalid: 1 no MFMA phase, 2 no weight DMA, 4 no normalisation, 8 no patch DMA, 16 no barriers) and .timing phase timestamps
 #ifndef DMX_HALO_DBG
-#define DMX_HALO_DBG 0                                 // (compile-time ablation builds: scripts/halo_ablate_build.sh)
+#define DMX_HALO_DBG 0                                 // (compile-time ablation builds: scripts/attic/halo_ablate_build.sh)
 #endif
   constexpr int DBG = DMX_HALO_DBG;
 #ifdef DMX_PROBES
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(512) void dmx_colstats_kernel(const bf16* x, int ld
 // Plan: tile geometry, column width BN (160 / 128: 4 x 2 waves; 80 / 64: 8 x 1 waves) and K split.  A K split costs an exchange of fp32
 // slabs through memory ((S - 1) / S x 256 x BN x 4 bytes per block, written and read back) and the co-residency of a tile's blocks, so the
 // plan takes the narrow tiles where they make the split unnecessary or smaller; with tiles to spare the wide tile wins (twice the work per
-// weight byte and per barrier).  Costs in us, fitted on scripts/halo_probe.py.
+// weight byte and per barrier).  Costs in us, fitted on scripts/attic/halo_probe.py.
 int g_halo_ws = 1;                                     // dmx_set_halo_ws: 0 = the planner never takes the warp-specialised instances (A/B aid)
 struct HaloPlan { int TH, TW, nf, wmw, bn, splits, waves; };
 HaloPlan halo_plan(const HaloConvArgs& a) {
@@ -1077,7 +1078,7 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
 // Measured per shape inside the 50-step pass (B = 4; halo incl. GroupNorm vs conv + reduce + GroupNorm): 64x64 level 61 vs 69, 87 vs 105,
 // 119 vs 129 us; 32x32 level 63 vs 66, 89 vs 98, 124 vs 125; 16x16 level 64 vs 61, 85 vs 77, 48 vs 44 - the blocks of the deep levels
 // are 8-way K splits whose fp32 slab exchange costs what the fusion saves.
-extern "C" int dmx_set_halo_ws(int on) { const int old = g_halo_ws; g_halo_ws = on; return old; }
+extern "C" int dmx_set_halo_ws(int on) { const int old = g_halo_ws; g_halo_ws = on; dmx_plan_switch(DMX_SW_HALO_WS, on); return old; }
 // ONE place for "could a fused GroupNorm -> conv launch consume statistics records of an H x W tensor": the tile geometries of halo_plan and the
 // level rule of dmx_conv_halo_pays.  The executors ask this before they spend a statistics pass / a statistics epilogue on a tensor
 // (Exec::ensure_stats, Exec::chain_stats); `everywhere` = dmx_set_halo_conv(2): wherever the kernel takes the problem.

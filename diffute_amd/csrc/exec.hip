@@ -33,14 +33,40 @@ int dmx_poll_device_error() {
                   "the blocks of the launch were not co-resident; the result of that launch is invalid", blk, d0, d1);
   else
     dmx_set_error("device error %d raised by block %d (%d, %d, %d)", k, blk, d0, d1, d2);
-  for (int i = 7; i >= 0; --i) e[i] = 0;                        // cleared: the process may go on after handling it
+  // cleared so that the process may go on after handling it - code word first, the claim word LAST (behind a fence): a block that gives up while
+  // the host is clearing either finds the claim still taken (its raise is dropped: the host is already reporting an error of this launch wave)
+  // or wins a claim that nobody zeroes afterwards.  Clearing the claim before the code (round 5) let a raiser win the CAS and have its code
+  // overwritten with 0 - claim taken, no code: every later raise of the process was dropped
+  e[0] = 0;
+  for (int i = 2; i < 8; ++i) e[i] = 0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  e[1] = 0;
   return DMX_ERR_DEVICE;
 }
 extern "C" int dmx_device_error(void) { return dmx_poll_device_error(); }
 int dmx_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { dmx_set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return DMX_ERR_HIP; }
-  return dmx_poll_device_error();
+  const int rc = dmx_poll_device_error();
+  if (rc) {                                            // the record belongs to an EARLIER launch: say so, and say where it surfaced
+    char first[400]; strncpy(first, dmx_get_error(), sizeof(first) - 1); first[sizeof(first) - 1] = 0;
+    dmx_set_error("%s [surfaced at the launch check of %s, which itself was enqueued correctly; the walk it belongs to is abandoned]", first, what ? what : "?");
+  }
+  return rc;
+}
+
+// --------------------------------------------------------------------------- plan signature
+// Every process-global switch that changes which kernels / plans a graph walk uses (dmx_set_*, dmx_gemm_plan_override) records its value here; the
+// hash of the values is part of the key of the captured hipGraphs (unet_model.h GraphKey) and of the host mirror's workspace-size cache, so toggling
+// a switch after the first forward can neither replay a graph captured under another setting nor run a walk in a workspace sized for another one -
+// and switching BACK finds the graphs of the old setting again (a counter would strand them).
+static int g_plan_sw[DMX_SW_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0};      // the defaults of the switches, in DmxPlanSwitch order
+void dmx_plan_switch(int slot, int value) { if (slot >= 0 && slot < DMX_SW_COUNT) g_plan_sw[slot] = value; }
+void dmx_plan_epoch_bump() { ++g_plan_sw[DMX_SW_OVERRIDES]; }
+extern "C" int dmx_plan_epoch(void) {
+  unsigned h = 2166136261u;
+  for (int i = 0; i < DMX_SW_COUNT; ++i) h = (h ^ (unsigned)g_plan_sw[i]) * 16777619u;
+  return (int)(h & 0x7fffffffu);
 }
 
 // --------------------------------------------------------------------------- profiler
@@ -177,14 +203,14 @@ void Workspace::release(const void* p) {
 // --------------------------------------------------------------------------- Exec ops
 // tuning aid (A/B inside one process, like dmx_gemm_plan_override): 0 switches the producer-side GroupNorm statistics off
 static int g_gn_producer_stats = 1;
-extern "C" int dmx_set_gn_producer_stats(int on) { const int old = g_gn_producer_stats; g_gn_producer_stats = on; return old; }
+extern "C" int dmx_set_gn_producer_stats(int on) { const int old = g_gn_producer_stats; g_gn_producer_stats = on; dmx_plan_switch(DMX_SW_GN_STATS, on); return old; }
 
 // tuning aid (A/B inside one process): 0 = split-K convolutions always run their own reduce pass (ConvOpts.defer ignored)
 static int g_defer_reduce = 1;
-extern "C" int dmx_set_defer_reduce(int on) { const int old = g_defer_reduce; g_defer_reduce = on; return old; }
+extern "C" int dmx_set_defer_reduce(int on) { const int old = g_defer_reduce; g_defer_reduce = on; dmx_plan_switch(DMX_SW_DEFER, on); return old; }
 
 static int g_halo_conv = 1;
-extern "C" int dmx_set_halo_conv(int on) { const int old = g_halo_conv; g_halo_conv = on; return old; }
+extern "C" int dmx_set_halo_conv(int on) { const int old = g_halo_conv; g_halo_conv = on; dmx_plan_switch(DMX_SW_HALO, on); return old; }
 bool dmx_halo_conv_enabled() { return g_halo_conv != 0; }
 
 // The per-forward pools (statistics records, stream-K / halo flags) are zeroed by a KERNEL node (dmx_zero16_launch), never by
@@ -253,7 +279,7 @@ void Exec::want_stats(GemmArgs& a, Tn& y, int rows_per_sample, int B) {
 }
 
 static int g_weight_prefetch = 1;
-extern "C" int dmx_set_weight_prefetch(int on) { const int old = g_weight_prefetch; g_weight_prefetch = on; return old; }
+extern "C" int dmx_set_weight_prefetch(int on) { const int old = g_weight_prefetch; g_weight_prefetch = on; dmx_plan_switch(DMX_SW_PREFETCH, on); return old; }
 void Exec::note(const void* w, long bytes) {
   if (!plan) return;
   if (plan_rec) plan->w.push_back({w, bytes});
@@ -562,7 +588,7 @@ Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps
 }
 
 static int g_xf_chain = 1;
-extern "C" int dmx_set_xf_chain(int on) { const int old = g_xf_chain; g_xf_chain = on; return old; }
+extern "C" int dmx_set_xf_chain(int on) { const int old = g_xf_chain; g_xf_chain = on; dmx_plan_switch(DMX_SW_XF_CHAIN, on); return old; }
 bool Exec::chain_ok(const Tn& x) const { return (g_xf_chain & 3) && !f32 && x.ld == x.C && ((g_xf_chain & 3) > 1 ? dmx_xf_chain_supported(x.rows(), x.C) : dmx_xf_chain_pays(x.rows(), x.C)); }
 // (dmx_set_xf_chain bit 2: chains without the folded entry GroupNorm - A/B aid)
 bool Exec::chain_gn_fold(const Tn& x) const { return !(g_xf_chain & 4) && !f32 && x.cst != nullptr && (x.H * x.W) % 64 == 0 && x.ld == x.C; }

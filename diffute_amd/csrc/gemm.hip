@@ -1144,7 +1144,7 @@ int dmx_zero_page(const bf16** out) {
 // filling the CUs, with split-K (fp32 partials + a reduce pass) when tiles alone leave CUs idle.  Costs are in
 // units of one 128x128x32 K-tile step of one block; constants fitted on scripts/tune_gemm.py measurements.
 struct TileCfg { int bm, bn, bk, slots; double per_ktile, fixed; };
-static const TileCfg kCfg[16] = {            // measured (scripts/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
+static const TileCfg kCfg[16] = {            // measured (scripts/attic/gemm_timeline.py): 0.45 / 0.35 / 1.05 us per K-tile,
     {128, 128, 32, 512, 1.00, 9.0},         // ~4 us of prologue + epilogue per block
     {128, 64, 32, 512, 0.78, 6.0},
     {256, 128, 64, 256, 2.35, 10.0},        // 4x the FLOPs of config 0 per K-tile at ~1.7x its rate
@@ -1220,6 +1220,7 @@ static double plan_cost(const GemmArgs& a, int c, int sk) {
 // candidate plan can be timed inside the real UNet pass - with the shape's real epilogue, neighbours and cache state.
 static std::vector<TunedPlan> g_plan_overrides;
 void dmx_gemm_plan_override_set(int M, int N, int K, int st, int ups, int cfg, int sk) {
+  dmx_plan_epoch_bump();
   if (cfg < 0) { g_plan_overrides.clear(); return; }
   for (TunedPlan& tp : g_plan_overrides)
     if (tp.M == M && tp.N == N && tp.K == K && tp.st == st && tp.ups == ups) { tp.cfg = cfg; tp.sk = sk; return; }
@@ -1260,7 +1261,7 @@ void dmx_gemm_plan(const GemmArgs& a, int* cfg_out, int* splitk_out, int* ktps_o
       if ((c == 2 || c == 6) && ((long)a.M * a.N < 256L * 128 * 96)) continue;     // big tiles only for big outputs
       // 3x3 convolutions over <= 128 input channels (the 512^2 / 256^2 levels of the autoencoder, K = 1152): the weight operand is
       // as large as the activation operand per tile, so the 256-row tile's reuse buys nothing and its longer prologue / epilogue
-      // shows - measured at batch 32 (scripts/vae_conv_probe.py): 128->128 3.54 vs 3.79 ms, 128->256 1.61 vs 1.76 ms
+      // shows - measured at batch 32 (scripts/attic/vae_conv_probe.py): 128->128 3.54 vs 3.79 ms, 128->256 1.61 vs 1.76 ms
       if (c == 2 && a.ksize == 3 && !a.direct && a.Cin <= 128 && a.Ktaps == a.K) continue;
     }
     const int nkt = a.K / T.bk;

@@ -9,6 +9,11 @@ enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN =
                  PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_WGRAD = 8, PROF_GEMM256WS = 9,
                  PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_HALO = 27 /* conv_halo.hip */, PROF_NCLASS = 28 };
 int n_cus();                                           // compute units of the CURRENT device (conv_halo.hip)
+// exec.hip: the plan signature (key of captured graphs / cached workspace sizes): every plan-changing switch records its value
+enum DmxPlanSwitch { DMX_SW_EXCLUSIVE = 0, DMX_SW_GN_STATS, DMX_SW_DEFER, DMX_SW_HALO, DMX_SW_PREFETCH, DMX_SW_XF_CHAIN, DMX_SW_HALO_WS, DMX_SW_OVERRIDES, DMX_SW_COUNT };
+void dmx_plan_switch(int slot, int value);
+void dmx_plan_epoch_bump();                            // (dmx_gemm_plan_override: a counter)
+extern "C" int dmx_plan_epoch(void);
 int dmx_exclusive_device();                            // dmx_set_exclusive_device (conv_halo.hip): 0 = plans that need co-resident blocks are off
 void dmx_profile_note_symbol(const char* sym);         // kernel symbol of the launch inside the innermost open ProfScope (exec.hip)
 struct ProfScope {

@@ -649,7 +649,7 @@ extern "C" int dmx_unet_forward_graph(dmx_unet* u, const float* f0, int c0, cons
   DMX_REQUIRE(u && u->finalized, "unet_forward_graph: weights not finalized");
   if (stream == nullptr || dmx_profile_active())
     return dmx_unet_forward(u, f0, c0, f1, c1, f2, c2, timesteps, t_count, cache, ctx_len, out, B, H, W, workspace, workspace_bytes, stream);
-  dmx_unet::GraphKey key(f0, f1, f2, timesteps, cache, out, workspace, c0, c1, c2, t_count, ctx_len, B, H, W, u->temb_table, u->temb_step, dmx_exclusive_device());
+  dmx_unet::GraphKey key(f0, f1, f2, timesteps, cache, out, workspace, c0, c1, c2, t_count, ctx_len, B, H, W, u->temb_table, u->temb_step, dmx_plan_epoch());
   dmx_unet::GraphEntry& e = u->graphs[key];
   hipStream_t s = (hipStream_t)stream;
   if (e.exec) { DMX_HIP(hipGraphLaunch(e.exec, s)); return dmx_poll_device_error(); }      // (what an earlier replay raised: common.h)

@@ -35,7 +35,7 @@ struct dmx_unet {
   std::shared_ptr<void> train_state;   // live training pass (unet_train.hip)
   // hipGraph cache: one captured UNet step per distinct argument tuple (pointers are baked into the nodes)
   typedef std::tuple<const void*, const void*, const void*, const void*, const void*, const void*, const void*,
-                     int, int, int, int, int, int, int, int, const void*, const void*, int> GraphKey;       // (last: dmx_exclusive_device() - it changes the plans baked into the graph)
+                     int, int, int, int, int, int, int, int, const void*, const void*, int> GraphKey;       // (last: dmx_plan_epoch() - every dmx_set_* switch changes the plans baked into the graph)
   // optional source of the time-embedding projections (dmx_unet_use_temb_table): row *temb_step of a table computed for all
   // timesteps of a denoise loop in one batched pass, instead of four small launches per step
   const float* temb_table = nullptr; const int* temb_step = nullptr;

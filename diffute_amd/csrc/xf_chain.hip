@@ -10,12 +10,12 @@
 //            y  = h3 Wpo^T + bpo + x                       (proj_out + the Transformer2DModel residual)
 //
 // Outside the two attention cores every op of the block is per query row.  As separate GEMMs they are 9 launches of 12-60 us whose
-// K = 320 loops are 70 % prologue + epilogue (scripts/linear_timeline.py), and the 4C-wide hidden tensor makes an 84 MB round
+// K = 320 loops are 70 % prologue + epilogue (scripts/attic/linear_timeline.py), and the 4C-wide hidden tensor makes an 84 MB round
 // trip.  Here a block owns 64 rows: the activation operand of the running GEMM lives in REGISTERS (each wave keeps its 32
 // rows x 320 k as twenty 16x32 fragments), the weights stream through a three-slot LDS ring of [320 n][64 k] tiles by
 // LDS-DMA (global_load_lds, 16 B per lane, XOR swizzle applied on the source side), two tiles (80 KB) always in flight
 // across phase boundaries - all 256 blocks walk the same weight stream, so it is L2-resident and the DMA runs at
-// ~120 GB/s per CU (scripts/probes/dma_depth_probe.hip), not at the ~25 GB/s per CU of an HBM stream.  A phase's output goes
+// ~120 GB/s per CU (scripts/attic/probes/dma_depth_probe.hip), not at the ~25 GB/s per CU of an HBM stream.  A phase's output goes
 // through the ring slot that was computed last (bf16, [64][320] swizzled) to become the next phase's register fragments.
 // Eight waves = 2 (rows) x 4 (80 output columns each), v_mfma_f32_16x16x32 with the weight tile as the A operand, so a lane
 // ends up with 4 consecutive output channels of one row (8-byte LDS writes, and a value / gate pair of GEGLU in one lane:

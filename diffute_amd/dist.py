@@ -108,7 +108,7 @@ def reduce_buckets(flat, plan, dist, group=None, wait_bucket=None, average_by=No
         for b, e in ranges:
             v = flat[b:e]
             n = e - b
-            main = (n // world) * world if mode == "rs_ag" and world > 1 else 0
+            main = (n // world) * world if mode == "rs_ag" else 0      # (world 1 too: the in-place aliasing of the two collectives is then exercised on a 1-rank RCCL group)
             if main:
                 c = main // world
                 body = v[:main]
@@ -122,6 +122,47 @@ def reduce_buckets(flat, plan, dist, group=None, wait_bucket=None, average_by=No
                 dist.all_reduce(tail, group=group)
                 if average_by:
                     tail.div_(average_by)
+
+
+class GradientAccumulator:
+    """Bookkeeping of `accelerator.accumulate(unet)` (train_diffute_v1.py:873,926) for the in-backward exchange: on the non-boundary
+    micro-steps of a gradient-accumulation window the reference (DDP under `no_sync`) skips the all-reduce and keeps the local gradient; only
+    the boundary micro-step exchanges - the ACCUMULATED gradient.  Here the backward WRITES the packed gradient arena, so the local sum of the
+    skipped micro-steps lives in a second arena (`acc`); at the boundary it is added to the fresh gradient bucket by bucket ON THE EXCHANGE
+    STREAM, right behind that bucket's completion event and in front of its collective: one exchange per optimizer step (not one per
+    micro-step), still overlapped with the backward.  Pure torch: shared by UNet2DConditionModel._train_backward and the gloo tests."""
+
+    def __init__(self, accumulate_steps=1):
+        self.n = max(1, int(accumulate_steps))
+        self.micro = 0          # backward passes since the last exchange
+        self.skip_ctx = 0       # depth of no_sync() contexts
+        self.acc = None
+        self.acc_n = 0          # micro-step gradients summed in `acc`
+
+    def boundary(self):
+        """does the backward that is about to run exchange?"""
+        return self.skip_ctx == 0 and (self.micro + 1) % self.n == 0
+
+    def stash(self, flat):
+        """a non-boundary backward has written `flat`: keep its gradient"""
+        if self.acc is None or self.acc.shape != flat.shape or self.acc.device != flat.device:
+            self.acc = torch.empty_like(flat)
+        if self.acc_n == 0:
+            self.acc.copy_(flat)
+        else:
+            self.acc.add_(flat)
+        self.acc_n += 1
+        self.micro += 1
+
+    def pre_add(self, flat, ranges):
+        """boundary step, bucket complete: flat[ranges] += what the skipped micro-steps left (call on the exchange stream)"""
+        if self.acc_n:
+            for b, e in ranges:
+                flat[b:e].add_(self.acc[b:e])
+
+    def exchanged(self):
+        self.acc_n = 0
+        self.micro = 0
 
 
 def broadcast_parameters(params, dist, src=0, group=None, module=None):

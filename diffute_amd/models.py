@@ -412,7 +412,7 @@ class UNet2DConditionModel(_HipModel):
         ps = [(p, p.shape[1]) for p in parts] + [(None, 0)] * (3 - len(parts))
         if out is None:
             out = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=x0.device)
-        key = (B, H, W, sl["ctx_shape"][1], _cabi.exclusive_device(lib))     # (the setting changes the plans, hence the workspace the walk needs)
+        key = (B, H, W, sl["ctx_shape"][1], int(lib.dmx_plan_epoch()))      # (every plan switch changes the walk, hence the workspace it needs)
         if sl["ws_need"] is None or sl["ws_need"][0] != key:
             sl["ws_need"] = (key, lib.dmx_unet_workspace_bytes(self._h, B, H, W, sl["ctx_shape"][1]))
         ws = self._slot_workspace(sl, sl["ws_need"][1])
@@ -512,20 +512,48 @@ class UNet2DConditionModel(_HipModel):
             tb["wt_sig"] = sig
         return tb
 
-    def set_gradient_sync(self, dist=None, group=None, mode="rs_ag"):
+    def set_gradient_sync(self, dist=None, group=None, mode="rs_ag", accumulate_steps=1):
         """Average gradients over the ranks of `dist` (torch.distributed; RCCL on GPUs) INSIDE the backward: each of the
         11 gradient buckets is exchanged on a side stream as soon as the backward has finished it - as an
         in-place reduce-scatter + all-gather of the arena slices (mode "rs_ag") or one all-reduce per slice ("all_reduce").
-        dist=None switches the exchange off (single GPU, or a wrapping torch DDP does it)."""
+        dist=None switches the exchange off (single GPU, or a wrapping torch DDP does it).
+
+        accumulate_steps=n (`--gradient_accumulation_steps`, `accelerator.accumulate(unet)`, train_diffute_v1.py:873,926): only every n-th
+        backward exchanges - the gradient ACCUMULATED over the window (diffute_amd.dist.GradientAccumulator); the others keep their
+        gradient local, like DDP under `no_sync()`.  `with unet.no_sync():` does the same for the backwards inside the block.  With a torch
+        optimizer the non-boundary backwards leave `.grad` untouched (the window's sum lives in the packed arena) and the boundary backward
+        delivers the exchanged sum of the whole window; with FusedAdamW nothing changes for the caller."""
         if mode not in ("rs_ag", "all_reduce"):
             raise ValueError(f"set_gradient_sync: unknown mode {mode!r}")
+        from .dist import GradientAccumulator
         self._sync = None if dist is None else dict(dist=dist, group=group, world=dist.get_world_size(group), stream=None, mode=mode,
-                                                    exposed=None)
+                                                    exposed=None, acc=GradientAccumulator(accumulate_steps))
         # the exchange runs collective kernels on a side stream while the library's launches run: those hold CUs, so plans whose blocks need
         # co-resident peers (the in-kernel K split of dmx_conv3x3_gn, e.g. in the VAE encodes of the training step) are off for this process
         shared = self._sync is not None and self._sync["world"] > 1
-        for lb in {id(x): x for x in (self._lib, _cabi.lib())}.values():
-            lb.dmx_set_exclusive_device(0 if shared else 1)
+        if shared and getattr(self, "_excl_before_sync", None) is None:
+            self._excl_before_sync = (_cabi.set_exclusive_device(False),)
+        elif not shared and getattr(self, "_excl_before_sync", None) is not None:
+            _cabi.set_exclusive_device(self._excl_before_sync[0])      # what the caller had before the exchange was switched on
+            self._excl_before_sync = None
+
+    def no_sync(self):
+        """`with unet.no_sync():` - the backwards inside the block keep their gradient local (torch DDP's contract, what
+        `accelerator.accumulate` uses on non-boundary micro-steps, train_diffute_v1.py:873); the first backward after the block exchanges
+        the accumulated gradient.  A no-op without set_gradient_sync."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            sync = getattr(self, "_sync", None)
+            if sync is not None:
+                sync["acc"].skip_ctx += 1
+            try:
+                yield
+            finally:
+                if sync is not None:
+                    sync["acc"].skip_ctx -= 1
+        return ctx()
 
     def exposed_exchange_ms(self):
         """how long the last backward's main stream sat waiting for the gradient exchange after its own kernels were done
@@ -583,27 +611,40 @@ class UNet2DConditionModel(_HipModel):
             dpred = dpred / sync["world"]                      # SUM over ranks below -> mean gradient
         dpred = dpred.to(torch.float32).contiguous()
         ev_arr, n_ev = None, 0
-        if sync is not None:
+        acc = sync["acc"] if sync is not None else None
+        fused = getattr(self, "_fused", None)
+        # gradient-accumulation window with the exchange on: local sum in acc.acc, one exchange at the boundary (dist.GradientAccumulator)
+        windowed = acc is not None and (not acc.boundary() or acc.acc_n > 0)
+        if windowed and acc.acc_n == 0 and fused is not None and fused._pending > 0:
+            raise RuntimeError("set_gradient_sync: a no_sync() / accumulate_steps window cannot start after a backward of the same optimizer step was already exchanged")
+        exchange = sync is not None and acc.boundary()
+        if exchange:
             n_ev = lib.dmx_unet_train_bucket_count(self._h)
             if tb["events"] is None:
                 tb["events"] = [torch.cuda.Event() for _ in range(n_ev)]
                 for ev in tb["events"]:
                     ev.record()                                # materialise the hipEvent_t handles
             ev_arr = (ctypes.c_void_p * n_ev)(*[ev.cuda_event for ev in tb["events"]])
-        fused = getattr(self, "_fused", None)
         with torch.cuda.stream(tb["fwd_stream"]):
-            if fused is not None:
+            if fused is not None and not windowed:
                 fused.before_backward(tb["grads"])             # gradient accumulation: stash what earlier backwards left
             _cabi.check(lib.dmx_unet_train_backward(self._h, _cabi.ptr(tb["grads"]), _cabi.ptr(dpred), ev_arr, n_ev, _cabi.current_stream()),
                         "unet_train_backward")
-        if sync is not None:
+            if sync is not None and not exchange:
+                acc.stash(tb["grads"])                         # a non-boundary micro-step: its gradient stays local (no_sync)
+        if exchange:
             from .dist import reduce_buckets
             if sync["stream"] is None:
                 sync["stream"] = torch.cuda.Stream(device=dpred.device)
             side = sync["stream"]
-            with torch.cuda.stream(side):
-                reduce_buckets(tb["grads"], self._sync_plan(tb), sync["dist"], group=sync["group"],
-                               wait_bucket=lambda i: side.wait_event(tb["events"][i]), mode=sync["mode"])
+            plan = self._sync_plan(tb)
+
+            def bucket_ready(i):                               # on the exchange stream: the bucket is complete, then + the window's local sum
+                side.wait_event(tb["events"][i])
+                acc.pre_add(tb["grads"], plan[i])
+            with torch.cuda.stream(side):                      # (acc.acc was completed by earlier backwards on the forward's stream: every bucket event orders behind them)
+                reduce_buckets(tb["grads"], plan, sync["dist"], group=sync["group"], wait_bucket=bucket_ready, mode=sync["mode"])
+            acc.exchanged()
             if sync["exposed"] is None:
                 sync["exposed"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             sync["exposed"][0].record(tb["fwd_stream"])                 # the backward's own kernels end here ...
@@ -611,7 +652,13 @@ class UNet2DConditionModel(_HipModel):
             sync["exposed"][1].record(tb["fwd_stream"])                 # ... and here the exchange has caught up
         if fused is not None:                              # the fused optimizer reads the gradient arena directly
             with torch.cuda.stream(tb["fwd_stream"]):
-                fused.after_backward(tb["grads"])
+                if windowed:
+                    fused._pending += 1                        # (the window's sum is in acc / was added before the exchange: nothing to add back)
+                else:
+                    fused.after_backward(tb["grads"])
+            torch.cuda.current_stream(dpred.device).wait_stream(tb["fwd_stream"])
+            return [None] * len(self._keys)
+        if sync is not None and not exchange:              # torch optimizer, non-boundary micro-step: `.grad` stays as it is; the boundary delivers the window's sum
             torch.cuda.current_stream(dpred.device).wait_stream(tb["fwd_stream"])
             return [None] * len(self._keys)
         out = []

@@ -113,6 +113,9 @@ class FusedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         """drops the accumulated gradient: the next backward starts from zero"""
         self._pending = 0
+        sync = getattr(self.unet, "_sync", None)
+        if sync is not None:
+            sync["acc"].exchanged()                 # ... and so does an open no_sync() / accumulate_steps window
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):

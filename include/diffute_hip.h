@@ -192,7 +192,12 @@ int dmx_set_halo_conv(int on);      /* tuning aid: 0 makes the model executors u
 int dmx_set_exclusive_device(int on); /* 1 (default): the library's launches have the GPU to themselves, one stream at a time.  0: other streams or other kernels (micro-batches on
                                        * several streams, a collective on a side stream) may hold CUs while a launch runs: dmx_conv3x3_gn then takes no in-kernel K split (its peers
                                        * must be co-resident; a starved launch raises DMX_ERR_DEVICE) and the executors use GroupNorm + dmx_conv_gemm where a split would be needed.
-                                       * Returns the old setting; captured UNet steps are keyed on it. */
+                                       * Returns the old setting; captured UNet steps are keyed on dmx_plan_epoch(), which it bumps.  The host mirror switches it
+                                       * to 0 by itself wherever IT creates the concurrency (denoise(micro_batches > 1), set_gradient_sync with world > 1);
+                                       * diffute_amd.set_exclusive_device() is the public setter for everything else (a second model / thread / stream). */
+int dmx_get_exclusive_device(void); /* the current setting */
+int dmx_plan_epoch(void);           /* counter bumped by every switch that changes which kernels / plans a graph walk uses (every dmx_set_* below and above,
+                                     * dmx_gemm_plan_override): part of the key of the captured UNet steps, and what a caller that caches workspace sizes keys on */
 int dmx_set_defer_reduce(int on);   /* tuning aid: 0 = a split-K convolution whose output is read first by a GroupNorm runs its own reduce pass (default 1: the GroupNorm's slab
                                      * kernel sums the partial planes in its load stage - bit-identical, one launch less); returns the old setting */
 int dmx_set_halo_ws(int on);        /* tuning aid: 0 keeps dmx_conv3x3_gn's planner off the warp-specialised instances (4 compute + 4 loader waves); returns the old setting */

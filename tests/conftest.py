@@ -10,6 +10,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 D1_WORLD2 = {"procs": None, "prefix": None}
+COTENANT = {"proc": None, "ctl": None, "out": None}      # tests/test_cotenant_gpu.py: a second process that loops the denoise loop on the same GPU
 
 
 def pytest_configure(config):
@@ -44,11 +45,25 @@ def pytest_sessionstart(session):
             p.wait(timeout=900)
         except subprocess.TimeoutExpired:
             pass                                   # test_dist_gpu.py reports it
+    # the deliberate co-tenant of tests/test_cotenant_gpu.py: started here for the same reason (no fork + exec once HIP is initialised), but it does
+    # not touch the GPU - it does not even import torch - until that test writes <ctl>.go, and it leaves when the test writes <ctl>.stop
+    d = tempfile.mkdtemp(prefix="cotenant_")
+    COTENANT["ctl"], COTENANT["out"] = os.path.join(d, "co"), os.path.join(d, "co.json")
+    COTENANT["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "cotenant_child.py"), "denoise-loop", "--wait-go",
+                                         "--ctl", COTENANT["ctl"], "--out", COTENANT["out"], "--dsteps", "10"], env=env,
+                                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def pytest_sessionfinish(session, exitstatus):
     for p in D1_WORLD2["procs"] or []:
         if p.poll() is None:
+            p.kill()
+    p = COTENANT["proc"]
+    if p is not None and p.poll() is None:
+        open(COTENANT["ctl"] + ".stop", "w").close()
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
             p.kill()
 
 

@@ -113,6 +113,7 @@ def test_cfg4_train_step_batch8_512px(cuda):
     del g_b, p_b
     # gradient of sample 0's loss inside the batch vs the B=1 step on sample 0
     l_s, p_s, g_s = step(x, t, ctx, tgt, sel=slice(0, 1))
+    assert torch.equal(p_s, p_a), "the sample-0 step runs the SAME forward as the full step (same inputs): its prediction must have the same bits"
     l_1, p_1, g_1 = step(x[:1].contiguous(), t[:1].contiguous(), ctx[:1].contiguous(), tgt[:1].contiguous())
     assert abs(l_s - l_1) <= 2e-2 * abs(l_1)
     assert rel_l2(p_s[:1], p_1) < 2e-2

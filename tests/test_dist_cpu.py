@@ -108,3 +108,83 @@ def test_bucketed_gradient_exchange_gloo_world2(mode):
         assert order == [0, 1]
         assert torch.equal(torch.from_numpy(w), torch.ones(3) * 5)
         assert abs(mean_loss - 1.5) < 1e-6
+
+
+
+def _accum_worker(rank, world, port, q, n_acc, mode):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from diffute_amd import dist as D
+    dist = D.init_from_env("gloo")
+    calls = {"n": 0}
+
+    class Counting:                                        # the process group seen through a counter of its collectives
+        def __getattr__(self, name):
+            f = getattr(dist, name)
+            if name in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor"):
+                def g(*a, **k):
+                    calls["n"] += 1
+                    return f(*a, **k)
+                return g
+            return f
+    cd = Counting()
+    n = 1024
+    params = [(0, 700 * 4), (800 * 4, 1024 * 4)]
+    buckets = [[(512 * 4, 1024 * 4)], [(0, 512 * 4)]]
+    plan = D.plan_buckets(params, buckets, gap=0)
+    acc = D.GradientAccumulator(accumulate_steps=n_acc)
+    flat = torch.empty(n)
+    micro = []
+    exchanges = 0
+    for k in range(2 * n_acc):                              # two windows: the state must reset at the boundary
+        g = (torch.arange(n, dtype=torch.float32) * 0.25 + 3 * k + 100 * rank) / world      # what a backward writes (1 / world folded in)
+        micro.append(g.clone())
+        flat.copy_(g)                                       # the backward WRITES the arena
+        if not acc.boundary():
+            acc.stash(flat)
+            continue
+        D.reduce_buckets(flat, plan, cd, wait_bucket=lambda i: acc.pre_add(flat, plan[i]), mode=mode)
+        acc.exchanged()
+        exchanges += 1
+        q.put((rank, k, flat.numpy().copy(), calls["n"]))
+    # a no_sync() block: skip_ctx > 0 makes every backward non-boundary whatever n says
+    acc2 = D.GradientAccumulator(1)
+    acc2.skip_ctx += 1
+    assert not acc2.boundary()
+    acc2.skip_ctx -= 1
+    assert acc2.boundary()
+    D.barrier_sync(dist)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["rs_ag", "all_reduce"])
+def test_gradient_accumulation_times_sync_gloo_world2(mode):
+    """`accelerator.accumulate(unet)` x DDP (train_diffute_v1.py:873,926): with accumulate_steps = 3 only every third backward exchanges, and what it
+    exchanges is the window's accumulated gradient - the result equals the sum over ranks of the sum over the window's micro-steps (1 / world is folded
+    into each backward), is identical on both ranks, the holes of the arena are untouched, the second window starts from zero, and the number of
+    collectives per window is that of ONE exchange."""
+    world, port, n_acc = 2, _free_port(), 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_accum_worker, args=(r, world, port, q, n_acc, mode)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in range(2 * world)]
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    idx = torch.arange(1024, dtype=torch.float32)
+    by = {}
+    for rank, k, flat, ncalls in res:
+        by.setdefault(k, {})[rank] = (torch.from_numpy(flat), ncalls)
+    assert sorted(by) == [n_acc - 1, 2 * n_acc - 1], "exactly the boundary micro-steps exchanged"
+    per_window = None
+    for w, k in enumerate(sorted(by)):
+        ks = range(w * n_acc, (w + 1) * n_acc)
+        want_live = sum((idx * 0.25 + 3 * kk + 100 * r) / world for kk in ks for r in range(world))
+        (f0, c0), (f1, c1) = by[k][0], by[k][1]
+        assert torch.equal(f0[:700], f1[:700]) and torch.equal(f0[800:], f1[800:]), "ranks hold different exchanged gradients"
+        for f in (f0, f1):
+            assert torch.allclose(f[:700], want_live[:700], rtol=1e-6, atol=1e-4) and torch.allclose(f[800:], want_live[800:], rtol=1e-6, atol=1e-4)
+        for r, f in ((0, f0), (1, f1)):                     # the hole [700, 800) is not a parameter: it keeps what the LAST backward of that rank wrote
+            assert torch.equal(f[700:800], ((idx * 0.25 + 3 * k + 100 * r) / world)[700:800])
+        assert c0 == c1
+        per_window = c0 if per_window is None else per_window
+        assert c0 == per_window * (w + 1), "one exchange worth of collectives per window"

@@ -603,31 +603,101 @@ def test_tiny_train_step_vs_golden(cuda):
 
 
 def test_gradient_sync_single_rank_matches_plain(cuda):
-    """D1 plumbing on one GPU: with a 1-rank RCCL group the in-backward bucketed all-reduce (events, side stream) must
-    leave the gradients exactly as without it."""
+    """D1 plumbing on one GPU: with a 1-rank RCCL group the in-backward bucketed exchange (events, side stream) must leave the gradients exactly
+    as without it - in BOTH schedules: "rs_ag" (the default; the in-place reduce-scatter + all-gather whose output aliases a slice of its input,
+    dist.py reduce_buckets - on RCCL and GPU tensors here) and "all_reduce".  And accumulation x sync (`accelerator.accumulate`,
+    train_diffute_v1.py:873,926): with accumulate_steps = 2 / inside `no_sync()` the first backward leaves `.grad` alone and exchanges nothing,
+    the second delivers the window's sum - the same bits as two plain backwards accumulated by autograd."""
     import torch.distributed as dist
     import diffute_amd as D
+    from diffute_amd import dist as DD
     from diffute_amd.models import mse_loss
     from diffute_amd.synthetic import synth_inputs
     model = D.UNet2DConditionModel(**TINY_UNET).cuda()
-    lat, mask, mlat, ctx = synth_inputs(1, 8, 8, 20, 128, device=cuda)
-    x = torch.cat([lat, mask, mlat], 1); t = torch.tensor([321], device=cuda); target = torch.ones(1, 4, 8, 8, device=cuda)
-    def grads():
-        model.zero_grad(set_to_none=True)
+    ins = []
+    for sd in (0, 7):
+        lat, mask, mlat, ctx = synth_inputs(1, 8, 8, 20, 128, seed=sd, device=cuda)
+        ins.append((torch.cat([lat, mask, mlat], 1), torch.tensor([321 + sd], device=cuda), ctx, torch.full((1, 4, 8, 8), 1.0 - 0.1 * sd, device=cuda)))
+
+    def backward(i):
+        x, t, ctx, target = ins[i]
         mse_loss(model(x, t, ctx).sample, target).backward()
         torch.cuda.synchronize()
+
+    def grads(seq, wrap=None):
+        model.zero_grad(set_to_none=True)
+        for j, i in enumerate(seq):
+            if wrap is not None and j < len(seq) - 1:
+                with wrap():
+                    backward(i)
+            else:
+                backward(i)
         return {k: p.grad.clone() for k, p in model.named_parameters()}
-    plain = grads()
+    plain, plain2 = grads([0]), grads([0, 1])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda if cuda.index is not None else torch.device("cuda", 0))
+    calls = {"n": 0}
+    real = DD.reduce_buckets
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    DD.reduce_buckets = counting
     try:
-        model.set_gradient_sync(dist)
-        synced = grads()
+        for mode in ("rs_ag", "all_reduce"):
+            model.set_gradient_sync(dist, mode=mode)
+            synced = grads([0])
+            for k in plain:
+                assert torch.equal(plain[k], synced[k]), (mode, k)
+            # accumulation window of two micro-steps: one exchange, the window's sum
+            model.set_gradient_sync(dist, mode=mode, accumulate_steps=2)
+            n0 = calls["n"]
+            model.zero_grad(set_to_none=True)
+            backward(0)
+            assert calls["n"] == n0 and all(p.grad is None for p in model.parameters()), "a non-boundary micro-step exchanged / delivered a gradient"
+            backward(1)
+            assert calls["n"] == n0 + 1
+            for k, p in model.named_parameters():
+                assert torch.equal(p.grad, plain2[k]), (mode, "accumulate_steps", k)
+            # the same window written with no_sync()
+            model.set_gradient_sync(dist, mode=mode)
+            n0 = calls["n"]
+            acc = grads([0, 1], wrap=model.no_sync)
+            assert calls["n"] == n0 + 1
+            for k in plain2:
+                assert torch.equal(acc[k], plain2[k]), (mode, "no_sync", k)
     finally:
+        DD.reduce_buckets = real
         model.set_gradient_sync(None)
         dist.destroy_process_group()
-    for k in plain:
-        assert torch.equal(plain[k], synced[k]), k
+    # FusedAdamW in a window: the arena holds the window's sum at the boundary, one pending step
+    model.set_gradient_sync(None)
+    opt = D.FusedAdamW(model, lr=1e-3)
+    model.zero_grad(set_to_none=True); opt.zero_grad()
+    backward(0); backward(1)
+    torch.cuda.synchronize()
+    want = model._tb["grads"].clone()                    # FusedAdamW's own accumulation (no exchange)
+    opt.zero_grad()
+
+    class OneRank:                                        # a 1-rank "process group" whose collectives are the identity
+        @staticmethod
+        def get_world_size(group=None): return 1
+        @staticmethod
+        def get_rank(group=None): return 0
+        @staticmethod
+        def reduce_scatter_tensor(out, inp, group=None): assert out.data_ptr() == inp.data_ptr()
+        @staticmethod
+        def all_gather_into_tensor(out, inp, group=None): assert out.data_ptr() == inp.data_ptr()
+        @staticmethod
+        def all_reduce(t, group=None): pass
+    model.set_gradient_sync(OneRank, accumulate_steps=2)
+    try:
+        backward(0); backward(1)
+        torch.cuda.synchronize()
+        assert opt._pending == 2 and torch.equal(model._tb["grads"], want), "FusedAdamW + accumulation window: the arena is not the window's sum"
+        opt.step()
+    finally:
+        model.set_gradient_sync(None)
 
 
 def test_cfg1_full_train_step_golden(cuda):
