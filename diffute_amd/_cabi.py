@@ -56,6 +56,17 @@ class HaloConvDesc(ctypes.Structure):
     ]
 
 
+class SkinnySeg(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("ld", c_int), ("C", c_int), ("taps", c_int), ("st", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("gn_c0", c_int)]
+
+
+class SkinnyDesc(ctypes.Structure):
+    _fields_ = [("seg", SkinnySeg * 4), ("nseg", c_int), ("B", c_int), ("H", c_int), ("W", c_int),
+                ("gn_groups", c_int), ("gn_Ctot", c_int), ("gn_eps", c_float), ("silu", c_int),
+                ("wp", c_void_p), ("N", c_int), ("bias", c_void_p), ("rowbias", c_void_p), ("ldrb", c_int),
+                ("res", c_void_p), ("ldres", c_int), ("out", c_void_p), ("ldo", c_int), ("colstats", c_void_p), ("force_S", c_int), ("timing", c_void_p), ("dbg", c_int)]
+
+
 class ViTConfig(ctypes.Structure):
     _fields_ = [("image_size", c_int), ("patch_size", c_int), ("num_channels", c_int), ("hidden_size", c_int), ("num_layers", c_int),
                 ("num_heads", c_int), ("intermediate_size", c_int), ("qkv_bias", c_int), ("layer_norm_eps", c_float)]
@@ -89,6 +100,11 @@ _PROTOS = {
     "dmx_conv3x3_gn_workspace_bytes": (c_size_t, [POINTER(HaloConvDesc)]),
     "dmx_conv3x3_gn": (c_int, [POINTER(HaloConvDesc), _P, c_size_t, _P]),
     "dmx_colstats": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "dmx_skinny_conv_supported": (c_int, [POINTER(SkinnyDesc)]),
+    "dmx_skinny_conv_workspace_bytes": (c_size_t, [POINTER(SkinnyDesc)]),
+    "dmx_skinny_conv": (c_int, [POINTER(SkinnyDesc), _P, c_size_t, _P]),
+    "dmx_skinny_pack": (c_int, [_P, c_int, _P, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), _P]),
+    "dmx_set_skinny": (c_int, [c_int]),
     "dmx_set_halo_conv": (c_int, [c_int]),
     "dmx_set_halo_ws": (c_int, [c_int]),
     "dmx_set_defer_reduce": (c_int, [c_int]),

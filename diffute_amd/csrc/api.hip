@@ -133,6 +133,34 @@ extern "C" int dmx_conv3x3_gn(const dmx_halo_conv_desc* d, void* workspace, size
   DMX_REQUIRE(d && d->x0 && d->w && d->out, "conv3x3_gn: null argument");
   return dmx_conv_halo_launch(halo_args(d), workspace, workspace_bytes, (hipStream_t)stream);
 }
+static SkinnyArgs skinny_args(const dmx_skinny_desc* d) {
+  SkinnyArgs a{};
+  a.nseg = d->nseg;
+  for (int k = 0; k < 4 && k < d->nseg; ++k) {
+    a.seg[k].x = (const bf16*)d->seg[k].x; a.seg[k].ld = d->seg[k].ld; a.seg[k].C = d->seg[k].C; a.seg[k].taps = d->seg[k].taps;
+    a.seg[k].st = d->seg[k].st; a.seg[k].gamma = d->seg[k].gamma; a.seg[k].beta = d->seg[k].beta; a.seg[k].gn_c0 = d->seg[k].gn_c0;
+  }
+  a.B = d->B; a.H = d->H; a.W = d->W; a.gn_groups = d->gn_groups; a.gn_Ctot = d->gn_Ctot; a.gn_eps = d->gn_eps; a.silu = d->silu;
+  a.wp = (const bf16*)d->wp; a.N = d->N; a.bias = d->bias; a.rowbias = d->rowbias; a.ldrb = d->ldrb;
+  a.res = (const bf16*)d->res; a.ldres = d->ldres; a.out = (bf16*)d->out; a.ldo = d->ldo; a.colstats = d->colstats; a.force_S = d->force_S; a.timing = d->timing; a.dbg = d->dbg;
+  return a;
+}
+extern "C" int dmx_skinny_conv_supported(const dmx_skinny_desc* d) { return d && d->nseg >= 1 && d->nseg <= 4 && dmx_skinny_supported(skinny_args(d)) ? 1 : 0; }
+extern "C" size_t dmx_skinny_conv_workspace_bytes(const dmx_skinny_desc* d) { return d && d->nseg >= 1 && d->nseg <= 4 ? dmx_skinny_workspace_bytes(skinny_args(d)) : 0; }
+extern "C" int dmx_skinny_conv(const dmx_skinny_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(d && d->nseg >= 1 && d->nseg <= 4 && d->wp && d->out, "skinny_conv: null argument");
+  return dmx_skinny_launch(skinny_args(d), workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int dmx_skinny_pack(const void* w, int ldw, void* wp, int N, int nseg, const int* C, const int* taps, const int* tap_stride, const int* koff, dmx_stream_t stream) {
+  DMX_REQUIRE(w && wp && C && taps && tap_stride && koff && nseg >= 1 && nseg <= 4, "skinny_pack: null argument");
+  SkinnyPackDesc d{}; d.nseg = nseg; int f = 0;
+  for (int k = 0; k < nseg; ++k) {
+    DMX_REQUIRE(C[k] > 0 && C[k] % 16 == 0 && (taps[k] == 9 || taps[k] == 1), "skinny_pack: segment %d: C=%d taps=%d", k, C[k], taps[k]);
+    d.frag0[k] = f; d.taps[k] = taps[k]; d.tap_stride[k] = tap_stride[k]; d.koff[k] = koff[k]; f += (C[k] / 16) * taps[k];
+  }
+  d.frags_per_nb = f;
+  return dmx_skinny_pack_launch((const bf16*)w, ldw, (bf16*)wp, N, d, (hipStream_t)stream);
+}
 extern "C" int dmx_colstats(const void* x, int ldx, int B, int HW, int C, long long* st, dmx_stream_t stream) {
   DMX_REQUIRE(x && st, "colstats: null argument");
   return dmx_colstats_launch((const bf16*)x, ldx, B, HW, C, st, (hipStream_t)stream);

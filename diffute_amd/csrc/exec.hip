@@ -31,6 +31,9 @@ int dmx_poll_device_error() {
   else if (k == DMX_DEVK_STREAMK_HELPER)
     dmx_set_error("device error: stream-K GEMM block %d (tile %d) gave up after 40 ms waiting for the partial sums of helper block %d - "
                   "the blocks of the launch were not co-resident; the result of that launch is invalid", blk, d0, d1);
+  else if (k == DMX_DEVK_SKINNY_PEER)
+    dmx_set_error("device error: weight-streaming conv (skinny.hip) block %d gave up after 40 ms waiting for the partial tile of K slice %d of output tile %d (slices %d) - "
+                  "the blocks of a tile were not co-resident (CUs taken by another stream?); the result of that launch is invalid", blk, d1, d0, d2);
   else
     dmx_set_error("device error %d raised by block %d (%d, %d, %d)", k, blk, d0, d1, d2);
   // cleared so that the process may go on after handling it - code word first, the claim word LAST (behind a fence): a block that gives up while
@@ -60,7 +63,7 @@ int dmx_check_launch(const char* what) {
 // hash of the values is part of the key of the captured hipGraphs (unet_model.h GraphKey) and of the host mirror's workspace-size cache, so toggling
 // a switch after the first forward can neither replay a graph captured under another setting nor run a walk in a workspace sized for another one -
 // and switching BACK finds the graphs of the old setting again (a counter would strand them).
-static int g_plan_sw[DMX_SW_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0};      // the defaults of the switches, in DmxPlanSwitch order
+static int g_plan_sw[DMX_SW_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1};      // the defaults of the switches, in DmxPlanSwitch order
 void dmx_plan_switch(int slot, int value) { if (slot >= 0 && slot < DMX_SW_COUNT) g_plan_sw[slot] = value; }
 void dmx_plan_epoch_bump() { ++g_plan_sw[DMX_SW_OVERRIDES]; }
 extern "C" int dmx_plan_epoch(void) {

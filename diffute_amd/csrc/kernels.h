@@ -7,10 +7,10 @@
 // Optional per-kernel-class timing with hipEvents on the launch stream (bench.py roofline leg).
 enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN = 3, PROF_GNORM = 4, PROF_LNORM = 5,
                  PROF_OTHER = 6, PROF_GEMM256 = 7, PROF_WGRAD = 8, PROF_GEMM256WS = 9,
-                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_HALO = 27 /* conv_halo.hip */, PROF_NCLASS = 28 };
+                 PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_HALO = 27 /* conv_halo.hip */, PROF_SKINNY = 28 /* skinny.hip */, PROF_NCLASS = 29 };
 int n_cus();                                           // compute units of the CURRENT device (conv_halo.hip)
 // exec.hip: the plan signature (key of captured graphs / cached workspace sizes): every plan-changing switch records its value
-enum DmxPlanSwitch { DMX_SW_EXCLUSIVE = 0, DMX_SW_GN_STATS, DMX_SW_DEFER, DMX_SW_HALO, DMX_SW_PREFETCH, DMX_SW_XF_CHAIN, DMX_SW_HALO_WS, DMX_SW_OVERRIDES, DMX_SW_COUNT };
+enum DmxPlanSwitch { DMX_SW_EXCLUSIVE = 0, DMX_SW_GN_STATS, DMX_SW_DEFER, DMX_SW_HALO, DMX_SW_PREFETCH, DMX_SW_XF_CHAIN, DMX_SW_HALO_WS, DMX_SW_OVERRIDES, DMX_SW_SKINNY, DMX_SW_COUNT };
 void dmx_plan_switch(int slot, int value);
 void dmx_plan_epoch_bump();                            // (dmx_gemm_plan_override: a counter)
 extern "C" int dmx_plan_epoch(void);
@@ -124,6 +124,55 @@ int dmx_conv_halo_flag_count(const HaloConvArgs& a);   // ints of zeroed flags t
 int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // statistics of a tensor nobody emitted them for: one streaming pass, DmxStat records [B][C][4] (zero before the launch)
 int dmx_colstats_launch(const bf16* x, int ldx, int B, int HW, int C, long long* st, hipStream_t stream);
+
+
+// ------------------------------------------------------------------ skinny.hip (weight-streaming conv / linear for M = B H W <= 256 rows)
+constexpr int SK_MAX_CHUNKS = 12;          // staged chunks (<= 8 k-steps of 16 channels each) per K slice
+constexpr int SK_COEF_CH = 448;            // GroupNorm'ed channels per K slice (the slice's (a, s) table in LDS)
+struct SkinnySeg {                         // one K segment: a source tensor seen through `taps` filter taps
+  const bf16* x; int ld;                   // NHWC rows = the pixels of the output grid (3x3 stride 1 pad 1, or 1x1)
+  int C;                                   // channels, multiple of 16
+  int taps;                                // 9 (3x3, pad 1) or 1
+  // GroupNorm (+ SiLU, SkinnyArgs.silu) applied while the chunk is staged; null st: the tensor is used as it is
+  const long long* st;                     // DmxStat records [B][C][4] of THIS tensor
+  const float* gamma; const float* beta;   // of this tensor's channels (pointers already offset by gn_c0)
+  int gn_c0;                               // first channel of this tensor inside the normalised (concatenated) tensor
+};
+struct SkinnyChunk { unsigned char seg, nks; unsigned short k0; int frag; unsigned short coef0, pad_; };
+struct SkinnyPiece { int n, taps, frag0, chunk0; };   // a slice's share of one segment: n = k-steps x taps items, fragments frag0 .. contiguous, first chunk
+struct SkinnyPlanSlice {
+  int nchunk, npiece;
+  SkinnyPiece pc[4];
+  int g_count;                             // (sample-independent) GroupNorm group slots of this slice, <= 16: slot -> group in slot_group
+  unsigned char slot_group[16];
+  unsigned char g_first[4], slot0[4];      // per segment: first group its piece of the slice touches, and that group's slot
+  SkinnyChunk ch[SK_MAX_CHUNKS];
+};
+struct SkinnyArgs {
+  SkinnySeg seg[4]; int nseg;
+  int B, H, W;                             // M = B H W in {64, 128, 256}; H, W powers of two; B <= 4
+  int gn_groups, gn_Ctot; float gn_eps; int silu;   // GroupNorm over the concatenation of the segments that carry statistics (gn_groups = 0: none)
+  const bf16* wp;                          // weights in fragment order (dmx_skinny_pack_launch): [N / 32][frags_per_nb][64 lanes][8]
+  int N;                                   // multiple of 32
+  const float* bias; const float* rowbias; int ldrb;     // rowbias[b * ldrb + n] (time-embedding projection) or null
+  const bf16* res; int ldres;              // residual or null
+  bf16* out; int ldo;
+  long long* colstats;                     // DmxStat records of the OUTPUT [B][N][4], added to (zero before the launch), or null
+  int force_S;                             // 0 = automatic number of K slices (tests)
+  long long* timing;                       // measurement aid: [blocks][6] phase stamps (null in the product path)
+  int dbg;                                 // measurement aid: bit 0 no MFMAs, bit 1 no weight refills, bit 2 no LDS fragment reads (results invalid)
+  // filled by the launcher
+  int S, frags_per_nb, gn_cpg, wsh, hwsh; float* slabs; int* flags; int* err; const bf16* zeros;
+  SkinnyPlanSlice plan[8];
+};
+struct SkinnyPackDesc { int nseg, frags_per_nb; int frag0[4], taps[4], tap_stride[4], koff[4]; };    // source column of (segment, tap, channel c): tap * tap_stride + koff + c
+bool dmx_skinny_enabled();
+bool dmx_skinny_supported(const SkinnyArgs& a);
+int dmx_skinny_frags_per_nb(const SkinnyArgs& a);
+int dmx_skinny_flag_count(const SkinnyArgs& a);
+size_t dmx_skinny_workspace_bytes(const SkinnyArgs& a);
+int dmx_skinny_launch(SkinnyArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int dmx_skinny_pack_launch(const bf16* w, int ldw, bf16* wp, int N, const SkinnyPackDesc& d, hipStream_t stream);
 
 // ------------------------------------------------------------------ wgrad.hip (training)
 struct WgradArgs {

@@ -365,6 +365,62 @@ def conv3x3_gn(x0, w, N, *, x1=None, gn=None, st0=None, st1=None, sc0=None, sc1=
     return (out, cst) if out_stats else out
 
 
+def skinny_pack(w, segs):
+    """row-major packed weights [N][ldw] (pack_conv_weight / pack_linear_weight) -> fragment order for skinny_conv.  segs: list of
+    (C, taps, tap_stride, koff): the source column of (tap t, channel c) of the segment is t * tap_stride + koff + c."""
+    import ctypes as _c
+    N = w.shape[0]
+    n = len(segs)
+    arr = lambda k: (_c.c_int * n)(*[int(sg[k]) for sg in segs])
+    K = sum(sg[0] * sg[1] for sg in segs)
+    wp = torch.empty(N * K, dtype=h16(), device=w.device)
+    check(lib().dmx_skinny_pack(ptr(w), w.stride(0), ptr(wp), N, n, arr(0), arr(1), arr(2), arr(3), current_stream()), "skinny_pack")
+    return wp
+
+
+def skinny_conv(segs, wp, N, *, gn=None, bias=None, rowbias=None, res=None, out_stats=False, force_S=0, timing=None, dbg=0):
+    """Weight-streaming conv / linear for M = B H W <= 256 rows (dmx_skinny_conv).  segs: list of dicts x=[B,H,W,C] tensor, taps=9|1, and for
+    GroupNorm'ed sources st= statistics records, gamma=, beta= (this tensor's channels), gn_c0=; gn = (groups, Ctot, eps, silu) of the norm
+    over the concatenation of those sources.  Returns out [B,H,W,N] (and the statistics records of out with out_stats)."""
+    from ._cabi import SkinnyDesc
+    x0 = segs[0]["x"]
+    B, H, W, _ = x0.shape
+    d = SkinnyDesc()
+    d.nseg = len(segs)
+    keep = []
+    for k, sg in enumerate(segs):
+        x = sg["x"]
+        d.seg[k].x = x.data_ptr(); d.seg[k].ld = _ld(x); d.seg[k].C = x.shape[-1]; d.seg[k].taps = sg.get("taps", 9)
+        if sg.get("st") is not None:
+            d.seg[k].st = sg["st"].data_ptr(); d.seg[k].gamma = sg["gamma"].data_ptr(); d.seg[k].beta = sg["beta"].data_ptr(); d.seg[k].gn_c0 = sg.get("gn_c0", 0)
+            keep += [sg["st"], sg["gamma"], sg["beta"]]
+    d.B, d.H, d.W = B, H, W
+    if gn is not None:
+        d.gn_groups, d.gn_Ctot, d.gn_eps, d.silu = int(gn[0]), int(gn[1]), float(gn[2]), int(gn[3])
+    d.wp = wp.data_ptr(); d.N = N
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    if rowbias is not None:
+        d.rowbias = rowbias.data_ptr(); d.ldrb = rowbias.stride(0)
+    if res is not None:
+        d.res = res.data_ptr(); d.ldres = _ld(res)
+    out = torch.empty(B, H, W, N, dtype=h16(), device=x0.device)
+    d.out = out.data_ptr(); d.ldo = N
+    cst = None
+    if out_stats:
+        cst = torch.zeros(B, N, 4, dtype=torch.int64, device=x0.device)
+        d.colstats = cst.data_ptr()
+    d.force_S = force_S; d.dbg = dbg
+    if timing is not None:
+        d.timing = timing.data_ptr()
+    if not lib().dmx_skinny_conv_supported(ctypes.byref(d)):
+        raise RuntimeError("skinny_conv: the kernel does not take this problem")
+    wsb = lib().dmx_skinny_conv_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x0.device)
+    check(lib().dmx_skinny_conv(ctypes.byref(d), ptr(ws), wsb, current_stream()), "skinny_conv")
+    return (out, cst) if out_stats else out
+
+
 def groupnorm_from_stats(x0, st0, gamma, beta, groups, eps, silu, x1=None, st1=None):
     """GroupNorm (+SiLU) whose statistics were emitted by the GEMM(s) that produced x0 / x1 (conv_gemm(..., gn_stats=True))"""
     B, H, W, C0 = x0.shape

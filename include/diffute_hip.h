@@ -202,6 +202,43 @@ int dmx_set_defer_reduce(int on);   /* tuning aid: 0 = a split-K convolution who
                                      * kernel sums the partial planes in its load stage - bit-identical, one launch less); returns the old setting */
 int dmx_set_halo_ws(int on);        /* tuning aid: 0 keeps dmx_conv3x3_gn's planner off the warp-specialised instances (4 compute + 4 loader waves); returns the old setting */
 
+/* Weight-streaming conv3x3 / conv1x1 / linear for the SKINNY levels (M = B H W in {64, 128, 256} output rows: ResnetBlock2D conv1 / conv2 at the 8x8 level at
+ * batch 4 and at the 16x16 / 8x8 levels at batch 1, behind unet(...), /root/reference/app.ipynb:814).  K is a list of up to four SEGMENTS - a source tensor
+ * [B H W][C] seen through 9 taps (3x3, stride 1, pad 1) or 1 tap (the fused 1x1 shortcut of a resnet; a linear) - and the weights come in FRAGMENT ORDER
+ * (dmx_skinny_pack): every compute wave streams its 1-KB MFMA operands straight from memory into registers, the activations of a K slice are staged once in
+ * LDS, the GroupNorm (+ SiLU) in front of the conv is applied to the staged chunk from the statistics records of its input(s) (seg.st; NULL = plain input),
+ * N / 32 x S blocks ~ one per CU reduce their K slices inside the kernel in slice order (bit-reproducible).  Epilogue: + bias + rowbias[b] + residual, one
+ * rounding, optional statistics records of the output.  Needs dmx_set_exclusive_device(1) (the S blocks of a tile wait for each other, bounded: a starved
+ * launch raises DMX_ERR_DEVICE).  dmx_set_skinny(0) keeps the model executors on the tiled GEMM (A/B aid); returns the old setting. */
+typedef struct {
+  const void* x; int ld;            /* NHWC 16-bit rows = output pixels */
+  int C;                            /* channels, multiple of 16 */
+  int taps;                         /* 9 or 1 */
+  const long long* st;              /* statistics records [B][C][4] of x, or NULL (no normalisation) */
+  const float* gamma; const float* beta;   /* GroupNorm affine of THIS tensor's channels */
+  int gn_c0;                        /* first channel of x inside the normalised (concatenated) tensor */
+} dmx_skinny_seg;
+typedef struct {
+  dmx_skinny_seg seg[4]; int nseg;
+  int B, H, W;
+  int gn_groups, gn_Ctot; float gn_eps; int silu;    /* GroupNorm over the concatenation of the segments with st != NULL (gn_groups = 0: none) */
+  const void* wp;                   /* dmx_skinny_pack output */
+  int N;                            /* multiple of 32 */
+  const float* bias; const float* rowbias; int ldrb;
+  const void* res; int ldres;
+  void* out; int ldo;
+  long long* colstats;
+  int force_S;                      /* 0 = automatic number of K slices (1 .. 8; tests) */
+  long long* timing;                /* measurement aid: [blocks][6] phase stamps in 10 ns ticks, or NULL */
+  int dbg;                          /* measurement aid, 0 */
+} dmx_skinny_desc;
+int dmx_skinny_conv_supported(const dmx_skinny_desc* d);
+size_t dmx_skinny_conv_workspace_bytes(const dmx_skinny_desc* d);
+int dmx_skinny_conv(const dmx_skinny_desc* d, void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+/* w [N][ldw] 16-bit, column of (segment s, tap t, channel c) = t * tap_stride[s] + koff[s] + c  ->  wp: N x sum_s(C[s] * taps[s]) elements in fragment order */
+int dmx_skinny_pack(const void* w, int ldw, void* wp, int N, int nseg, const int* C, const int* taps, const int* tap_stride, const int* koff, dmx_stream_t stream);
+int dmx_set_skinny(int on);
+
 /* The row-local chains of diffusers' BasicTransformerBlock + Transformer2DModel.proj_out (the unet(...) call at
  * /root/reference/app.ipynb:814) at the C = 320 levels, ONE launch each (xf_chain.hip); rows M % 64 == 0:
  *   mode 0:  h_out = x w0^T + b0 + res ;  y = LayerNorm(h_out) folded into w1:  rstd * (h_out w1^T - mean * c1) + c2

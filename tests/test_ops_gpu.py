@@ -807,3 +807,77 @@ def test_device_error_channel(cuda):
     again = ops.conv3x3_gn(X, W_, N, **kw)             # the library goes on working after the error was handled
     assert torch.equal(again, good)
     del starved
+
+
+SKINNY_CASES = [
+    # name, B, H, W, C0, C1, N, Csc0, Csc1, gn, force_S
+    ("plain_b4_8x8_1280", 4, 8, 8, 1280, 0, 1280, 0, 0, False, 0),
+    ("plain_b4_8x8_S1", 4, 8, 8, 256, 0, 64, 0, 0, False, 1),
+    ("plain_b4_8x8_S3_oddslices", 4, 8, 8, 224, 0, 96, 0, 0, False, 3),
+    ("plain_b1_8x8_1280", 1, 8, 8, 1280, 0, 1280, 0, 0, False, 0),
+    ("plain_b1_16x16_640", 1, 16, 16, 640, 0, 1280, 0, 0, False, 0),
+    ("plain_b2_8x8", 2, 8, 8, 640, 0, 320, 0, 0, False, 0),
+    ("concat_sc_b4_8x8", 4, 8, 8, 1280, 1280, 1280, 1280, 1280, False, 0),
+    ("gn_b4_8x8_1280", 4, 8, 8, 1280, 0, 1280, 0, 0, True, 0),
+    ("gn_concat_sc_b4_8x8_2560", 4, 8, 8, 1280, 1280, 1280, 1280, 1280, True, 0),
+    ("gn_straddle_b1_16x16_1920", 1, 16, 16, 1280, 640, 1280, 1280, 640, True, 0),
+    ("gn_b1_8x8_S2", 1, 8, 8, 320, 0, 64, 0, 0, True, 2),
+]
+
+
+@pytest.mark.parametrize("case", SKINNY_CASES, ids=[c[0] for c in SKINNY_CASES])
+def test_skinny_conv(cuda, case):
+    """skinny.hip (the weight-streaming conv of the M = B H W <= 256 levels: ResnetBlock2D conv1 / conv2 at 8x8 / 16x16, app.ipynb:814) against
+    F.conv2d(F.silu(F.group_norm(x))) + 1x1 shortcut + time embedding + residual: M = 64 / 128 / 256, 8x8 and 16x16 images, two-source concat with
+    GroupNorm groups that straddle the sources, the fused 1x1 shortcut as one-tap K segments, 1 / 2 / 3 / automatic K slices (uneven channel slices),
+    the output's statistics records, twice for bit-reproducibility, and against the tiled implicit-GEMM path it replaces."""
+    from diffute_amd import ops
+    name, B, H, W, C0, C1, N, S0, S1, gn, fS = case
+    x0 = bf(seeded((B, C0, H, W), 1) * 1.5 + 0.3)
+    x1 = bf(seeded((B, C1, H, W), 2) * 0.5 - 1.0) if C1 else None
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    Cin = C0 + C1
+    w = bf(seeded((N, Cin, 3, 3), 3, 1 / math.sqrt(9 * Cin))); b = seeded((N,), 4, 0.1)
+    temb = seeded((B, N), 5); r = bf(seeded((B, N, H, W), 6))
+    s0 = bf(seeded((B, S0, H, W), 7)) if S0 else None
+    s1 = bf(seeded((B, S1, H, W), 8)) if S1 else None
+    sc = None if s0 is None else (s0 if s1 is None else torch.cat([s0, s1], 1))
+    wsc = bf(seeded((N, S0 + S1, 1, 1), 9, 1 / math.sqrt(S0 + S1))) if S0 else None
+    g = 1 + 0.1 * seeded((Cin,), 10); be = 0.1 * seeded((Cin,), 11)
+    ref = _halo_ref(x, w, b, gn=(g, be, 1e-5, True) if gn else None, sc=sc, wsc=wsc, temb=temb, res=None if S0 else r)
+    X0 = nhwc(x0, cuda); X1 = None if x1 is None else nhwc(x1, cuda)
+    W_ = ops.pack_conv_weight(w.to(cuda), shortcut_w=None if wsc is None else wsc.to(cuda))
+    gd, bd = g.to(cuda), be.to(cuda)
+    segs, pk = [], []
+    for src, c0 in ((X0, 0), (X1, C0)):
+        if src is None:
+            continue
+        sg = dict(x=src, taps=9)
+        if gn:
+            sg.update(st=ops.colstats(src), gamma=gd[c0:c0 + src.shape[-1]].contiguous(), beta=bd[c0:c0 + src.shape[-1]].contiguous(), gn_c0=c0)
+        segs.append(sg); pk.append((src.shape[-1], 9, Cin, c0))
+    SC0 = SC1 = None
+    if S0:
+        SC0 = nhwc(s0, cuda); segs.append(dict(x=SC0, taps=1)); pk.append((S0, 1, 0, 9 * Cin))
+        if S1:
+            SC1 = nhwc(s1, cuda); segs.append(dict(x=SC1, taps=1)); pk.append((S1, 1, 0, 9 * Cin + S0))
+    WP = ops.skinny_pack(W_, pk)
+    kw = dict(gn=(32, Cin, 1e-5, True) if gn else None, bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(), res=None if S0 else nhwc(r, cuda), out_stats=True, force_S=fS)
+    out, st = ops.skinny_conv(segs, WP, N, **kw)
+    torch.cuda.synchronize()
+    from diffute_amd import _cabi
+    _cabi.poll_device_error()
+    assert_close(nchw(out), ref, 2e-3 if gn else TOL, name)
+    yf = nchw(out).double()
+    s_hip, q_hip = ops.stat_sums(st)
+    s_ref = yf.sum((2, 3)); q_ref = (yf * yf).sum((2, 3))
+    assert float(((s_hip - s_ref).abs() / (1e-5 * yf.abs().sum((2, 3)) + 1e-4)).max()) <= 1.0, f"{name}: channel sums of the output"
+    assert float(((q_hip - q_ref).abs() / q_ref).max()) <= 1e-5, f"{name}: channel sums of squares of the output"
+    out2, st2 = ops.skinny_conv(segs, WP, N, **kw)
+    assert torch.equal(out, out2) and torch.equal(st, st2), f"{name}: not bit-reproducible"
+    # against the path it replaces: (GroupNorm kernel,) then the tiled implicit-GEMM conv
+    t, t1 = X0, X1
+    if gn:
+        t, t1 = ops.groupnorm(X0, gd, bd, 32, 1e-5, True, x1=X1), None
+    old = ops.conv_gemm(t, W_, N, x1=t1, bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(), res=None if S0 else nhwc(r, cuda), sc0=SC0, sc1=SC1)
+    assert_close(nchw(out), nchw(old).float(), 2e-3, f"{name}: vs the tiled implicit-GEMM path")
