@@ -127,7 +127,7 @@ int dmx_colstats_launch(const bf16* x, int ldx, int B, int HW, int C, long long*
 
 
 // ------------------------------------------------------------------ skinny.hip (weight-streaming conv / linear for M = B H W <= 256 rows)
-constexpr int SK_MAX_CHUNKS = 12;          // staged chunks (<= 8 k-steps of 16 channels each) per K slice
+constexpr int SK_MAX_CHUNKS = 24;          // staged chunks (<= 4 k-steps of 16 channels each) per K slice
 constexpr int SK_COEF_CH = 448;            // GroupNorm'ed channels per K slice (the slice's (a, s) table in LDS)
 struct SkinnySeg {                         // one K segment: a source tensor seen through `taps` filter taps
   const bf16* x; int ld;                   // NHWC rows = the pixels of the output grid (3x3 stride 1 pad 1, or 1x1)
@@ -139,10 +139,8 @@ struct SkinnySeg {                         // one K segment: a source tensor see
   int gn_c0;                               // first channel of this tensor inside the normalised (concatenated) tensor
 };
 struct SkinnyChunk { unsigned char seg, nks; unsigned short k0; int frag; unsigned short coef0, pad_; };
-struct SkinnyPiece { int n, taps, frag0, chunk0; };   // a slice's share of one segment: n = k-steps x taps items, fragments frag0 .. contiguous, first chunk
 struct SkinnyPlanSlice {
-  int nchunk, npiece;
-  SkinnyPiece pc[4];
+  int nchunk;
   int g_count;                             // (sample-independent) GroupNorm group slots of this slice, <= 16: slot -> group in slot_group
   unsigned char slot_group[16];
   unsigned char g_first[4], slot0[4];      // per segment: first group its piece of the slice touches, and that group's slot

@@ -1,24 +1,29 @@
 // Weight-streaming convolution / linear for the SKINNY levels of the UNet (M = B*H*W <= 256 output rows: the 8x8 level at batch 4, the
 // 16x16 and 8x8 levels at batch 1 - ResnetBlock2D conv1 / conv2 behind unet(...), app.ipynb:814).
 //
-// There the problem is a weight stream: 256 x 1280 x 11520 moves 29.5 MB of weights for 0.65 MB of activations, the HBM floor (4.7 us) is
-// above the matrix-pipe floor (3 us), and what the tiled GEMM pays for - staging the weights through LDS for reuse - buys nothing (each
-// weight element is used by ONE block).  So:
-//   * the layer's weights exist a second time in MFMA-FRAGMENT order (dmx_skinny_pack_launch, at pack time): fragment f of n-block nb is the
-//     1 KB a wave needs as the A operand of one v_mfma_f32_32x32x16 (lane l: row n = l & 31, k = 8 (l >> 5) .. + 8), fragments ordered
-//     (segment, 16-channel k-step, tap).  A compute wave streams them with ONE coalesced `global_load_dwordx4 nt` per fragment straight
-//     into VGPRs, D fragments in flight - no LDS, no DMA, no barrier on the weight path;
-//   * a block = (32 output channels) x (one K slice); K is sliced BY CHANNEL RANGE, so a slice's activations are a [M][<= 128 channel] chunk
-//     staged ONCE in LDS (256-byte rows, 16-byte pieces XOR-swizzled with row & 15 on the source side: conflict-free ds_read_b128) and the nine
-//     taps are nine shifted fragment reads of it (rows outside the image read a zero row).  Four loader waves stage chunk c + 1 while the four
-//     compute waves (one per SIMD) run chunk c; one barrier per chunk;
-//   * the GroupNorm + SiLU in front of the conv (ResnetBlock2D norm1 / norm2) is applied by the loader waves to the staged chunk in place,
-//     from the DmxStat records of the input(s) - no separate GroupNorm launch;
-//   * tiles x slices = N / 32 x S ~ one block per CU: all 256 CUs stream disjoint weight slices.  The partial sums meet in the kernel: every
-//     block folds its four waves' accumulators through LDS in wave order and publishes the [M][32] fp32 tile write-through (sc1) + flag; then
-//     block s of a tile finishes rows [M s / S, M (s + 1) / S): adds the S tiles in slice order (fixed -> bit-reproducible), bias + time-embedding
-//     row + residual, one rounding, the DmxStat records of the output.  The blocks of a tile have adjacent block ids, so they are dispatched
-//     together; the wait is bounded (~40 ms) and a block that gives up RAISES the device error (common.h) - never a silent wrong tile.
+// STATUS (round 6): correct (tests/test_ops_gpu.py::test_skinny_conv), exported as dmx_skinny_conv, and NOT taken by the model executors: in a captured
+// graph it measures 32 us (42.9 with the GroupNorm fused) for 256 x 1280 x 11520 against 25 + ~10 us for the tiled split-K GEMM + GroupNorm launch it
+// would replace.  EXPERIMENTS.md round 6 item 2 has the per-block timelines and ablations (profiles/r06_skinny_probe.jsonl): cross-block exchange 10.7 us,
+// K loop 12.4 us against a 7 us load floor of its double-buffered chunks, prologue 3 us (9.5 us with the statistics round trip of the fused GroupNorm).
+//
+// The design.  There the problem is a weight stream: 256 x 1280 x 11520 moves 29.5 MB of weights for 0.65 MB of activations, the HBM floor (4.7 us) is
+// above the matrix-pipe floor (3 us), and every weight element is used by ONE block.  So:
+//   * the layer's weights exist a second time in MFMA-FRAGMENT order (dmx_skinny_pack_launch, at pack time): fragment f of n-block nb is the 1 KB a wave
+//     needs as the A operand of one v_mfma_f32_32x32x16 (lane l: row n = l & 31, k = 8 (l >> 5) .. + 8), fragments ordered (segment, 16-channel k-step, tap):
+//     the fragments of a chunk are ONE contiguous run, staged with coalesced 1-KB LDS-DMA instructions (68 KB per CU in flight);
+//   * a block = (32 output channels) x (one K slice); K is sliced BY CHANNEL RANGE, so a slice's activations are [M][64 channel] chunks staged ONCE in LDS
+//     (128-byte rows, 16-byte pieces XOR-swizzled with (row >> 1) & 7 on the source side: conflict-free ds_read_b128) and the nine taps are nine shifted
+//     fragment reads of a chunk (rows outside the image read the buffer's zero row);
+//   * the GroupNorm + SiLU in front of the conv (ResnetBlock2D norm1 / norm2) is applied to the staged chunk in place, from the DmxStat records of the
+//     input(s) - no separate GroupNorm launch;
+//   * eight symmetric waves (two per SIMD): each stages its eighth of chunk c + 1, computes its eighth of chunk c's (k-step, tap) items, normalises what it
+//     staged; one barrier per chunk.  (First built with four compute + four loader waves and a hand-scheduled asm stream: one compute wave per SIMD issues
+//     in order, and hipcc copies / spills registers that asm ds_reads are still filling - EXPERIMENTS.md.)
+//   * tiles x slices = N / 32 x S ~ one block per CU: all 256 CUs stream disjoint weight slices.  The partial sums meet in the kernel: every block folds its
+//     waves' accumulators through LDS in wave order and publishes the [M][32] fp32 tile write-through (sc1) + flag; then block s of a tile finishes rows
+//     [M s / S, M (s + 1) / S): adds the S tiles in slice order (fixed -> bit-reproducible), bias + time-embedding row + residual, one rounding, the
+//     DmxStat records of the output.  The blocks of a tile have adjacent block ids, so they are dispatched together; the wait is bounded (~40 ms) and a
+//     block that gives up RAISES the device error (common.h) - never a silent wrong tile.
 #include "common.h"
 #include "kernels.h"
 #include <stdio.h>
@@ -26,27 +31,26 @@
 namespace {
 
 constexpr int SK_NT = 512;                 // 4 compute + 4 loader waves
-constexpr int SK_D = 6;                    // weight fragments in flight per compute wave (even: the LDS fragment double buffer alternates with it)
-constexpr int SK_ROWB = 256;               // LDS bytes per staged pixel row (128 channels)
-constexpr int SK_MAX_ITEMS = 176;            // items (k-step, tap) per compute wave and K slice (+ pad), bounded by the plan
+constexpr int SK_CKS = 4;                  // k-steps (16 channels) per staged chunk
+constexpr int SK_ROWB = SK_CKS * 32;       // LDS bytes per staged pixel row (64 channels)
+constexpr int SK_WBUF = SK_CKS * 9 * 1024; // a chunk's weight fragments: <= 36 x 1 KB
 constexpr int SK_LDT = 36;                 // floats per row of a wave's accumulator tile in LDS (32 + 4: conflict-free b128 rows)
 
-// LDS map.  K loop: two chunk buffers [M][256 B] + 16 guard rows in front of / behind each (tap-shifted rows of the first / last image rows land
-// there; they are masked to the zero row anyway) ; zero row ; GroupNorm tables.  Epilogue: the four waves' accumulator tiles reuse the buffers.
+// LDS map.  K loop: two activation chunk buffers [M + 1][128 B] (row M stays zero: what a masked tap reads), two weight chunk buffers (the chunk's
+// fragments in item order), GroupNorm tables.  Epilogue: four accumulator tiles reuse everything.
 template <int MB> struct SkL {
   static constexpr int M = 32 * MB;
-  static constexpr int BUF = M * SK_ROWB;
-  static constexpr int BUF0 = 0, BUF1 = BUF, ZERO = 2 * BUF;                 // zero row: 256 B
-  static constexpr int GST = ZERO + 256;                                      // (mean, rstd) per (sample, group slot): 4 samples x 16 slots x 8 B
+  static constexpr int BUF = (M + 1) * SK_ROWB;
+  static constexpr int BUF0 = 0, BUF1 = BUF;
+  static constexpr int WB0 = 2 * BUF, WB1 = WB0 + SK_WBUF;
+  static constexpr int GST = WB1 + SK_WBUF;                                   // (mean, rstd) per (sample, group slot): 4 samples x 16 slots x 8 B
   static constexpr int COEF = GST + 512;                                      // (a, s) per (sample, GroupNorm'ed channel of the slice): 4 x SK_COEF_CH x 8 B
-  static constexpr int TAB = COEF + 4 * SK_COEF_CH * 8;                       // the four compute waves' item tables: SK_MAX_ITEMS x 8 B each
-  static constexpr int KLOOP = TAB + 4 * SK_MAX_ITEMS * 8;
+  static constexpr int KLOOP = COEF + 4 * SK_COEF_CH * 8;
   static constexpr int RED = 4 * M * SK_LDT * 4;                              // epilogue: four [M][36] fp32 tiles (tile 0 ends up holding their sum; tile 1 the rounded outputs)
   static constexpr int TOTAL = KLOOP > RED ? KLOOP : RED;
 };
 
-__device__ __forceinline__ u32x4 ld_frag_nt(const bf16* p) { return __builtin_nontemporal_load((const u32x4*)p); }
-
+// (DBG: p.dbg's measurement switches are live - uniform branches; the one instantiation serves both.)
 template <int MB, bool DBG>
 __global__ __launch_bounds__(SK_NT, 2) void dmx_skinny_kernel(const SkinnyArgs p) {
   typedef SkL<MB> L;
@@ -64,8 +68,8 @@ __global__ __launch_bounds__(SK_NT, 2) void dmx_skinny_kernel(const SkinnyArgs p
 
   long long tm[6] = {0, 0, 0, 0, 0, 0};
   if (p.timing) tm[0] = __builtin_amdgcn_s_memrealtime();
-  // zero row (read by every masked tap lane) - visible after the first barrier
-  if (t < 16) *(u32x4*)(smem + L::ZERO + t * 16) = u32x4{0u, 0u, 0u, 0u};
+  // the zero rows (row M of both activation buffers: what a masked tap reads) - visible after the first barrier
+  if (t < 16) *(u32x4*)(smem + (t < 8 ? L::BUF0 : L::BUF1) + M * SK_ROWB + (t & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
 
   f32x16 acc[MB];
 #pragma unroll
@@ -73,269 +77,205 @@ __global__ __launch_bounds__(SK_NT, 2) void dmx_skinny_kernel(const SkinnyArgs p
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  if (wave >= 4) {
-    // ================================================================= loader waves: stage chunk c + 1 while chunk c is consumed
-    const int lw = wave - 4;
-    const bool gn_any = p.gn_groups > 0;
-    // ---- GroupNorm group statistics for the groups this slice touches (prologue; overlaps the first chunk's DMA)
-    auto stage = [&](int c, int buf) {
-      const SkinnyChunk ch = PS.ch[c];
-      const SkinnySeg& sg = p.seg[ch.seg];
-      const int r = lane >> 4, slot = lane & 15;
-      for (int j = lw; j < M / 4; j += 4) {
-        const int px = 4 * j + r;
-        const int g = slot ^ (px & 15);
-        const bf16* src = (g < 2 * ch.nks) ? sg.x + (size_t)px * sg.ld + (ch.k0 * 16 + g * 8) : p.zeros;
-        dmx_dma16(src, (unsigned)(buf + j * 1024));
-      }
-    };
-    // in place: y = silu(x a + s) for the pieces this lane requested itself (its own vmcnt wait is all the ordering it needs)
-    auto normalise = [&](int c, int buf) {
-      const SkinnyChunk ch = PS.ch[c];
-      const SkinnySeg& sg = p.seg[ch.seg];
-      if (!sg.st || (DBG && (p.dbg & 8))) return;
-      const int r = lane >> 4, slot = lane & 15;
-      const float* cf = (const float*)(smem + L::COEF) + (size_t)ch.coef0 * 2;
-      for (int j = lw; j < M / 4; j += 4) {
-        const int px = 4 * j + r;
-        const int g = slot ^ (px & 15);
-        if (g >= 2 * ch.nks) continue;
-        const int b = px >> hwsh;
-        char* q = smem + buf + j * 1024 + lane * 16;
-        const u32x4 xv = *(const u32x4*)q;
-        float x[8]; unpack_bf8(xv, x);
-        const float* cc = cf + ((size_t)b * SK_COEF_CH + g * 8) * 2;
-        float y[8];
+  // ================================================================= K loop: eight symmetric waves (two per SIMD)
+  // Every wave stages its eighth of chunk c + 1 (LDS-DMA: activations and weight fragments), computes its eighth of chunk c's items, then normalises the
+  // pieces it staged itself; one barrier per chunk.  Two waves per SIMD hide each other's LDS latency and MFMA issue: the stream needs no hand
+  // scheduling (a single compute wave per SIMD with dedicated loader waves was built first and measured: EXPERIMENTS.md round 6).
+  const int lr = lane & 31, lh = lane >> 5;
+  const bool gn_any = p.gn_groups > 0;
+  auto stage = [&](int c) {
+    const SkinnyChunk ch = PS.ch[c];
+    const SkinnySeg& sg = p.seg[ch.seg];
+    const int buf = (c & 1) ? L::BUF1 : L::BUF0;
+    const int r = lane >> 3, slot = lane & 7;           // one DMA instruction = 8 pixel rows x 8 pieces of 16 B
+    for (int j = wave; j < M / 8; j += 8) {
+      const int px = 8 * j + r;
+      const int g = slot ^ ((px >> 1) & 7);              // (128-byte rows: two rows per bank sweep, so the swizzle key is (row >> 1) & 7)
+      const bf16* src = (g < 2 * ch.nks) ? sg.x + (size_t)px * sg.ld + (ch.k0 * 16 + g * 8) : p.zeros;
+      dmx_dma16(src, (unsigned)(buf + j * 1024));
+    }
+    // ... and the chunk's weight fragments: nks x taps consecutive 1-KB fragments of this n-block, in item order
+    const int nfr = (int)ch.nks * sg.taps;
+    const bf16* wsrc = p.wp + ((size_t)tile * p.frags_per_nb + ch.frag) * 512 + lane * 8;
+    const unsigned wb = (c & 1) ? L::WB1 : L::WB0;
+    for (int j = wave; j < nfr; j += 8) dmx_dma16(wsrc + (size_t)j * 512, wb + (unsigned)(j * 1024));
+  };
+  // in place: y = silu(x a + s) for the pieces this lane requested itself (its own vmcnt wait is all the ordering it needs)
+  auto normalise = [&](int c) {
+    const SkinnyChunk ch = PS.ch[c];
+    const SkinnySeg& sg = p.seg[ch.seg];
+    if (!sg.st || (DBG && (p.dbg & 8))) return;
+    const int buf = (c & 1) ? L::BUF1 : L::BUF0;
+    const int r = lane >> 3, slot = lane & 7;
+    const float* cf = (const float*)(smem + L::COEF) + (size_t)ch.coef0 * 2;
+    for (int j = wave; j < M / 8; j += 8) {
+      const int px = 8 * j + r;
+      const int g = slot ^ ((px >> 1) & 7);
+      if (g >= 2 * ch.nks) continue;
+      const int b = px >> hwsh;
+      char* q = smem + buf + j * 1024 + lane * 16;
+      const u32x4 xv = *(const u32x4*)q;
+      float x[8]; unpack_bf8(xv, x);
+      const float* cc = cf + ((size_t)b * SK_COEF_CH + g * 8) * 2;
+      float y[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float v = __builtin_fmaf(x[e], cc[2 * e], cc[2 * e + 1]);
-          if (DBG && (p.dbg & 16)) v = x[e];
-          if (p.silu && !(DBG && (p.dbg & 32))) v *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
-          y[e] = v;
-        }
-        *(u32x4*)q = pack_bf8(y);
+      for (int e = 0; e < 8; ++e) {
+        float v = __builtin_fmaf(x[e], cc[2 * e], cc[2 * e + 1]);
+        if (p.silu) v *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
+        y[e] = v;
       }
-    };
-    // (a, s) of every GroupNorm'ed channel of the slice for every sample, from the group statistics in GST (slot = group - g_first)
-    auto coef_tables = [&]() {
-      float* cf = (float*)(smem + L::COEF);
-      const float* gs = (const float*)(smem + L::GST);
-      const int lt = t - 256;                          // 0 .. 255 among the loader threads
-      for (int c = 0; c < nchunk; ++c) {
-        const SkinnyChunk ch = PS.ch[c];
-        const SkinnySeg& sg = p.seg[ch.seg];
-        if (!sg.st) continue;
-        for (int i = lt; i < p.B * 16 * ch.nks; i += 256) {
-          const int cl = i % (16 * ch.nks), b = i / (16 * ch.nks);
-          const int cseg = ch.k0 * 16 + cl;            // channel inside the segment
-          const int gslot = PS.slot0[ch.seg] + (sg.gn_c0 + cseg) / p.gn_cpg - PS.g_first[ch.seg];
-          const float mean = gs[(b * 16 + gslot) * 2], rstd = gs[(b * 16 + gslot) * 2 + 1];
-          const float a = rstd * sg.gamma[cseg];
-          cf[((size_t)b * SK_COEF_CH + ch.coef0 + cl) * 2] = a;
-          cf[((size_t)b * SK_COEF_CH + ch.coef0 + cl) * 2 + 1] = sg.beta[cseg] - mean * a;
-        }
+      *(u32x4*)q = pack_bf8(y);
+    }
+  };
+  // (a, s) of every GroupNorm'ed channel of the slice for every sample, from the group statistics in GST (slot = group - g_first of the segment's piece)
+  auto coef_tables = [&]() {
+    float* cf = (float*)(smem + L::COEF);
+    const float* gs = (const float*)(smem + L::GST);
+    for (int c = 0; c < nchunk; ++c) {
+      const SkinnyChunk ch = PS.ch[c];
+      const SkinnySeg& sg = p.seg[ch.seg];
+      if (!sg.st) continue;
+      for (int i = t; i < p.B * 16 * ch.nks; i += SK_NT) {
+        const int cl = i % (16 * ch.nks), b = i / (16 * ch.nks);
+        const int cseg = ch.k0 * 16 + cl;            // channel inside the segment
+        const int gslot = PS.slot0[ch.seg] + (sg.gn_c0 + cseg) / p.gn_cpg - PS.g_first[ch.seg];
+        const float mean = gs[(b * 16 + gslot) * 2], rstd = gs[(b * 16 + gslot) * 2 + 1];
+        const float a = rstd * sg.gamma[cseg];
+        cf[((size_t)b * SK_COEF_CH + ch.coef0 + cl) * 2] = a;
+        cf[((size_t)b * SK_COEF_CH + ch.coef0 + cl) * 2 + 1] = sg.beta[cseg] - mean * a;
       }
-    };
-    if (nchunk > 0) stage(0, L::BUF0);
-    if (gn_any && PS.g_count > 0) {
-      // 16 loader threads per (sample, group slot): sum the group's channel records (integers: exact, any order), mean / variance in double
-      const int lt = t - 256;
-      const int sub = lt & 15, pair = lt >> 4;         // 16 pairs per round
-      for (int pr = pair; pr < p.B * PS.g_count; pr += 16) {
-        const int b = pr / PS.g_count, gslot = pr - b * PS.g_count, g = PS.slot_group[gslot];
-        long long s0 = 0, qh = 0, ql = 0;
-        for (int cg = g * p.gn_cpg + sub; cg < (g + 1) * p.gn_cpg; cg += 16) {
-          const long long* rec = nullptr;              // which GroupNorm'ed segment holds channel cg of the concatenated tensor
+    }
+  };
+  if (nchunk > 0) stage(0);
+  if (gn_any && PS.g_count > 0) {
+    // 16 threads per (sample, group slot): sum the group's channel records (integers: exact, any order), mean / variance in double.  Every record load of a
+    // thread is issued before the first is used (cpg / 16 <= 5 records: the loads are L2 / memory round trips, ~2 us each when they are serial)
+    const int sub = t & 15, pair = t >> 4;             // 32 pairs per round
+    for (int pr = pair; pr < p.B * PS.g_count; pr += 32) {
+      const int b = pr / PS.g_count, gslot = pr - b * PS.g_count, g = PS.slot_group[gslot];
+      long long r0[5], r1[5], r2[5];
+#pragma unroll
+      for (int k5 = 0; k5 < 5; ++k5) {
+        const int cg = g * p.gn_cpg + sub + 16 * k5;
+        const long long* rec = nullptr;                // which GroupNorm'ed segment holds channel cg of the concatenated tensor
+        if (cg < (g + 1) * p.gn_cpg) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const SkinnySeg& sg = p.seg[k];
             if (k < p.nseg && sg.st && cg >= sg.gn_c0 && cg < sg.gn_c0 + sg.C) rec = sg.st + ((size_t)b * sg.C + (cg - sg.gn_c0)) * DMX_STAT_WORDS;
           }
-          if (rec) { s0 += rec[0]; qh += rec[1]; ql += rec[2]; }
         }
+        r0[k5] = rec ? rec[0] : 0; r1[k5] = rec ? rec[1] : 0; r2[k5] = rec ? rec[2] : 0;
+      }
+      long long s0 = 0, qh = 0, ql = 0;
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) { s0 += __shfl_xor(s0, d); qh += __shfl_xor(qh, d); ql += __shfl_xor(ql, d); }
-        if (sub == 0) {
-          const double n = (double)p.gn_cpg * (double)HW;
-          const double mean = dmx_stat_sum(s0) / n;
-          double var = dmx_stat_sumsq(qh, ql) / n - mean * mean;
-          var = var < 0.0 ? 0.0 : var;
-          float* gs = (float*)(smem + L::GST);
-          gs[(b * 16 + gslot) * 2] = (float)mean; gs[(b * 16 + gslot) * 2 + 1] = (float)(1.0 / __builtin_sqrt(var + (double)p.gn_eps));      // (as dmx_gn_apply_kernel: same bits on every path)
-        }
+      for (int k5 = 0; k5 < 5; ++k5) { s0 += r0[k5]; qh += r1[k5]; ql += r2[k5]; }
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) { s0 += __shfl_xor(s0, d); qh += __shfl_xor(qh, d); ql += __shfl_xor(ql, d); }
+      if (sub == 0) {
+        const double n = (double)p.gn_cpg * (double)HW;
+        const double mean = dmx_stat_sum(s0) / n;
+        double var = dmx_stat_sumsq(qh, ql) / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        float* gs = (float*)(smem + L::GST);
+        gs[(b * 16 + gslot) * 2] = (float)mean; gs[(b * 16 + gslot) * 2 + 1] = (float)(1.0 / __builtin_sqrt(var + (double)p.gn_eps));      // (as dmx_gn_apply_kernel: same bits on every path)
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // #0: zero rows + group statistics published; chunk 0 landed (raw)
+  if (gn_any) {
+    coef_tables();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // #0: zero row + group statistics published; chunk 0 landed (raw)
-    if (gn_any) coef_tables();
+    __builtin_amdgcn_s_barrier();                      // #1: the slice's coefficient table published (every lane reads entries other lanes wrote)
+    if (nchunk > 0) normalise(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // #1: the slice's coefficient table published (every loader lane reads entries other lanes wrote)
-    if (gn_any && nchunk > 0) normalise(0, L::BUF0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // #2: chunk 0 ready for the compute waves
+    __builtin_amdgcn_s_barrier();                      // #2: chunk 0 normalised
+  }
+  if (p.timing) tm[1] = __builtin_amdgcn_s_memrealtime();
+  {
+    const int Hm = p.H - 1, Wm = p.W - 1;
+    const unsigned wlane = (unsigned)(lane * 16);
     for (int c = 0; c < nchunk; ++c) {
-      const int nb = ((c + 1) & 1) ? L::BUF1 : L::BUF0;
-      if (c + 1 < nchunk) {                            // (buffer nb was last read in chunk c - 1: every compute wave passed barrier c - 1)
-        stage(c + 1, nb);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (gn_any) normalise(c + 1, nb);              // ... while the compute waves run chunk c
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();                    // c: chunk c + 1 ready; the compute waves are done with chunk c's buffer
-    }
-  } else {
-    // ================================================================= compute waves: stream the weight fragments, nine shifted reads per chunk
-    const int w = wave;
-    const int lr = lane & 31, lh = lane >> 5;
-    const bf16* wbase = p.wp + (size_t)tile * p.frags_per_nb * 512 + lane * 8;
-    // ---- the wave's item table (built once through LDS, then held in registers: lane l keeps entries l, 64 + l, 128 + l).  Entry i = {fragment index,
-    // tap | kk << 4 | chunk << 8}.  Chunk c holds nks x taps items (kk, tap); flattened tap-major (i' = tap nks + kk) the wave takes the contiguous
-    // quarter [n w / 4, n (w + 1) / 4): consecutive items mostly share their tap, so the per-tap address set-up (row of every m-block, masked to the
-    // zero row outside the image) is paid ~3 times per chunk, not per item.  In the loop an entry is one v_readlane away: no memory access at all.
-    unsigned* tab = (unsigned*)(smem + L::TAB + w * (SK_MAX_ITEMS * 8));
-    int n_items = 0;
-    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk && !(DBG && (p.dbg & 2))) stage(c + 1);       // (buffers (c + 1) & 1 were last read in chunk c - 1: every wave passed barrier c - 1)
       const SkinnyChunk ch = PS.ch[c];
       const int taps = p.seg[ch.seg].taps, nks = ch.nks, n = nks * taps;
-      const int lo = (n * w) >> 2, hi = (n * (w + 1)) >> 2;
-      const int ip = lo + lane;
-      if (ip < hi) {
-        int tp = 0, kk = ip;
-        while (kk >= nks) { kk -= nks; ++tp; }           // (tap = i' / nks: at most 8 rounds, once per block)
-        if (taps == 1) tp = 4;
-        const int slot = n_items + lane;
-        tab[2 * slot] = (unsigned)(ch.frag + kk * taps + (taps == 9 ? tp : 0));
-        tab[2 * slot + 1] = (unsigned)tp | ((unsigned)kk << 4) | ((unsigned)c << 8);
-      }
-      n_items += hi - lo;
-    }
-    if (lane < SK_D + 2) { tab[2 * (n_items + lane)] = 0u; tab[2 * (n_items + lane) + 1] = 0xff04u; }     // pad: harmless re-reads of fragment 0; chunk 255 = "no item"
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     // (the wave reads only its own table: no barrier needed)
-    unsigned tf[3], td[3];
+      const int lo = (n * wave) >> 3, hi = (n * (wave + 1)) >> 3;      // this wave's eighth of the chunk's items, flattened tap-major (i' = tap nks + kk)
+      const unsigned abuf = (c & 1) ? L::BUF1 : L::BUF0, wbuf = (c & 1) ? L::WB1 : L::WB0;
+      int tp = 0, kk = lo;
+      while (kk >= nks) { kk -= nks; ++tp; }
+      int cur_tap = -1; unsigned sw = 0; unsigned rowsel[MB];
+      for (int ip = lo; ip < hi; ++ip) {
+        const int tap = taps == 9 ? tp : 4;
+        if (tap != cur_tap) {                            // per-tap set-up: the tap-shifted source row of every m-block (the buffer's zero row outside the image)
+          const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+          const int dlt = (dy << wsh) + dx;
+          sw = (unsigned)(((lr + dlt) >> 1) & 7);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int e = 64 * k + lane;
-      tf[k] = e < SK_MAX_ITEMS ? tab[2 * e] : 0u; td[k] = e < SK_MAX_ITEMS ? tab[2 * e + 1] : 0xff04u;
-    }
-    auto desc_of = [&](int i) -> unsigned {              // wave-uniform i
-      const unsigned a = __builtin_amdgcn_readlane(td[0], i & 63), b = __builtin_amdgcn_readlane(td[1], i & 63), c = __builtin_amdgcn_readlane(td[2], i & 63);
-      return i < 64 ? a : (i < 128 ? b : c);
-    };
-    auto frag_of = [&](int i) -> const bf16* {
-      const unsigned a = __builtin_amdgcn_readlane(tf[0], i & 63), b = __builtin_amdgcn_readlane(tf[1], i & 63), c = __builtin_amdgcn_readlane(tf[2], i & 63);
-      return wbase + (size_t)(i < 64 ? a : (i < 128 ? b : c)) * 512;
-    };
-    u32x4 ring[SK_D];
-#pragma unroll
-    for (int d = 0; d < SK_D; ++d) ring[d] = ld_frag_nt(frag_of(d));
-    // pixel coordinates of this lane's row of every m-block
-    const int Hm = p.H - 1, Wm = p.W - 1;
-    unsigned rowsel[MB];                                 // LDS byte offset of the tap-shifted source row of m-block mb (chunk buffer 0), or the zero row
-    int cur_tap = -1, sw = 0;
-    auto tap_setup = [&](int tp) {                       // wave-uniform tp
-      const int dy = tp / 3 - 1, dx = tp % 3 - 1;
-      const int dlt = (dy << wsh) + dx;
-      sw = (lr + dlt) & 15;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int px = mb * 32 + lr, y = ((px >> wsh) & Hm) + dy, x = (px & Wm) + dx;
-        const bool ok = (unsigned)y <= (unsigned)Hm && (unsigned)x <= (unsigned)Wm;
-        rowsel[mb] = ok ? (unsigned)((px + dlt) * SK_ROWB) : 0x80000000u;
-      }
-      cur_tap = tp;
-    };
-    // LDS fragment reads of one HALF (m-blocks h MB/2 ..) of the item with descriptor dsc.  Hand-scheduled: the reads are inline-asm ds_read_b128 with counted
-    // lgkmcnt waits tied to the registers they fill (hipcc would sink the reads of the NEXT half below the MFMAs of the current one and wait lgkmcnt(0)),
-    // the MFMAs are asm statements too, so the order below is the order in the binary (scripts/isa_audit.py checks the MFMA wait states).
-    constexpr int HB = MB / 2;
-    u32x4 bb[2][HB];
-#pragma unroll
-    for (int m = 0; m < HB; ++m) { bb[0][m] = u32x4{0u, 0u, 0u, 0u}; bb[1][m] = u32x4{0u, 0u, 0u, 0u}; }
-#define SK_DSR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory")
-#ifdef DMX_F16
-#define SK_MFMA(accv, a_, b_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(accv) : "v"(a_), "v"(b_))
-#else
-#define SK_MFMA(accv, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "v"(a_), "v"(b_))
-#endif
-    auto b_issue = [&](unsigned dsc, const int h, u32x4* dst) {
-      const int tp = dsc & 15, kk = (dsc >> 4) & 15, c = (dsc >> 8) & 255;
-      if (tp != cur_tap) tap_setup(tp);
-      const unsigned pc = (unsigned)((c & 1) ? L::BUF1 : L::BUF0) + (unsigned)(((2 * kk + lh) ^ sw) << 4);      // buffer + the swizzled 16-byte piece inside the row
-#pragma unroll
-      for (int m = 0; m < HB; ++m) {
-        const unsigned rs = rowsel[h * HB + m];
-        const unsigned ad = (int)rs >= 0 ? rs + pc : (unsigned)L::ZERO;
-        SK_DSR(dst[m], ad);
-      }
-    };
-    auto wait_half = [&](u32x4* f) {                     // the HB reads issued BEFORE the newest HB reads have landed
-      if constexpr (HB == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
-      else if constexpr (HB == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]), "+v"(f[1]));
-      else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f[0]));
-    };
-    __builtin_amdgcn_s_barrier();                      // #0
-    __builtin_amdgcn_s_barrier();                      // #1
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // #2: chunk 0 staged (and normalised)
-    if (p.timing) tm[1] = __builtin_amdgcn_s_memrealtime();
-    int done_c = 0;                                    // chunks whose closing barrier this wave has taken
-    unsigned dcur = desc_of(0);
-    if (n_items > 0) {
-      const int c0 = (dcur >> 8) & 255;
-      while (done_c < c0) { __builtin_amdgcn_s_barrier(); ++done_c; }
-      b_issue(dcur, 0, bb[0]);
-    }
-    // steady state per item, no data-dependent branch except the rare chunk / tap changes:
-    //   LDS reads of half 1 | wait: weight fragment, half 0 | MFMAs half 0 | next descriptor (readlane) | LDS reads of half 0 of item i + 1 | wait half 1 | MFMAs half 1 | refill the ring
-    for (int i0 = 0; i0 < n_items; i0 += SK_D) {
-#pragma unroll
-      for (int d = 0; d < SK_D; ++d) {
-        const int i = i0 + d;
-        if (i >= n_items) break;
-        if (!(DBG && (p.dbg & 4))) b_issue(dcur, 1, bb[1]);
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring[d]) : "n"(SK_D - 1) : "memory");
-        if (!(DBG && (p.dbg & 4))) wait_half(bb[0]);
-        if (!(DBG && (p.dbg & 1))) {
-#pragma unroll
-          for (int m = 0; m < HB; ++m) SK_MFMA(acc[m], ring[d], bb[0][m]);
+          for (int mb = 0; mb < MB; ++mb) {
+            const int px = mb * 32 + lr, y = ((px >> wsh) & Hm) + dy, x = (px & Wm) + dx;
+            const bool ok = (unsigned)y <= (unsigned)Hm && (unsigned)x <= (unsigned)Wm;
+            rowsel[mb] = abuf + (unsigned)((ok ? px + dlt : M) * SK_ROWB);
+          }
+          cur_tap = tap;
         }
-        const unsigned dnext = desc_of(i + 1);           // (the pad entries make i + 1 and i + SK_D valid indices)
-        const int cn = (dnext >> 8) & 255;
-        if (cn > done_c && cn != 255) {                // the next item lives in a later chunk: this wave is done with the current one (its fragments are in registers)
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          while (done_c < cn) { __builtin_amdgcn_s_barrier(); ++done_c; }
-        }
-        if (!(DBG && (p.dbg & 4))) { b_issue(dnext, 0, bb[0]); wait_half(bb[1]); }      // (behind the last item: a pad descriptor - reads nobody uses)
-        if (!(DBG && (p.dbg & 1))) {
+        const unsigned pos = (unsigned)(kk * taps + (taps == 9 ? tp : 0));
+        const unsigned pc = ((unsigned)(2 * kk + lh) ^ sw) << 4;
+        if (!(DBG && (p.dbg & 4))) {
+          const bf16x8 afrag = *(const bf16x8*)(smem + wbuf + pos * 1024u + wlane);
+          bf16x8 bfr[MB];
 #pragma unroll
-          for (int m = 0; m < HB; ++m) SK_MFMA(acc[HB + m], ring[d], bb[1][m]);
+          for (int mb = 0; mb < MB; ++mb) bfr[mb] = *(const bf16x8*)(smem + rowsel[mb] + pc);
+          if (!(DBG && (p.dbg & 1))) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = DMX_MFMA_32x32x16(afrag, bfr[mb], acc[mb]);
+            // pin the issue order the scheduler would otherwise undo (one read, wait, one MFMA - eight exposed LDS latencies per item): all reads, then the MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, MB + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MB, 0);
+          }
         }
-        if (!(DBG && (p.dbg & 2))) ring[d] = ld_frag_nt(frag_of(i + SK_D));      // (dbg bit 1: measurement aid - no refills)
-        dcur = dnext;
+        if (++kk == nks) { kk = 0; ++tp; }
       }
+      if (c + 1 < nchunk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (gn_any) normalise(c + 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // chunk c + 1 ready; every wave is done with chunk c's buffers
     }
-#undef SK_DSR
-#undef SK_MFMA
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    while (done_c < nchunk) { __builtin_amdgcn_s_barrier(); ++done_c; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetch tail
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (every path from an LDS-DMA request to s_endpgm passes a drain: scripts/isa_audit.py rule L checks the binary)
   }
-
   if (p.timing) tm[2] = __builtin_amdgcn_s_memrealtime();
   // ================================================================= epilogue
   // fold the four compute waves' accumulators through LDS (wave order), publish the [M][32] fp32 tile, finish this block's rows from the S tiles
   float* red = (float*)smem;
-  if (wave < 4) {
-    const int lr = lane & 31, lh = lane >> 5;
-    float* mine = red + (size_t)wave * M * SK_LDT;
+  {
+    // the eight waves' accumulators -> four [M][36] fp32 tiles: waves 0-3 write, then waves 4-7 add theirs to the tile of wave w - 4 (same lanes, same
+    // addresses: tile_w = acc_w + acc_(w+4)); fixed order -> deterministic
+    float* mine = red + (size_t)(wave & 3) * M * SK_LDT;
+    if (wave < 4) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = {acc[mb][4 * g], acc[mb][4 * g + 1], acc[mb][4 * g + 2], acc[mb][4 * g + 3]};
-        *(f32x4*)(mine + (mb * 32 + lr) * SK_LDT + 8 * g + 4 * lh) = v;
-      }
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {acc[mb][4 * g], acc[mb][4 * g + 1], acc[mb][4 * g + 2], acc[mb][4 * g + 3]};
+          *(f32x4*)(mine + (mb * 32 + lr) * SK_LDT + 8 * g + 4 * lh) = v;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 4) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float* q = mine + (mb * 32 + lr) * SK_LDT + 8 * g + 4 * lh;
+          const f32x4 o = *(const f32x4*)q;
+          const f32x4 v = {o[0] + acc[mb][4 * g], o[1] + acc[mb][4 * g + 1], o[2] + acc[mb][4 * g + 2], o[3] + acc[mb][4 * g + 3]};
+          *(f32x4*)q = v;
+        }
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -528,25 +468,20 @@ static int skinny_plan(SkinnyArgs& a) {
   int frag0[4]; { int f = 0; for (int k = 0; k < a.nseg; ++k) { frag0[k] = f; f += (a.seg[k].C / 16) * a.seg[k].taps; } }
   for (int s = 0; s < S; ++s) {
     SkinnyPlanSlice& P = a.plan[s];
-    P.nchunk = 0; P.g_count = 0; P.npiece = 0;
-    int coef = 0, items_q = SK_D + 2;
+    P.nchunk = 0; P.g_count = 0;
+    int coef = 0;
     for (int k = 0; k < a.nseg; ++k) {
       const int nks = a.seg[k].C / 16, lo = nks * s / S, hi = nks * (s + 1) / S;
       P.g_first[k] = 0; P.slot0[k] = 0;
-      if (hi > lo) {
-        SkinnyPiece& pc = P.pc[P.npiece++];
-        pc.n = (hi - lo) * a.seg[k].taps; pc.taps = a.seg[k].taps; pc.frag0 = frag0[k] + lo * a.seg[k].taps; pc.chunk0 = P.nchunk;
-      }
-      for (int k0 = lo; k0 < hi; k0 += 8) {
+      for (int k0 = lo; k0 < hi; k0 += SK_CKS) {
         if (P.nchunk >= SK_MAX_CHUNKS) return DMX_ERR_UNSUPPORTED;
         SkinnyChunk& c = P.ch[P.nchunk++];
-        c.seg = (unsigned char)k; c.k0 = (unsigned short)k0; c.nks = (unsigned char)((hi - k0) < 8 ? (hi - k0) : 8);
+        c.seg = (unsigned char)k; c.k0 = (unsigned short)k0; c.nks = (unsigned char)((hi - k0) < SK_CKS ? (hi - k0) : SK_CKS);
         c.frag = frag0[k] + k0 * a.seg[k].taps;
         c.coef0 = (unsigned short)coef; c.pad_ = 0;
         if (a.seg[k].st) coef += 16 * c.nks;
       }
       if (coef > SK_COEF_CH) return DMX_ERR_UNSUPPORTED;
-      items_q += ((hi - lo) * a.seg[k].taps + 3) / 4 + 1;
       if (a.seg[k].st && hi > lo) {                    // the groups this segment's piece touches get consecutive slots (a group that straddles two sources gets one per source)
         const int g_lo = (a.seg[k].gn_c0 + lo * 16) / a.gn_cpg, g_hi = (a.seg[k].gn_c0 + hi * 16 - 1) / a.gn_cpg;
         if (g_hi > 255 || P.g_count + (g_hi - g_lo + 1) > 16) return DMX_ERR_UNSUPPORTED;
@@ -554,7 +489,6 @@ static int skinny_plan(SkinnyArgs& a) {
         for (int g = g_lo; g <= g_hi; ++g) P.slot_group[P.g_count++] = (unsigned char)g;
       }
     }
-    if (items_q + 12 > SK_MAX_ITEMS) return DMX_ERR_UNSUPPORTED;         // (a wave's quarter of every chunk, rounded up, + the pad)
   }
   return DMX_OK;
 }
@@ -576,9 +510,7 @@ template <int MB, bool DBG> static int skinny_launch_t2(const SkinnyArgs& a, hip
   hipLaunchKernelGGL((dmx_skinny_kernel<MB, DBG>), dim3((a.N / 32) * a.S), dim3(SK_NT), L::TOTAL, stream, a);
   return dmx_check_launch("dmx_skinny_kernel");
 }
-template <int MB> static int skinny_launch_t(const SkinnyArgs& a, hipStream_t stream) {
-  return a.dbg ? skinny_launch_t2<MB, true>(a, stream) : skinny_launch_t2<MB, false>(a, stream);      // (dbg: the measurement-aid instantiation)
-}
+template <int MB> static int skinny_launch_t(const SkinnyArgs& a, hipStream_t stream) { return skinny_launch_t2<MB, true>(a, stream); }
 
 int dmx_skinny_launch(SkinnyArgs a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   DMX_REQUIRE(dmx_skinny_supported(a), "skinny conv: unsupported problem (B=%d H=%d W=%d N=%d segments=%d)", a.B, a.H, a.W, a.N, a.nseg);

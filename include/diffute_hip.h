@@ -209,7 +209,8 @@ int dmx_set_halo_ws(int on);        /* tuning aid: 0 keeps dmx_conv3x3_gn's plan
  * LDS, the GroupNorm (+ SiLU) in front of the conv is applied to the staged chunk from the statistics records of its input(s) (seg.st; NULL = plain input),
  * N / 32 x S blocks ~ one per CU reduce their K slices inside the kernel in slice order (bit-reproducible).  Epilogue: + bias + rowbias[b] + residual, one
  * rounding, optional statistics records of the output.  Needs dmx_set_exclusive_device(1) (the S blocks of a tile wait for each other, bounded: a starved
- * launch raises DMX_ERR_DEVICE).  dmx_set_skinny(0) keeps the model executors on the tiled GEMM (A/B aid); returns the old setting. */
+ * launch raises DMX_ERR_DEVICE).  Round 6: the kernel is correct and exported, but it measures slower than the tiled split-K GEMM + GroupNorm launch it would
+ * replace (EXPERIMENTS.md round 6), so the model executors do NOT take it; dmx_set_skinny is reserved for the day they do (returns the old setting). */
 typedef struct {
   const void* x; int ld;            /* NHWC 16-bit rows = output pixels */
   int C;                            /* channels, multiple of 16 */
