@@ -33,7 +33,7 @@ GEMM_CFGS = [("gemm_128x128x32", "<2, 2, 32, 4, 2, 0, 2, false, 32>"), ("gemm_12
              ("streamk_256x160x64", "<8, 5, 64, 3, 1, 0, 1, true, 32>"), ("retired_13", ""),
              ("streamk_256x128x64", "<8, 4, 64, 3, 1, 0, 1, true, 32>"), ("streamk_256x160x64_mf16", "<4, 5, 64, 3, 4, 0, 2, true, 16>")]
 PROF_CLASSES = ["gemm_128x128_legacy", "gemm_128x64_legacy", "splitk_reduce", "attention_d64", "groupnorm", "layernorm", "other", "gemm_256x128_legacy", "wgrad",
-                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS] + ["xf_chain", "conv3x3_gn_halo"]
+                "gemm_256x128_ws_legacy"] + [n for n, _ in GEMM_CFGS] + ["xf_chain", "conv3x3_gn_halo", "skinny_conv"]
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
@@ -48,6 +48,45 @@ def pmc_traffic(kernel_name):
         if r["kernel"] == kernel_name:
             return float(r["traffic_bytes_per_launch"])
     return None
+
+
+def pmc_l2(kernel_name):
+    """the committed L2-side / wave-state counter row of `kernel_name` (scripts/rocprof_to_profiles.py l2), or None"""
+    import csv
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((os.path.join(here, f) for f in ("r06_pmc_l2.csv",) if os.path.exists(os.path.join(here, f))), None)
+    if path is None:
+        return None
+    for r in csv.DictReader(open(path)):
+        if r["kernel"] == kernel_name:
+            return {k: (float(v) if k != "kernel" else v) for k, v in r.items()}
+    return None
+
+
+L2_PEAK_GBPS = 34500.0          # /opt/skills/guides/MI355X_MICROARCH.md, L2 section
+HBM_ACHIEVABLE_GBPS = 6300.0    # same guide, HBM section
+
+
+def secondary_bound(symbol, avg_launch_us, traffic_bytes):
+    """What bounds the dominant kernel once the MFMA roof is ruled out (roofline.frac well under 1): the L2-side request rate against the L2 peak, the HBM
+    traffic against the achievable HBM rate, and where the waves' cycles went (SQ counters).  The label is the largest of those fractions; when every
+    bandwidth fraction is under one half and the waves sit parked most of the time, the bound is latency (load round trips and block-level barriers), not a pipe."""
+    row = pmc_l2(symbol)
+    if row is None or avg_launch_us <= 0:
+        return None
+    l2_gbps = row["l2_request_bytes_per_launch_at_128B"] / (avg_launch_us * 1e-6) / 1e9
+    hbm_gbps = (traffic_bytes / (avg_launch_us * 1e-6) / 1e9) if traffic_bytes else None
+    fr = {"l2": l2_gbps / L2_PEAK_GBPS, "hbm": (hbm_gbps / HBM_ACHIEVABLE_GBPS) if hbm_gbps else 0.0,
+          "lds": row["lds_issuing_frac_SQ_ACTIVE_INST_LDS"] + row["lds_issue_stall_frac_SQ_WAIT_INST_LDS"]}
+    label = max(fr, key=fr.get)
+    if fr[label] < 0.5 and row["wave_parked_frac_SQ_WAIT_ANY"] > 0.5:
+        label = "latency"
+    return {"label": label, "l2_GBps": round(l2_gbps, 1), "l2_frac_of_peak": round(fr["l2"], 4), "l2_hit_rate": row["l2_hit_rate"],
+            "hbm_GBps": round(hbm_gbps, 1) if hbm_gbps else None, "hbm_frac_of_achievable": round(fr["hbm"], 4),
+            "wave_parked_frac": row["wave_parked_frac_SQ_WAIT_ANY"], "issue_stall_frac": row["issue_stall_frac_SQ_WAIT_INST_ANY"],
+            "issuing_frac": row["issuing_frac_SQ_ACTIVE_INST_ANY"], "lds_issuing_frac": row["lds_issuing_frac_SQ_ACTIVE_INST_LDS"],
+            "lds_bank_conflict_per_lds_cycle": row["lds_bank_conflict_cycles_per_lds_active_cycle"],
+            "source": "profiles/r06_pmc_l2.csv (separate rocprofv3 --pmc passes: TCC_* / TCP_TCC_READ_REQ, SQ_*), rates over this run's live avg_launch_us"}
 
 
 def secondary_configs(dev, unet):
@@ -314,6 +353,7 @@ def main():
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom["symbol"]),
                               "kernel": dom["symbol"],
+                              "secondary_bound": secondary_bound(dom["symbol"], 1e3 * dom["ms_corrected"] / dom["launches"], pmc_traffic(dom["symbol"])),
                               "launches": dom["launches"], "avg_launch_us": round(1e3 * dom["ms_corrected"] / dom["launches"], 2),
                               "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
                               "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),      # activations + weights + output of this symbol's launches: compare with `traffic`

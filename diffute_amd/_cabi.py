@@ -107,6 +107,7 @@ _PROTOS = {
     "dmx_set_skinny": (c_int, [c_int]),
     "dmx_set_halo_conv": (c_int, [c_int]),
     "dmx_set_halo_ws": (c_int, [c_int]),
+    "dmx_set_halo_peers": (c_int, [c_int]),
     "dmx_set_defer_reduce": (c_int, [c_int]),
     "dmx_set_exclusive_device": (c_int, [c_int]),
     "dmx_get_exclusive_device": (c_int, []),

@@ -168,9 +168,22 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
   // (xcd_tile_major: pixel tiles XCD-contiguous, their column tiles / K slices inside - the blocks of an XCD share the ACTIVATION tiles)
   // (no integer divisions in the block decode: hb_div with the host's magic numbers - a scalar division is ~25 instructions through
   // the vector unit, and a dozen of them sat in front of the first DMA request)
-  const int q_nc = hb_div(Lb, p.mg_ncombo), q_tm = hb_div(Lb, p.mg_tiles_m);
-  const int combo = p.xcd_tile_major ? Lb - q_nc * ncombo : q_tm, tile_m = p.xcd_tile_major ? q_nc : Lb - q_tm * tiles_m;
-  const int tile_n = combo >> sshift, r = combo & (S - 1);
+  // (peers_local: the K slice r is the FASTEST index of the decode in both orders, so the S blocks of a tile are neighbours in Lb and sit on one XCD -
+  // their fp32 slabs then change hands inside that XCD's L2; the weights-major order deals (n-tile, pixel tile) pairs instead of (n-tile, slice) combos)
+  int tile_n, tile_m, r;
+  if (p.peers_local && !p.xcd_tile_major) {
+    const int L2i = Lb >> sshift;
+    tile_n = hb_div(L2i, p.mg_tiles_m); tile_m = L2i - tile_n * tiles_m; r = Lb & (S - 1);
+  } else {
+    const int q_nc = hb_div(Lb, p.mg_ncombo), q_tm = hb_div(Lb, p.mg_tiles_m);
+    const int combo = p.xcd_tile_major ? Lb - q_nc * ncombo : q_tm;
+    tile_m = p.xcd_tile_major ? q_nc : Lb - q_tm * tiles_m;
+    tile_n = combo >> sshift; r = combo & (S - 1);
+  }
+  // this block's XCC id + 1, published at once beside the flags; the peers' ids are read in the prologue (xcc_seen) and compared before the slabs are stored
+  const size_t tile_slot = ((size_t)tile_n * tiles_m + tile_m) * S;
+  const int xcc_mine = 1 + (int)(__builtin_amdgcn_s_getreg(6164) & 15);    // hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits)
+  if (S > 1 && p.peers_local && t == 0) __hip_atomic_store(p.flags + nb + tile_slot + r, xcc_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int b = hb_div(tile_m, p.mg_tiles_img), ti = tile_m - b * tiles_img;
   const int tyq = hb_div(ti, p.mg_tiles_x);
   const int ty0 = tyq * TH, tx0 = (ti - tyq * tiles_x) * TW;
@@ -461,6 +474,9 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
     }
   }
   if (TIMING) tp[0] = __builtin_amdgcn_s_memrealtime();
+  // lane s of every wave asks for peer s's XCC word (one request per wave; it lands under the statistics below and the wait for the patch)
+  int xcc_seen = xcc_mine;
+  if (S > 1 && p.peers_local && lane < S) xcc_seen = __hip_atomic_load(p.flags + nb + tile_slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (p.gn && ch_first < nc) {
     // 16 threads per group sum the group's channels' records (integers: exact, any order), then mean / variance in double
     const int g = t >> 4, sub = t & 15;                // (threads 0 .. 511)
@@ -490,6 +506,8 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                        // the group statistics are published (the patch pieces a thread normalises are its own)
   if (TIMING) tp[2] = __builtin_amdgcn_s_memrealtime();
+  // every peer is confirmed on THIS XCD (a peer that had not started yet, or sits elsewhere: the write-through exchange of round 3) - wave-uniform
+  const bool slabs_local = S > 1 && p.peers_local && __builtin_amdgcn_ballot_w64(xcc_seen != xcc_mine) == 0;
   if (cur < nc && p.gn) {
     coef_table(cur);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -803,16 +821,28 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
   constexpr int LDT = L::LDT, OCP = L::OCP, RL = L::RL;
   const int RO = 256 / S, own0 = r * RO;
   const size_t slab_elems = (size_t)256 * BN;
-  const size_t tile_slot = ((size_t)tile_n * tiles_m + tile_m) * S;
   if (S > 1) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slabs + (tile_slot + r) * slab_elems), 0, (int)(slab_elems * 4), 0x00020000);
+    // peers on this XCD: PLAIN stores - the lines stay in the XCD's L2, where the peers' sc1 loads (L1 bypassed, L2 served) find them; otherwise
+    // write-through (sc1) stores, which reach memory and drop the line (MI355X_MICROARCH.md, "stores of each flavour")
+    if (slabs_local) {
 #pragma unroll
-    for (int i = 0; i < MFR; ++i) {
-      const int row0 = wm * (16 * MFR) + i * 16;
-      if (row0 / RO == r || (WS && wave >= NCW)) continue;   // wave-uniform (the loader waves hold no accumulators)
+      for (int i = 0; i < MFR; ++i) {
+        const int row0 = wm * (16 * MFR) + i * 16;
+        if (row0 / RO == r || (WS && wave >= NCW)) continue;   // wave-uniform (the loader waves hold no accumulators)
 #pragma unroll
-      for (int j = 0; j < NF; ++j)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), rs, ((row0 + lr) * BN + wn * 16 * NF + j * 16 + 4 * lq) * 4, 0, 16);
+        for (int j = 0; j < NF; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), rs, ((row0 + lr) * BN + wn * 16 * NF + j * 16 + 4 * lq) * 4, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MFR; ++i) {
+        const int row0 = wm * (16 * MFR) + i * 16;
+        if (row0 / RO == r || (WS && wave >= NCW)) continue;
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), rs, ((row0 + lr) * BN + wn * 16 * NF + j * 16 + 4 * lq) * 4, 0, 16);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through (sc1) stores drained -> block barrier -> flag (relaxed, agent scope)
     __syncthreads();
@@ -857,6 +887,13 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
             // sc1 loads of the write-through slabs: served by L2 / the fabric, no agent-scope acquire needed (gemm.hip stream-K)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slabs + (tile_slot + s) * slab_elems), 0, (int)(slab_elems * 4), 0x00020000);
             const int off = (pp * BN + o * 8) * 4;
+#ifdef HB_LOCAL_AUX
+            if (slabs_local) {
+              pv[u][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, HB_LOCAL_AUX));
+              pv[u][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, HB_LOCAL_AUX));
+              continue;
+            }
+#endif
             pv[u][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
             pv[u][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16));
           }
@@ -937,6 +974,8 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (TIMING) tm[4] = __builtin_amdgcn_s_memrealtime();
+    // (the slab loads are sc1 in both exchange modes: L1 bypassed, served by the XCD's L2 where the peers left the lines there, by the fabric otherwise.
+    // nt / sc0 / plain loads of L2-resident slabs measured no faster - EXPERIMENTS.md round 6)
     if (S == 2) items(std::integral_constant<int, 2>{}, std::integral_constant<int, PP ? KPP : (WS ? (KPP + 1) / 2 : 1)>{}, own0);
     else if (S == 4) items(std::integral_constant<int, 4>{}, std::integral_constant<int, PP ? (KPP + 1) / 2 : (WS ? 2 : 1)>{}, own0);
     else if constexpr (PP || WS) items(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, own0);      // (8-way splits: 8-wave instances only - the plan sees to it)
@@ -973,7 +1012,7 @@ __global__ __launch_bounds__((HaloLds<NF, WMW, WNW, WS>::NT), ((HaloLds<NF, WMW,
     tm[5] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int i = 0; i < 7; ++i) o_[i] = tm[i];
-    o_[7] = se - sb;
+    o_[7] = (long long)(se - sb) | ((long long)(slabs_local ? 1 : 0) << 32) | ((long long)xcc_mine << 40) | ((long long)r << 48);      // (taps of the slice | exchange through L2 | XCC id + 1 | slice)
   }
 }
 
@@ -1026,6 +1065,7 @@ __global__ __launch_bounds__(512) void dmx_colstats_kernel(const bf16* x, int ld
 // slabs through memory ((S - 1) / S x 256 x BN x 4 bytes per block, written and read back) and the co-residency of a tile's blocks, so the
 // plan takes the narrow tiles where they make the split unnecessary or smaller; with tiles to spare the wide tile wins (twice the work per
 // weight byte and per barrier).  Costs in us, fitted on scripts/attic/halo_probe.py.
+int g_halo_peers = 1;
 int g_halo_ws = 1;                                     // dmx_set_halo_ws: 0 = the planner never takes the warp-specialised instances (A/B aid)
 struct HaloPlan { int TH, TW, nf, wmw, bn, splits, waves; };
 HaloPlan halo_plan(const HaloConvArgs& a) {
@@ -1078,6 +1118,8 @@ HaloPlan halo_plan(const HaloConvArgs& a) {
 // Measured per shape inside the 50-step pass (B = 4; halo incl. GroupNorm vs conv + reduce + GroupNorm): 64x64 level 61 vs 69, 87 vs 105,
 // 119 vs 129 us; 32x32 level 63 vs 66, 89 vs 98, 124 vs 125; 16x16 level 64 vs 61, 85 vs 77, 48 vs 44 - the blocks of the deep levels
 // are 8-way K splits whose fp32 slab exchange costs what the fusion saves.
+// dmx_set_halo_peers: 0 = round-5 dealing and write-through slabs everywhere (A/B and the tests' second opinion); 1 = a tile's K-split peers on one XCD
+extern "C" int dmx_set_halo_peers(int on) { const int old = g_halo_peers; g_halo_peers = on ? 1 : 0; dmx_plan_switch(DMX_SW_HALO_PEERS, g_halo_peers); return old; }
 extern "C" int dmx_set_halo_ws(int on) { const int old = g_halo_ws; g_halo_ws = on; dmx_plan_switch(DMX_SW_HALO_WS, on); return old; }
 // ONE place for "could a fused GroupNorm -> conv launch consume statistics records of an H x W tensor": the tile geometries of halo_plan and the
 // level rule of dmx_conv_halo_pays.  The executors ask this before they spend a statistics pass / a statistics epilogue on a tensor
@@ -1114,12 +1156,13 @@ static long halo_blocks(const HaloConvArgs& a, const HaloPlan& P) {
   return (long)a.B * (a.H / P.TH) * (a.W / P.TW) * (a.N / P.bn) * P.splits;
 }
 
+// one completion flag per block + one XCC-id word per block (peers_local)
 int dmx_conv_halo_flag_count(const HaloConvArgs& a) {
   const HaloPlan P = halo_plan(a);
-  return P.splits > 1 ? (int)halo_blocks(a, P) : 0;
+  return P.splits > 1 ? 2 * (int)halo_blocks(a, P) : 0;
 }
 
-static size_t halo_flag_bytes(int n) { return align_up((size_t)n * sizeof(int), 256); }
+static size_t halo_flag_bytes(int n) { return align_up((size_t)2 * n * sizeof(int), 256); }
 
 size_t dmx_conv_halo_workspace_bytes(const HaloConvArgs& a) {
   const HaloPlan P = halo_plan(a);
@@ -1165,6 +1208,8 @@ int dmx_conv_halo_launch(HaloConvArgs a, void* workspace, size_t workspace_bytes
     // weights-major: every XCD reads its combos' weights once, the activations combos / 8 .. combos times; tile-major: the reverse
     a.xcd_tile_major = (abytes * (combos >= 8 ? combos / 8.0 : 1.0) + wbytes > abytes + wbytes * 8.0) ? 1 : 0;
   }
+  // the S blocks of a tile on one XCD: r is the fastest index of the decode and an XCD's share of the grid (blocks / 8 consecutive Lb) holds whole tiles
+  a.peers_local = (g_halo_peers && a.splits > 1 && blocks % 8 == 0 && (blocks / 8) % a.splits == 0) ? 1 : 0;
   if (a.splits > 1) {
     const size_t fb = halo_flag_bytes(blocks), need = fb + (size_t)blocks * 256 * P.bn * sizeof(float);
     if (!workspace || workspace_bytes < need) { dmx_set_error("conv_halo: the K split needs %zu bytes of workspace, got %zu", need, workspace_bytes); return DMX_ERR_WORKSPACE; }

@@ -159,6 +159,10 @@ class Exec {
       if (pend_[t.pend].wsp) ws.release(pend_[t.pend].wsp);
       pend_[t.pend].wsp = nullptr; pend_[t.pend].done = true;
     }
+    // t may be the RESIDUAL a still pending reduce pass has to add (conv2 of a resnet whose input dies before the next block's GroupNorm runs): that
+    // pass runs now, while t's memory is still t's.  (Offsets compare equal in the dry walk too: the same allocator decides both walks.)
+    for (size_t i = 0; i < pend_.size(); ++i)
+      if (!pend_[i].done && pend_[i].a.res && (const void*)pend_[i].a.res == (const void*)t.p) { Tn q; q.pend = (int)i; flush(q); }
     drop((const void*)t.p);
   }
 

@@ -63,7 +63,7 @@ int dmx_check_launch(const char* what) {
 // hash of the values is part of the key of the captured hipGraphs (unet_model.h GraphKey) and of the host mirror's workspace-size cache, so toggling
 // a switch after the first forward can neither replay a graph captured under another setting nor run a walk in a workspace sized for another one -
 // and switching BACK finds the graphs of the old setting again (a counter would strand them).
-static int g_plan_sw[DMX_SW_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1};      // the defaults of the switches, in DmxPlanSwitch order
+static int g_plan_sw[DMX_SW_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1, 1};      // the defaults of the switches, in DmxPlanSwitch order
 void dmx_plan_switch(int slot, int value) { if (slot >= 0 && slot < DMX_SW_COUNT) g_plan_sw[slot] = value; }
 void dmx_plan_epoch_bump() { ++g_plan_sw[DMX_SW_OVERRIDES]; }
 extern "C" int dmx_plan_epoch(void) {
@@ -348,6 +348,7 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
                                     gamma, beta, eps, silu ? 1 : 0, (float*)y.p, y.ld, stream);
     return y;
   }
+  if (x1) flush(*x1);                                  // (only x0 can hand its reduce pass to this GroupNorm)
   if (x0.cst && (!x1 || x1->cst)) {                    // statistics came with the tensor(s): one apply-only launch
     flush(x0);
     if (!dry && !rc) {
@@ -397,6 +398,8 @@ Tn Exec::groupnorm(const Tn& x0, const Tn* x1, const float* gamma, const float* 
 }
 
 Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpts& o, void* f32_out) {
+  // a source whose split-K reduce pass is still pending (ConvOpts.defer of ITS producer: the promised GroupNorm did not come first) is completed now
+  flush(x0); if (x1) flush(*x1); if (o.sc0) flush(*o.sc0); if (o.sc1) flush(*o.sc1); if (o.res) flush(*o.res);
   int OH = x0.H, OW = x0.W;
   if (o.ups) { OH *= 2; OW *= 2; }
   if (o.stride > 1) { OH /= o.stride; OW /= o.stride; }          // (2 in the UNet / autoencoder; the ViT patch conv of the fp32 path: patch size)
@@ -489,7 +492,7 @@ Tn Exec::conv_gn(const Tn& x0, const Tn* x1, const float* gamma, const float* be
     drop(t);
     return y;
   }
-  flush(x0);
+  flush(x0); if (x1) flush(*x1); if (o.sc0) flush(*o.sc0); if (o.sc1) flush(*o.sc1); if (o.res) flush(*o.res);
   Tn y = make(x0.B, x0.H, x0.W, Cout);
   a.out = y.p;
   if (o.stats && g_gn_producer_stats) { a.colstats = stat_slice(x0.B, Cout); y.cst = a.colstats; }
@@ -514,6 +517,7 @@ Tn Exec::conv_gn(const Tn& x0, const Tn* x1, const float* gamma, const float* be
 
 Tn Exec::linear(const Tn& x, const bf16* w, int N, const float* bias, const Tn* res, bool geglu,
                 RowStats* rowstats, const LnIn* ln, bool gn_stats) {
+  flush(x); if (res) flush(*res);
   const int Nout = geglu ? N / 2 : N;
   Tn y = make(x.B, x.H, x.W, Nout);
   if (f32) {                                           // (the folded-LayerNorm / row-statistics protocol is a bf16-path fusion: callers normalise explicitly)
@@ -556,6 +560,7 @@ void Exec::gemm_raw(const bf16* x, int ldx, int M, const bf16* w, int ldw, int N
 }
 
 Tn Exec::linear_gelu(const Tn& x, const bf16* w, int N, const float* bias) {
+  flush(x);
   Tn y = make(x.B, x.H, x.W, N);
   if (f32) {
     GemmF32Args a{};
@@ -577,6 +582,7 @@ Tn Exec::linear_gelu(const Tn& x, const bf16* w, int N, const float* bias) {
 }
 
 Tn Exec::layernorm(const Tn& x, const float* gamma, const float* beta, float eps) {
+  flush(x);
   Tn y = make(x.B, x.H, x.W, x.C);
   if (f32) {
     if (!dry && !rc) rc = dmx_layernorm_f32_launch((const float*)x.p, x.ld, (float*)y.p, y.ld, gamma, beta, x.rows(), x.C, eps, stream);
@@ -646,6 +652,7 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
 
 void Exec::tap(const Tn& t) {
   if (!taps) return;
+  flush(t);
   if (dry || rc) return;
   const size_t n = (size_t)t.rows() * t.C;
   if (taps->n >= 16) return;                           // (only reachable with the DMX_TAPS_FINE debugging switch)
@@ -699,6 +706,8 @@ Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn
   if (r.temb_off >= 0 && tproj) { o1.rowbias = tproj + r.temb_off; o1.ldrb = tproj_total; }
   Tn t2 = ex.conv_gn(x0, x1, F(r.n1g), F(r.n1b), groups, eps, H(r.w1), r.cout, o1);
   ConvOpts o2; o2.bias = F(r.b2); o2.stats = 1;        // a GroupNorm comes next in every graph (next resnet / transformer / out norm)
+  o2.defer = 1;                                        // ... and where it reads y as its x0 FIRST, a split-K conv2 leaves its reduce pass to it (any other first
+                                                       // consumer - down / up-sampling conv, tap, linear - completes the tensor itself: Exec::flush in each of them)
   if (ex.f32 && r.shortcut) { o2.bias = F(r.b2raw); o2.bias2 = F(r.bscraw); }     // the folded bias is derived data: not in the master arena
   if (r.shortcut) { o2.sc0 = &x0; o2.sc1 = x1; } else { o2.res = &x0; }
   Tn y = ex.conv_gn(t2, nullptr, F(r.n2g), F(r.n2b), groups, eps, H(r.w2), r.cout, o2);

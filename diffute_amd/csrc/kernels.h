@@ -10,7 +10,7 @@ enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN =
                  PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_HALO = 27 /* conv_halo.hip */, PROF_SKINNY = 28 /* skinny.hip */, PROF_NCLASS = 29 };
 int n_cus();                                           // compute units of the CURRENT device (conv_halo.hip)
 // exec.hip: the plan signature (key of captured graphs / cached workspace sizes): every plan-changing switch records its value
-enum DmxPlanSwitch { DMX_SW_EXCLUSIVE = 0, DMX_SW_GN_STATS, DMX_SW_DEFER, DMX_SW_HALO, DMX_SW_PREFETCH, DMX_SW_XF_CHAIN, DMX_SW_HALO_WS, DMX_SW_OVERRIDES, DMX_SW_SKINNY, DMX_SW_COUNT };
+enum DmxPlanSwitch { DMX_SW_EXCLUSIVE = 0, DMX_SW_GN_STATS, DMX_SW_DEFER, DMX_SW_HALO, DMX_SW_PREFETCH, DMX_SW_XF_CHAIN, DMX_SW_HALO_WS, DMX_SW_OVERRIDES, DMX_SW_SKINNY, DMX_SW_HALO_PEERS, DMX_SW_COUNT };
 void dmx_plan_switch(int slot, int value);
 void dmx_plan_epoch_bump();                            // (dmx_gemm_plan_override: a counter)
 extern "C" int dmx_plan_epoch(void);
@@ -112,6 +112,8 @@ struct HaloConvArgs {
   const void* pf[2]; int pf_bytes[2];                // optional: byte ranges (the next launches' weights) the blocks touch at their start (Exec::peek)
   // filled by the launcher
   int TH, TW, splits, xcd_tile_major; float* slabs; int* flags; const bf16* zeros; int* err;      // err: dmx_dev_err_words() (set by the launcher)
+  int peers_local;          // launcher: 1 = the S blocks of a tile are dealt to ONE XCD (r fastest in the block decode) and may exchange their slabs through that
+                            // XCD's L2 (plain stores) once every peer has confirmed its XCC id (words flags[blocks ..)); 0 = round-5 dealing, write-through always
   // (the block decode of the kernel without integer divisions: x / d = (x * magic) >> 32 for the dividends that occur, all < 2^20)
   int tiles_x, tiles_img, tiles_m, ncombo, cpg;
   unsigned mg_tiles_x, mg_tiles_img, mg_tiles_m, mg_ncombo, mg_pw, mg_cpg;

@@ -292,6 +292,7 @@ struct Fwd {
     const bool chain = ex.chain_ok(x);     // C = 320 levels: the per-row GEMM chains around the two attention cores are three kernels (xf_chain.hip)
     // the entry GroupNorm rides in the first chain's operand load when x came with its statistics records (xf_chain.hip mode 2)
     const bool gn_fold = chain && ex.chain_gn_fold(x);
+    if (gn_fold) ex.flush(x);                // (the chains read x through raw pointers; the GroupNorm below completes a pending x itself)
     Tn t = gn_fold ? x : ex.groupnorm(x, nullptr, u->at<float>(w.ng), u->at<float>(w.nb), G, 1e-6f, false);
     // LayerNorms are folded: each residual-stream producer also emits per-row (sum, sumsq) partials and the
     // consuming GEMM multiplies the raw rows by W*gamma and normalises in its epilogue - no LN kernels, no LN tensors.
@@ -517,15 +518,18 @@ int unet_run(dmx_unet* u, Exec& ex, const float* f0, int c0, const float* f1, in
     }
     ex.tap(h);                                         // "down{i}"
   }
+  Tn mid_in;
   { Tn y = f.resnet(u->mid_res[0], h, nullptr);          // h is also skips.back(): keep it
     Tn z = f.xformer(u->mid_xf, y); ex.drop(y);
     ex.ensure_stats(z);
-    h = f.resnet(u->mid_res[1], z, nullptr); ex.drop(z); }
+    h = f.resnet(u->mid_res[1], z, nullptr); mid_in = z; }
   ex.tap(h);                                           // "mid"
   for (int i = 0; i < 4; ++i) {
     for (int j = 0; j < L + 1; ++j) {
       Tn s = skips.back(); skips.pop_back();
       Tn y = f.resnet(u->up_res[i][j], h, &s);
+      // (z is the residual of mid_res[1]'s conv2: where that conv left its split-K reduce to the GroupNorm that has just run, z had to live until here)
+      if (i == 0 && j == 0) ex.drop(mid_in);
       ex.drop(h); ex.drop(s);
       if (cfg.up_has_attn[i]) { Tn z = f.xformer(u->up_xf[i][j], y); ex.drop(y); y = z; }
       ex.ensure_stats(y);

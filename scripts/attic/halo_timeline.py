@@ -1,14 +1,15 @@
 """Per-block phase timeline of the halo conv (HaloConvArgs.timing): prologue / K loop / publish / wait / epilogue, in us.
     python scripts/halo_timeline.py [B H W C0 C1 N Csc] [--split S] [--dbg D]"""
 import argparse, math, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from diffute_amd import ops
+from diffute_amd import ops, _cabi
 ap = argparse.ArgumentParser(); ap.add_argument("shape", nargs="*", type=int, default=[4, 64, 64, 320, 0, 320, 0])
-ap.add_argument("--split", type=int, default=0); ap.add_argument("--bn", type=int, default=0); ap.add_argument("--dbg", type=int, default=0); ap.add_argument("--waves", type=int, default=0); ap.add_argument("--nogn", action="store_true")
+ap.add_argument("--split", type=int, default=0); ap.add_argument("--bn", type=int, default=0); ap.add_argument("--dbg", type=int, default=0); ap.add_argument("--waves", type=int, default=0); ap.add_argument("--nogn", action="store_true"); ap.add_argument("--peers", type=int, default=1)
 a = ap.parse_args()
 B, H, W, C0, C1, N, Csc = a.shape
 dev = torch.device("cuda:0")
+_cabi.lib().dmx_set_halo_peers(a.peers)
 Cin = C0 + C1; K = 9 * Cin + Csc
 x0 = torch.randn(B, H, W, C0, device=dev).to(torch.bfloat16)
 x1 = torch.randn(B, H, W, C1, device=dev).to(torch.bfloat16) if C1 else None
@@ -25,6 +26,10 @@ for i in range(3): ops.conv3x3_gn(x0, w, N, **kw)
 ops.conv3x3_gn(x0, w, N, timing=tm, **kw)
 torch.cuda.synchronize()
 tall = tm.cpu()
+word7 = tall[:4096, 7].clone()
+tall[:4096, 7] = word7 & 0xffffffff                 # taps of the block's slice; above: exchange through L2 | XCC id + 1 | slice
+live = tall[:4096, 0] > 0
+print(f"peers={a.peers}: blocks exchanging through their XCD's L2: {int(((word7[live] >> 32) & 1).sum())} of {int(live.sum())}; XCC ids seen: {sorted(set((((word7[live] >> 40) & 0xff) - 1).tolist()))}")
 ph8 = tall[4096:].reshape(-1, 2, 8)
 ph = ph8[:, :, :5].double()
 t = tall[:4096]

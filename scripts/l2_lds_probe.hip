@@ -1,7 +1,7 @@
 // Measurement aid: per-CU LDS-DMA (global_load_lds, 16 B per lane) throughput as a function of the bytes kept in flight,
 // for (a) a weight stream SHARED by all blocks (L2-resident after the first block: the fused transformer tail's pattern) and
 // (b) a private stream per block (HBM / MALL).  No compute; 256 blocks x 512 threads, one block per CU.
-//   hipcc --offload-arch=gfx950 -O3 -o dma_depth_probe dma_depth_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/l2_lds_probe scripts/l2_lds_probe.hip && /tmp/l2_lds_probe > profiles/rNN_l2_lds_probe.txt   (the "shared" rows are the L2 -> LDS ceiling bench.py prices roofline.secondary_bound against)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>

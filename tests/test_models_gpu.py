@@ -1168,7 +1168,10 @@ def test_profile_by_kernel_symbol(cuda):
 def test_deferred_splitk_reduce_is_bit_identical(cuda):
     """ConvOpts.defer (exec.hip): at the 16x16 / 8x8 levels conv1 of a resnet is a split-K GEMM; its reduce pass is left to norm2, whose slab kernel sums
     the partial planes in its load stage (norm.hip GroupNormArgs.red_*) with the arithmetic of dmx_splitk_reduce_kernel - the same bits, one launch
-    less.  Full-size UNet, batch 4 and batch 1, and the tiny config, with the switch on and off."""
+    less.  conv2 does the same ACROSS blocks: its reduce pass rides in the next block's norm1 (resnet_run sets ConvOpts.defer; every other first consumer
+    flushes).  Full-size UNet, batch 4 and batch 1, and the tiny config, with the switch on and off; at full size the deferral must actually happen:
+    fewer launches of the reduce kernel (profile class 2) with the switch on."""
+    import ctypes
     import diffute_amd as D
     from diffute_amd import _cabi
     from diffute_amd.synthetic import synth_inputs
@@ -1186,12 +1189,24 @@ def test_deferred_splitk_reduce_is_bit_identical(cuda):
         for unet, shp in ((full, (4, 64, 64, 577, 1024)), (full, (1, 64, 64, 577, 1024)), (tiny, (2, 16, 16, 77, 128)), (tiny, (3, 8, 24, 40, 128))):
             lat, mask, mlat, ctx = synth_inputs(*shp, device=cuda)
             unet.set_context(ctx)
-            outs = {}
+            outs, reduces = {}, {}
             for on in (1, 0, 1):
                 lib.dmx_set_defer_reduce(on)
                 outs.setdefault(on, []).append(fwd(unet, [lat, mask, mlat], t))
+                torch.cuda.synchronize()
+                lib.dmx_profile_begin()                      # (bracketed walk: launches per kernel class)
+                prof = unet.forward_parts([lat, mask, mlat], t).clone()
+                buf = (ctypes.c_double * (4 * 32))()
+                _cabi.check(lib.dmx_profile_end(buf, len(buf)), "profile_end")
+                assert torch.equal(prof, outs[on][-1])
+                reduces[on] = int(buf[4 * 2])
             torch.cuda.synchronize()
             assert torch.isfinite(outs[1][0]).all()
             assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][0], outs[1][1]), f"deferred reduce changes the result at {shp}"
+            if unet is full:
+                # split-K resnet convs exist at full size (8x8 level: 6 conv1 + 6 conv2 at least); with the switch on, only a conv whose first consumer
+                # is not a GroupNorm keeps its own reduce launch
+                print(f"splitk_reduce launches at {shp[:3]}: {reduces[0]} without deferral, {reduces[1]} with")
+                assert reduces[0] >= 8 and reduces[1] <= reduces[0] - 8, reduces
     finally:
         lib.dmx_set_defer_reduce(1)

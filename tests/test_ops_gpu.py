@@ -722,12 +722,53 @@ def test_conv3x3_gn_halo(cuda, case):
     assert float(((q_hip - q_ref).abs() / q_ref).max()) <= 1e-5, f"{name}: channel sums of squares of the output"
     out2, st2 = ops.conv3x3_gn(X0, W_, N, **kw)
     assert torch.equal(out, out2) and torch.equal(st, st2), f"{name}: not bit-reproducible"
+    # the K-split peers of a tile on one XCD exchanging through its L2 (default) against the round-5 dealing with write-through slabs: same K order, same bits
+    from diffute_amd import _cabi
+    old_peers = _cabi.lib().dmx_set_halo_peers(0)
+    try:
+        out3, st3 = ops.conv3x3_gn(X0, W_, N, **kw)
+    finally:
+        _cabi.lib().dmx_set_halo_peers(old_peers)
+    assert torch.equal(out, out3) and torch.equal(st, st3), f"{name}: XCD-local slab exchange changes the result"
     if gn:
         # against the unfused HIP path: GroupNorm kernel, then the implicit-GEMM conv
         t = ops.groupnorm(X0, g.to(cuda), be.to(cuda), 32, 1e-5, True, x1=X1)
         old = ops.conv_gemm(t, W_, N, bias=b.to(cuda), rowbias=temb.to(cuda).contiguous(), res=None if S0 else nhwc(r, cuda),
                             sc0=kw.get("sc0"), sc1=kw.get("sc1"))
         assert_close(nchw(out), nchw(old).float(), 2e-3, f"{name}: vs GroupNorm + implicit-GEMM conv")
+
+
+def test_conv3x3_gn_halo_peers_under_uneven_load(cuda):
+    """The XCD-local slab exchange (conv_halo.hip peers_local: plain stores into the XCD's L2, flag, sc1 loads) at the two shapes that carry it in the
+    headline pass (64x64 x 320, two-way split; 32x32 x 640, four-way split), 12 launches each while a side stream keeps 16 CUs busy in bursts (uneven
+    load: some tiles' peers start late, some blocks share their CU's L1 with an earlier tile's slabs) - every word equal to the write-through result."""
+    import time
+    from diffute_amd import ops, _cabi
+    lib = _cabi.lib()
+    side = torch.cuda.Stream(device=cuda)
+    for (B, H, W, C, N, split) in ((4, 64, 64, 320, 320, 2), (4, 32, 32, 640, 640, 4)):
+        x = bf(seeded((B, C, H, W), 21) * 1.2 + 0.1)
+        w = bf(seeded((N, C, 3, 3), 22, 1 / math.sqrt(9 * C))); b = seeded((N,), 23, 0.1)
+        g = 1 + 0.1 * seeded((C,), 24); be = 0.1 * seeded((C,), 25)
+        r = bf(seeded((B, N, H, W), 26))
+        X = nhwc(x, cuda); W_ = ops.pack_conv_weight(w.to(cuda))
+        kw = dict(bias=b.to(cuda), res=nhwc(r, cuda), force_split=split, out_stats=True, gn=(g.to(cuda), be.to(cuda), 32, 1e-5, True), st0=ops.colstats(X))
+        old_peers = lib.dmx_set_halo_peers(0)
+        try:
+            ref, st_ref = ops.conv3x3_gn(X, W_, N, **kw)
+            ref, st_ref = ref.clone(), st_ref.clone()
+        finally:
+            lib.dmx_set_halo_peers(old_peers)
+        torch.cuda.synchronize()
+        for it in range(12):
+            with torch.cuda.stream(side):
+                _cabi.check(lib.dmx_test_occupy_cus(16, 100_000 + 40_000 * (it % 3), _cabi.current_stream()), "occupy")      # 1 - 1.8 ms bursts
+            if it % 2:
+                time.sleep(0.0005)
+            out, st = ops.conv3x3_gn(X, W_, N, **kw)
+            torch.cuda.synchronize()
+            _cabi.poll_device_error()
+            assert torch.equal(out, ref) and torch.equal(st, st_ref), f"{H}x{W} split {split}, launch {it}: XCD-local exchange differs from write-through"
 
 
 def test_statistics_records_large_magnitudes(cuda):
