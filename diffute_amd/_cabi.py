@@ -108,6 +108,10 @@ _PROTOS = {
     "dmx_set_halo_conv": (c_int, [c_int]),
     "dmx_set_halo_ws": (c_int, [c_int]),
     "dmx_set_halo_peers": (c_int, [c_int]),
+    "dmx_set_attn_balanced": (c_int, [c_int]),
+    "dmx_attention_fwd_v_balanced_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dmx_attention_fwd_v_balanced": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                             c_void_p, c_size_t, c_void_p]),
     "dmx_set_defer_reduce": (c_int, [c_int]),
     "dmx_set_exclusive_device": (c_int, [c_int]),
     "dmx_get_exclusive_device": (c_int, []),

@@ -252,6 +252,31 @@ extern "C" int dmx_attention_fwd_v(const void* q, int ldq, const void* k, int ld
   a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
   return dmx_attention_launch(a, (hipStream_t)stream);
 }
+// K5 with the balanced schedule (attention_sk.hip): workspace = dmx_attention_fwd_v_balanced_workspace_bytes (0: the plan keeps the plain grid for this
+// problem - dmx_set_attn_balanced(2) plans it wherever the kernel takes the problem); flags zeroed here
+static size_t attn_bal_flag_bytes(int slots) { return align_up((size_t)slots * sizeof(int), 256); }
+extern "C" size_t dmx_attention_fwd_v_balanced_workspace_bytes(int B, int H, int Sq, int Skv) {
+  AttnArgs a{};
+  a.v = (const bf16*)8; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv;
+  const int ns = dmx_attention_balanced_slots(a);
+  return ns ? attn_bal_flag_bytes(ns) + dmx_attention_balanced_part_bytes(a) : 0;
+}
+extern "C" int dmx_attention_fwd_v_balanced(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                                            void* o, int ldo, int B, int H, int Sq, int Skv, float scale,
+                                            void* workspace, size_t workspace_bytes, dmx_stream_t stream) {
+  DMX_REQUIRE(q && k && v && o && workspace, "attention (balanced): null argument");
+  AttnArgs a{};
+  a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.kv_rows = kv_rows;
+  a.v = (const bf16*)v; a.ldv = ldv; a.o = (bf16*)o; a.ldo = ldo;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  const int ns = dmx_attention_balanced_slots(a);
+  DMX_REQUIRE(ns > 0, "attention (balanced): the plan keeps the plain grid for B=%d H=%d Sq=%d Skv=%d (dmx_attention_fwd_v)", B, H, Sq, Skv);
+  const size_t fb = attn_bal_flag_bytes(ns), need = fb + dmx_attention_balanced_part_bytes(a);
+  if (workspace_bytes < need) { dmx_set_error("attention (balanced): workspace %zu < %zu bytes", workspace_bytes, need); return DMX_ERR_WORKSPACE; }
+  a.sk_flags = (int*)workspace; a.sk_part = (float*)((char*)workspace + fb);
+  if (const int zr = dmx_zero16_launch(a.sk_flags, fb, (hipStream_t)stream)) return zr;
+  return dmx_attention_balanced_launch(a, (hipStream_t)stream);
+}
 extern "C" int dmx_attention_fwd_train(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
                                        void* o, int ldo, float* lse, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream) {
   DMX_REQUIRE(q && k && v && o && lse, "attention_fwd_train: null argument");

@@ -44,7 +44,7 @@ int dmx_check_launch(const char* what);
 // bounded in-kernel wait RAISES here (first raiser wins) and goes on, so the GPU never hangs; every later launch check (dmx_check_launch),
 // hipGraph replay and dmx_device_error() reads word 0 from the host side - no synchronisation - and returns DMX_ERR_DEVICE with the
 // detail in dmx_last_error().  The failing launch itself has returned by then: the error surfaces at the NEXT C-ABI call or poll.
-enum DmxDevKernel { DMX_DEVK_HALO_PEER = 1, DMX_DEVK_STREAMK_HELPER = 2, DMX_DEVK_SKINNY_PEER = 3 };
+enum DmxDevKernel { DMX_DEVK_HALO_PEER = 1, DMX_DEVK_STREAMK_HELPER = 2, DMX_DEVK_SKINNY_PEER = 3, DMX_DEVK_ATTN_PEER = 4 };
 int* dmx_dev_err_words();              // device-visible pointer (nullptr when the pinned allocation failed: kernels then do not raise)
 int dmx_poll_device_error();           // DMX_OK, or DMX_ERR_DEVICE + dmx_set_error(...) and the words cleared
 #ifdef __HIPCC__

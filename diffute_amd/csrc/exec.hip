@@ -34,6 +34,9 @@ int dmx_poll_device_error() {
   else if (k == DMX_DEVK_SKINNY_PEER)
     dmx_set_error("device error: weight-streaming conv (skinny.hip) block %d gave up after 40 ms waiting for the partial tile of K slice %d of output tile %d (slices %d) - "
                   "the blocks of a tile were not co-resident (CUs taken by another stream?); the result of that launch is invalid", blk, d1, d0, d2);
+  else if (k == DMX_DEVK_ATTN_PEER)
+    dmx_set_error("device error: attention (balanced schedule) slot %d gave up after 40 ms waiting for the partial (O, m, l) record of slot %d for query block %d (%d slots) - "
+                  "the slots in front of it did not run; the result of that launch is invalid", blk, d0, d1, d2);
   else
     dmx_set_error("device error %d raised by block %d (%d, %d, %d)", k, blk, d0, d1, d2);
   // cleared so that the process may go on after handling it - code word first, the claim word LAST (behind a fence): a block that gives up while
@@ -63,7 +66,7 @@ int dmx_check_launch(const char* what) {
 // hash of the values is part of the key of the captured hipGraphs (unet_model.h GraphKey) and of the host mirror's workspace-size cache, so toggling
 // a switch after the first forward can neither replay a graph captured under another setting nor run a walk in a workspace sized for another one -
 // and switching BACK finds the graphs of the old setting again (a counter would strand them).
-static int g_plan_sw[DMX_SW_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1, 1};      // the defaults of the switches, in DmxPlanSwitch order
+static int g_plan_sw[DMX_SW_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1};      // the defaults of the switches, in DmxPlanSwitch order
 void dmx_plan_switch(int slot, int value) { if (slot >= 0 && slot < DMX_SW_COUNT) g_plan_sw[slot] = value; }
 void dmx_plan_epoch_bump() { ++g_plan_sw[DMX_SW_OVERRIDES]; }
 extern "C" int dmx_plan_epoch(void) {
@@ -629,14 +632,29 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
   constexpr int kv_pf = 1;
 #endif
   if (kv_static && kv_pf) note(k, (long)B * kv_rows * ldk * 2);
+  // balanced schedule (attention_sk.hip) where its plan takes the problem: partial records in the workspace, flags from the zeroed pool
+  AttnArgs a{};
+  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.v = v; a.ldv = ldv;
+  a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
+  const int sk_slots = f32 ? 0 : dmx_attention_balanced_slots(a);
+  void* sk_ws = nullptr;
+  if (sk_slots) {
+    constexpr size_t POOL = 64 * 1024;
+    if (!flag_pool) {
+      flag_pool = (int*)raw(POOL * sizeof(int)); flag_cap = POOL; flag_used = 0;
+      if (!zero_pool(flag_pool, POOL * sizeof(int), 2)) return;
+    }
+    const size_t n = align_up((size_t)sk_slots, 64);
+    const size_t pb = dmx_attention_balanced_part_bytes(a);
+    if (flag_used + n <= flag_cap) { a.sk_flags = flag_pool + flag_used; flag_used += n; sk_ws = raw(pb); a.sk_part = (float*)sk_ws; }
+    // (pool exhausted: the plain grid - the same decision in the dry walk, which counts the same slices)
+  }
+  struct Rel { Workspace& w; void* p; ~Rel() { if (p) w.release(p); } } rel{ws, sk_ws};
   if (dry || rc) return;
   if (f32) {
     rc = dmx_attention_f32_launch((const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, kv_rows, (float*)o, ldo, B, H, Sq, Skv, scale, stream);
     return;
   }
-  AttnArgs a{};
-  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.kv_rows = kv_rows; a.v = v; a.ldv = ldv;
-  a.o = o; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.scale = scale;
   {
 #ifdef DMX_PROBES      // (probe builds, DMX_PF_ATTN=0: the attention launches issue no prefetch units - the launches in front of them already cover the next ranges)
     static const int attn_pf = [] { const char* e = getenv("DMX_PF_ATTN"); return e ? atoi(e) : 1; }();
@@ -647,7 +665,7 @@ void Exec::attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16*
   }
   char tag[96]; snprintf(tag, sizeof(tag), "B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
   ProfScope ps(PROF_ATTN, stream, 4.0 * B * H * (double)Sq * Skv * 64.0, 2.0 * 64.0 * B * H * (2.0 * Sq + 2.0 * Skv), tag);
-  rc = dmx_attention_launch(a, stream);
+  rc = a.sk_part ? dmx_attention_balanced_launch(a, stream) : dmx_attention_launch(a, stream);
 }
 
 void Exec::tap(const Tn& t) {

@@ -10,7 +10,7 @@ enum ProfClass { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_SPLITK = 2, PROF_ATTN =
                  PROF_GEMM_CFG0 = 10 /* one class per GEMM tile config (template instance): 10 + plan id */, PROF_XFCHAIN = 26 /* xf_chain.hip */, PROF_HALO = 27 /* conv_halo.hip */, PROF_SKINNY = 28 /* skinny.hip */, PROF_NCLASS = 29 };
 int n_cus();                                           // compute units of the CURRENT device (conv_halo.hip)
 // exec.hip: the plan signature (key of captured graphs / cached workspace sizes): every plan-changing switch records its value
-enum DmxPlanSwitch { DMX_SW_EXCLUSIVE = 0, DMX_SW_GN_STATS, DMX_SW_DEFER, DMX_SW_HALO, DMX_SW_PREFETCH, DMX_SW_XF_CHAIN, DMX_SW_HALO_WS, DMX_SW_OVERRIDES, DMX_SW_SKINNY, DMX_SW_HALO_PEERS, DMX_SW_COUNT };
+enum DmxPlanSwitch { DMX_SW_EXCLUSIVE = 0, DMX_SW_GN_STATS, DMX_SW_DEFER, DMX_SW_HALO, DMX_SW_PREFETCH, DMX_SW_XF_CHAIN, DMX_SW_HALO_WS, DMX_SW_OVERRIDES, DMX_SW_SKINNY, DMX_SW_HALO_PEERS, DMX_SW_ATTN_BALANCED, DMX_SW_COUNT };
 void dmx_plan_switch(int slot, int value);
 void dmx_plan_epoch_bump();                            // (dmx_gemm_plan_override: a counter)
 extern "C" int dmx_plan_epoch(void);
@@ -289,8 +289,14 @@ struct AttnArgs {
   // optional: up to four byte ranges (the weights of the kernel that runs NEXT) every block touches a slice of at its start, so that they
   // sit in the memory-side cache when that kernel's blocks - which walk them in lock step - ask for them (row-major-V path only)
   const void* pf[4]; int pf_bytes[4];
+  // balanced schedule (attention_sk.hip): partial (O, m, l) records of the helper parts [slots][36 KB], one zeroed flag per slot, the device-error words
+  float* sk_part; int* sk_flags; int* err;
 };
 int dmx_attention_launch(const AttnArgs& a, hipStream_t stream);
+// attention_sk.hip: stream-K over (query block, key tile) items on 3 x CUs block slots; slots = 0 where the plain grid is the plan
+int dmx_attention_balanced_slots(const AttnArgs& a);
+size_t dmx_attention_balanced_part_bytes(const AttnArgs& a);
+int dmx_attention_balanced_launch(AttnArgs a, hipStream_t stream);
 
 // ------------------------------------------------------------------ attention_wide.hip (single head, d = 128 / 256 / 512: the VAE mid block)
 struct AttnWideArgs {

@@ -518,6 +518,19 @@ def attention_v(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
     return o
 
 
+def attention_v_balanced(q, k, v, B, H, Sq, Skv, scale, kv_rows=None):
+    """attention_v on the balanced schedule (attention_sk.hip); None when the plan keeps the plain grid for this problem (dmx_set_attn_balanced)"""
+    wsb = lib().dmx_attention_fwd_v_balanced_workspace_bytes(B, H, Sq, Skv)
+    if not wsb:
+        return None
+    o = torch.empty(B * Sq, H * 64, dtype=h16(), device=q.device)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+    kv_rows = Skv if kv_rows is None else kv_rows
+    check(lib().dmx_attention_fwd_v_balanced(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), kv_rows,
+                                             ptr(o), H * 64, B, H, Sq, Skv, float(scale), ptr(ws), wsb, current_stream()), "attention_fwd_v_balanced")
+    return o
+
+
 def attention_wide(q, k, v, B, Sq, Skv, D, scale, kv_rows=None):
     """single head of width D (128 / 256 / 512): q [B*Sq, >=D], k / v [B*kv_rows, >=D] row-major 2-D views -> [B*Sq, D]"""
     o = torch.empty(B * Sq, D, dtype=h16(), device=q.device)

@@ -328,6 +328,14 @@ int dmx_attention_wide(const void* q, int ldq, const void* k, int ldk, const voi
                        void* o, int ldo, int B, int Sq, int Skv, int D, float scale, dmx_stream_t stream);
 int dmx_attention_fwd_v(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
                         void* o, int ldo, int B, int H, int Sq, int Skv, float scale, dmx_stream_t stream);
+/* The same op on the BALANCED schedule (stream-K over (128-query block, 64-key tile) items on 3 x CUs block slots; a split row's (O, m, l) halves are
+ * folded in a fixed order: bit-repeatable, equal to dmx_attention_fwd_v within the fp32 rounding of the fold).  The executors take it where the plain
+ * grid fills the slots unevenly (the 4096 x 4096 self-attention of the 64x64 level at batch 4).  workspace_bytes = 0: the plan keeps the plain grid. */
+size_t dmx_attention_fwd_v_balanced_workspace_bytes(int B, int H, int Sq, int Skv);
+int dmx_attention_fwd_v_balanced(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int kv_rows,
+                                 void* o, int ldo, int B, int H, int Sq, int Skv, float scale,
+                                 void* workspace, size_t workspace_bytes, dmx_stream_t stream);
+int dmx_set_attn_balanced(int mode);   /* 0: never; 1 (default): where the plan says it pays; 2: wherever the kernel takes the problem (tests, A/B); returns the old setting */
 
 /* Training (P5 over K5/K6): forward that also keeps each row's log2-sum-exp, and the flash-style backward (dQ, dK, dV;
  * deterministic, nothing of size Sq x Skv is stored).  workspace: [B][H][Sq] floats.  Replace autograd's scaled-dot-

@@ -1,5 +1,5 @@
 """A/B of a library switch inside ONE process and on one box: alternating timed 50-step passes with the switch on / off.
-    python scripts/ab_pass.py gn_stats|xf_chain|xf_gn_fold|halo_ws|weight_prefetch|temb_table|halo|halo_all|halo_peers|defer_reduce [--rounds 4] [--batch 4]"""
+    python scripts/ab_pass.py gn_stats|xf_chain|xf_gn_fold|halo_ws|weight_prefetch|temb_table|halo|halo_all|halo_peers|attn_balanced|defer_reduce [--rounds 4] [--batch 4]"""
 import sys
 import time
 
@@ -35,6 +35,8 @@ def setting(on):
         lib.dmx_set_halo_conv(2 if on else 1)         # 2: wherever the kernel takes the problem vs the default rule
     elif what == "halo_peers":
         lib.dmx_set_halo_peers(1 if on else 0)        # a tile's K-split peers on one XCD, slabs through its L2, vs the round-5 dealing with write-through slabs
+    elif what == "attn_balanced":
+        lib.dmx_set_attn_balanced(1 if on else 0)     # stream-K attention (attention_sk.hip) where its plan takes the launch vs the plain grid everywhere
     elif what == "weight_prefetch":
         lib.dmx_set_weight_prefetch(1 if on else 0)     # every launch touches the weights of the launches that follow it (Exec::note / peek)
     elif what == "halo_ws":

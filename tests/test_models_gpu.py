@@ -634,8 +634,11 @@ def test_gradient_sync_single_rank_matches_plain(cuda):
                 backward(i)
         return {k: p.grad.clone() for k, p in model.named_parameters()}
     plain, plain2 = grads([0]), grads([0, 1])
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda if cuda.index is not None else torch.device("cuda", 0))
+    import socket
+    with socket.socket() as sk:                          # a free port of this box (a fixed one may be held by an earlier rendezvous)
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=cuda if cuda.index is not None else torch.device("cuda", 0))
     calls = {"n": 0}
     real = DD.reduce_buckets
 

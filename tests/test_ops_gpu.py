@@ -370,6 +370,70 @@ def test_attention_reference_max_stress(cuda, shape):
     assert_close(out, ref, 6e-3, f"attention, {shape} scores")
 
 
+BAL_CASES = [("self_S4096_B1H2_many_helpers", 1, 2, 4096, 4096), ("cross_S1024x577_ragged", 4, 5, 1024, 577), ("self_S1024_B4H10", 4, 10, 1024, 1024),
+             ("self_S256_B4H20_two_tiles_per_slot", 4, 20, 256, 512)]
+
+
+@pytest.mark.parametrize("case", BAL_CASES, ids=[c[0] for c in BAL_CASES])
+def test_attention_balanced_schedule(cuda, case):
+    """attention_sk.hip: stream-K over (128-query block, 64-key tile) items on 3 x CUs slots, forced wherever the kernel takes the problem
+    (dmx_set_attn_balanced(2)): query blocks split over 2 ... 13 slots (helper parts publish (O, m, l), owners fold them in a fixed order), the ragged
+    577-key tail inside a part, a spiked key row so that the halves of a row carry different reference maxima.  Against fp32 softmax(Q K^T) V on the
+    same bf16 inputs at the kernel's stated 4e-3, against the plain grid (same inputs, same tile arithmetic: the fold's rounding only), and twice
+    for bit-reproducibility."""
+    from diffute_amd import ops, _cabi
+    name, B, H, Sq, Skv = case
+    q = bf(seeded((B, Sq, H * 64), 1)); k = bf(seeded((B, Skv, H * 64), 2)); v = bf(seeded((B, Skv, H * 64), 3))
+    k[0, Skv // 3] *= 6.0; k[B - 1, Skv - 2] *= 5.0            # the running max jumps in the first and in the last part of a row
+    pad = (Skv + 63) // 64 * 64
+    kp = torch.zeros(B, pad, H * 64); kp[:, :Skv] = k
+    vp = torch.zeros(B, pad, H * 64); vp[:, :Skv] = v
+    kv = torch.cat([kp, vp], dim=-1).reshape(B * pad, 2 * H * 64).to(cuda).to(torch.bfloat16)
+    C = H * 64
+    qd = q.reshape(B * Sq, -1).to(cuda).to(torch.bfloat16)
+    plain = ops.attention_v(qd, kv[:, :C], kv[:, C:], B, H, Sq, Skv, 0.125, kv_rows=pad)
+    old = _cabi.lib().dmx_set_attn_balanced(2)
+    try:
+        out = ops.attention_v_balanced(qd, kv[:, :C], kv[:, C:], B, H, Sq, Skv, 0.125, kv_rows=pad)
+        assert out is not None, "the balanced schedule did not take the problem"
+        out2 = ops.attention_v_balanced(qd, kv[:, :C], kv[:, C:], B, H, Sq, Skv, 0.125, kv_rows=pad)
+    finally:
+        _cabi.lib().dmx_set_attn_balanced(old)
+    torch.cuda.synchronize()
+    _cabi.poll_device_error()
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out, out2), f"{name}: not bit-reproducible"
+    if B * H * Sq * Skv <= 1 << 26:
+        qh = q.view(B, Sq, H, 64).transpose(1, 2); kh = k.view(B, Skv, H, 64).transpose(1, 2); vh = v.view(B, Skv, H, 64).transpose(1, 2)
+        ref = torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh
+        assert_close(out, bf(ref.transpose(1, 2).reshape(B * Sq, H * 64)), 4e-3, name)
+    # (the halves of a split row round P to bf16 against different reference maxima: the same ~2e-3 the bf16 P costs either kernel against fp32)
+    assert_close(out, plain.float().cpu(), 4e-3, name + " vs the plain grid")
+
+
+def test_attention_balanced_plan(cuda):
+    """the executors' rule (dmx_set_attn_balanced(1)): the balanced schedule where it measured a win (between one and two 128-row blocks per CU with a
+    long key stream: 4096 x 4096 at batch 2 / 3); the headline launch (2.5 blocks per CU: a wash), evenly filled grids, short key streams and the
+    training forward keep the plain grid"""
+    from diffute_amd import _cabi
+    lib = _cabi.lib()
+    old = lib.dmx_set_attn_balanced(1)
+    try:
+        n_cu = torch.cuda.get_device_properties(cuda).multi_processor_count
+        if n_cu == 256:
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(2, 5, 4096, 4096) > 0
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(3, 5, 4096, 4096) > 0
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(4, 5, 4096, 4096) == 0
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(16, 5, 4096, 4096) == 0
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(2, 5, 4096, 577) == 0
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(1, 5, 4096, 4096) == 0
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(2, 5, 9216, 9216) == 0
+        lib.dmx_set_attn_balanced(0)
+        assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(2, 5, 4096, 4096) == 0
+    finally:
+        lib.dmx_set_attn_balanced(old)
+
+
 WIDE_CASES = [("d512_S4096", 1, 512, 4096), ("d512_S1024_B2", 2, 512, 1024), ("d128_S64", 2, 128, 64), ("d128_S96_tail", 3, 128, 96),
               ("d256_S200_tails", 1, 256, 200), ("d512_S70_tails", 1, 512, 70)]
 
