@@ -63,25 +63,43 @@ def pmc_l2(kernel_name):
     return None
 
 
-L2_PEAK_GBPS = 34500.0          # /opt/skills/guides/MI355X_MICROARCH.md, L2 section
+L2_PEAK_GBPS = 34500.0          # /opt/skills/guides/MI355X_MICROARCH.md, L2 section (fallback when the probe output below is absent)
 HBM_ACHIEVABLE_GBPS = 6300.0    # same guide, HBM section
 
 
+def l2_lds_ceiling():
+    """the L2 -> LDS ceiling measured on this part: the best aggregate rate of an L2-resident ("shared") LDS-DMA stream over all 256 CUs, no compute -
+    scripts/l2_lds_probe.hip, output committed as profiles/r06_l2_lds_probe.txt.  Returns (GB/s, source)."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_l2_lds_probe.txt")
+    best = 0.0
+    if os.path.exists(path):
+        for line in open(path):
+            m = re.search(r"shared\s+stream:.*?([0-9.]+) TB/s aggregate", line)
+            if m:
+                best = max(best, float(m.group(1)) * 1e3)
+    return (best, "profiles/r06_l2_lds_probe.txt (scripts/l2_lds_probe.hip: L2-resident LDS-DMA stream on 256 CUs, best of the ring depths)") if best > 0 else \
+           (L2_PEAK_GBPS, "MI355X_MICROARCH.md L2 section")
+
+
 def secondary_bound(symbol, avg_launch_us, traffic_bytes):
-    """What bounds the dominant kernel once the MFMA roof is ruled out (roofline.frac well under 1): the L2-side request rate against the L2 peak, the HBM
-    traffic against the achievable HBM rate, and where the waves' cycles went (SQ counters).  The label is the largest of those fractions; when every
-    bandwidth fraction is under one half and the waves sit parked most of the time, the bound is latency (load round trips and block-level barriers), not a pipe."""
+    """What bounds the dominant kernel once the MFMA roof is ruled out (roofline.frac well under 1): the bytes it moves through the L2 -> LDS path per launch
+    (TCC requests x 128 B) over its live launch time against the measured L2 -> LDS ceiling, the HBM traffic against the achievable HBM rate, and where the
+    waves' cycles went (SQ counters).  The label is the largest of those fractions if it reaches one half; otherwise "latency" (waves parked on s_waitcnt /
+    s_barrier: load round trips and block-level serialisation) or "issue" (the SIMD's issue slots: VALU / MFMA dependency stalls)."""
     row = pmc_l2(symbol)
     if row is None or avg_launch_us <= 0:
         return None
+    ceil_gbps, ceil_src = l2_lds_ceiling()
     l2_gbps = row["l2_request_bytes_per_launch_at_128B"] / (avg_launch_us * 1e-6) / 1e9
     hbm_gbps = (traffic_bytes / (avg_launch_us * 1e-6) / 1e9) if traffic_bytes else None
-    fr = {"l2": l2_gbps / L2_PEAK_GBPS, "hbm": (hbm_gbps / HBM_ACHIEVABLE_GBPS) if hbm_gbps else 0.0,
+    fr = {"l2": l2_gbps / ceil_gbps, "hbm": (hbm_gbps / HBM_ACHIEVABLE_GBPS) if hbm_gbps else 0.0,
           "lds": row["lds_issuing_frac_SQ_ACTIVE_INST_LDS"] + row["lds_issue_stall_frac_SQ_WAIT_INST_LDS"]}
     label = max(fr, key=fr.get)
-    if fr[label] < 0.5 and row["wave_parked_frac_SQ_WAIT_ANY"] > 0.5:
-        label = "latency"
-    return {"label": label, "l2_GBps": round(l2_gbps, 1), "l2_frac_of_peak": round(fr["l2"], 4), "l2_hit_rate": row["l2_hit_rate"],
+    if fr[label] < 0.5:              # no pipe is half busy: the waves either sit parked (load round trips, block barriers) or the SIMD's issue slots are the limit
+        label = "latency" if row["wave_parked_frac_SQ_WAIT_ANY"] >= 0.45 else "issue"
+    return {"label": label, "l2_GBps": round(l2_gbps, 1), "l2_lds_ceiling_GBps": round(ceil_gbps, 1), "l2_frac_of_ceiling": round(fr["l2"], 4), "ceiling_source": ceil_src,
+            "l2_hit_rate": row["l2_hit_rate"],
             "hbm_GBps": round(hbm_gbps, 1) if hbm_gbps else None, "hbm_frac_of_achievable": round(fr["hbm"], 4),
             "wave_parked_frac": row["wave_parked_frac_SQ_WAIT_ANY"], "issue_stall_frac": row["issue_stall_frac_SQ_WAIT_INST_ANY"],
             "issuing_frac": row["issuing_frac_SQ_ACTIVE_INST_ANY"], "lds_issuing_frac": row["lds_issuing_frac_SQ_ACTIVE_INST_LDS"],

@@ -211,7 +211,8 @@ void Workspace::release(const void* p) {
 static int g_gn_producer_stats = 1;
 extern "C" int dmx_set_gn_producer_stats(int on) { const int old = g_gn_producer_stats; g_gn_producer_stats = on; dmx_plan_switch(DMX_SW_GN_STATS, on); return old; }
 
-// tuning aid (A/B inside one process): 0 = split-K convolutions always run their own reduce pass (ConvOpts.defer ignored)
+// tuning aid (A/B inside one process): 0 = split-K convolutions always run their own reduce pass (ConvOpts.defer ignored); 2 = only the in-block deferrals
+// (conv1 -> norm2), conv2 keeps its own reduce pass
 static int g_defer_reduce = 1;
 extern "C" int dmx_set_defer_reduce(int on) { const int old = g_defer_reduce; g_defer_reduce = on; dmx_plan_switch(DMX_SW_DEFER, on); return old; }
 
@@ -455,7 +456,8 @@ Tn Exec::conv(const Tn& x0, const Tn* x1, const bf16* w, int Cout, const ConvOpt
   if (o.res) { a.res = o.res->p; a.ldres = o.res->ld; }
   a.out = o.out_f32 ? f32_out : (void*)y.p; a.ldo = Cout; a.out_f32 = o.out_f32;
   if (o.stats && !o.out_f32) want_stats(a, y, (o.ups && o.ups2) ? x0.H * x0.W : OH * OW, x0.B);
-  run_gemm(a, (o.defer && g_defer_reduce && !o.out_f32 && !a.ups2) ? &y : nullptr);
+  // (o.defer == 2: the consumer is the NEXT block's GroupNorm - dmx_set_defer_reduce(2) keeps only the in-block deferrals of round 5: A/B aid)
+  run_gemm(a, (o.defer && g_defer_reduce && !(o.defer == 2 && g_defer_reduce == 2) && !o.out_f32 && !a.ups2) ? &y : nullptr);
   return y;
 }
 
@@ -724,7 +726,7 @@ Tn resnet_run(Exec& ex, const char* arena, const ResW& r, const Tn& x0, const Tn
   if (r.temb_off >= 0 && tproj) { o1.rowbias = tproj + r.temb_off; o1.ldrb = tproj_total; }
   Tn t2 = ex.conv_gn(x0, x1, F(r.n1g), F(r.n1b), groups, eps, H(r.w1), r.cout, o1);
   ConvOpts o2; o2.bias = F(r.b2); o2.stats = 1;        // a GroupNorm comes next in every graph (next resnet / transformer / out norm)
-  o2.defer = 1;                                        // ... and where it reads y as its x0 FIRST, a split-K conv2 leaves its reduce pass to it (any other first
+  o2.defer = 2;                                        // ... and where it reads y as its x0 FIRST, a split-K conv2 leaves its reduce pass to it (any other first
                                                        // consumer - down / up-sampling conv, tap, linear - completes the tensor itself: Exec::flush in each of them)
   if (ex.f32 && r.shortcut) { o2.bias = F(r.b2raw); o2.bias2 = F(r.bscraw); }     // the folded bias is derived data: not in the master arena
   if (r.shortcut) { o2.sc0 = &x0; o2.sc1 = x1; } else { o2.res = &x0; }

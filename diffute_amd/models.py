@@ -504,7 +504,7 @@ class UNet2DConditionModel(_HipModel):
         tb = getattr(self, "_tb", None)
         if tb is None or tb["wt"].device != self.device:
             tb = self._tb = dict(wt=torch.empty(lib.dmx_unet_train_wt_bytes(self._h), dtype=torch.uint8, device=self.device),
-                                 grads=torch.empty(lib.dmx_unet_grad_bytes(self._h) // 4, dtype=torch.float32, device=self.device),
+                                 grads=torch.zeros(lib.dmx_unet_grad_bytes(self._h) // 4, dtype=torch.float32, device=self.device),      # (zeros: slots no backward writes - derived weights - are summed / exchanged with the rest)
                                  wt_sig=None, ws=None, events=None, plan=None)
         sig = (self._packed_sig, getattr(self, "_arena_version", 0))
         if tb["wt_sig"] != sig:
@@ -890,7 +890,7 @@ class AutoencoderKL(_HipModel):
         tb = getattr(self, "_tb", None)
         if tb is None or tb["wt"].device != self.device:
             tb = self._tb = dict(wt=torch.empty(lib.dmx_vae_train_wt_bytes(self._h), dtype=torch.uint8, device=self.device),
-                                 grads=torch.empty(lib.dmx_vae_grad_bytes(self._h) // 4, dtype=torch.float32, device=self.device),
+                                 grads=torch.zeros(lib.dmx_vae_grad_bytes(self._h) // 4, dtype=torch.float32, device=self.device),
                                  wt_sig=None, ws=None)
         if tb["wt_sig"] != self._packed_sig:
             _cabi.check(lib.dmx_vae_train_prepare(self._h, _cabi.ptr(tb["wt"]), tb["wt"].numel(), _cabi.current_stream()), "vae_train_prepare")

@@ -199,7 +199,7 @@ int dmx_get_exclusive_device(void); /* the current setting */
 int dmx_plan_epoch(void);           /* counter bumped by every switch that changes which kernels / plans a graph walk uses (every dmx_set_* below and above,
                                      * dmx_gemm_plan_override): part of the key of the captured UNet steps, and what a caller that caches workspace sizes keys on */
 int dmx_set_defer_reduce(int on);   /* tuning aid: 0 = a split-K convolution whose output is read first by a GroupNorm runs its own reduce pass (default 1: the GroupNorm's slab
-                                     * kernel sums the partial planes in its load stage - bit-identical, one launch less); returns the old setting */
+                                     * kernel sums the partial planes in its load stage - bit-identical, one launch less; 2: only inside a resnet, conv1 -> norm2, not conv2 -> the next block's first GroupNorm); returns the old setting */
 int dmx_set_halo_peers(int on);     /* 1 (default): the K-split blocks of a dmx_conv3x3_gn tile are dealt to ONE XCD and, once every peer has confirmed its XCC id, exchange their
                                        fp32 slabs through that XCD's L2 (plain stores); 0: the round-5 dealing with write-through slabs everywhere.  Same bits either way; returns the old setting */
 int dmx_set_halo_ws(int on);        /* tuning aid: 0 keeps dmx_conv3x3_gn's planner off the warp-specialised instances (4 compute + 4 loader waves); returns the old setting */

@@ -1,5 +1,5 @@
 """A/B of a library switch inside ONE process and on one box: alternating timed 50-step passes with the switch on / off.
-    python scripts/ab_pass.py gn_stats|xf_chain|xf_gn_fold|halo_ws|weight_prefetch|temb_table|halo|halo_all|halo_peers|attn_balanced|defer_reduce [--rounds 4] [--batch 4]"""
+    python scripts/ab_pass.py gn_stats|xf_chain|xf_gn_fold|halo_ws|weight_prefetch|temb_table|halo|halo_all|halo_peers|attn_balanced|defer_reduce|defer_cross [--rounds 4] [--batch 4]"""
 import sys
 import time
 
@@ -43,6 +43,8 @@ def setting(on):
         lib.dmx_set_halo_ws(1 if on else 0)           # the warp-specialised halo instances vs the two-group ping-pong
     elif what == "defer_reduce":
         lib.dmx_set_defer_reduce(1 if on else 0)      # split-K conv1 of a resnet leaves its reduce pass to norm2's slab kernel
+    elif what == "defer_cross":
+        lib.dmx_set_defer_reduce(1 if on else 2)      # conv2's reduce in the NEXT block's norm1 (round 6) vs only the in-block deferral of round 5
     elif what == "xf_gn_fold":
         lib.dmx_set_xf_chain(1 if on else 5)          # bit 2: chains without the folded entry GroupNorm
     elif what == "xf_chain":

@@ -697,7 +697,10 @@ def test_gradient_sync_single_rank_matches_plain(cuda):
     try:
         backward(0); backward(1)
         torch.cuda.synchronize()
-        assert opt._pending == 2 and torch.equal(model._tb["grads"], want), "FusedAdamW + accumulation window: the arena is not the window's sum"
+        got = model._tb["grads"]
+        bad = (got != want).nonzero().flatten()
+        assert opt._pending == 2 and bad.numel() == 0, (f"FusedAdamW + accumulation window: the arena is not the window's sum: {bad.numel()} of {got.numel()} slots differ, "
+                                                        f"first at {bad[:4].tolist()}, got {got[bad[:4]].tolist()} want {want[bad[:4]].tolist()}")
         opt.step()
     finally:
         model.set_gradient_sync(None)
