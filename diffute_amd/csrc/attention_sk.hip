@@ -295,6 +295,9 @@ int dmx_attention_balanced_slots(const AttnArgs& a) {
   const int ns = 3 * sk_n_cus();
   if (T < ns) return 0;
   if (g_attn_balanced >= 2) return ns;
+  // (with other streams sharing the CUs - dmx_set_exclusive_device(0): micro-batches, a collective next to the step - the slots of a launch are not all
+  // resident and the 8 slots at an XCD boundary would wait for blocks dispatched after them: correct (bounded, others retire), but not a plan to choose)
+  if (!dmx_exclusive_device()) return 0;
   if (nqb <= sk_n_cus() || nqb > 2 * sk_n_cus() || T / ns < 24) return 0;
   return ns;
 }
