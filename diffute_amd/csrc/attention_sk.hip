@@ -287,7 +287,7 @@ static int sk_n_cus() {
 }
 // slots of the balanced schedule for this problem, 0 = the plain grid.  Measured (EXPERIMENTS.md round 6, profiles/r06_attn_balanced_probe.txt): a slot pays ~7 us
 // for its second prologue, the publish and the fold, and the slots lose the lock step that keeps a head's K / V tiles in L2.  That is a win where the plain
-// grid leaves whole CUs with half the work of their neighbours (1 < blocks per CU <= 2: 4096 x 4096 at batch 2, 82 -> 64 us), a wash at the headline shape
+// grid leaves CUs idle or with half the work of their neighbours (at most two blocks per CU: 4096 x 4096 at batch 1, 59.6 -> 40.7 us, batch 2, 82 -> 64 us), a wash at the headline shape
 // (2.5 blocks per CU on 3 slots: 130 vs 130 us stand-alone, 334.2 vs 334.3 ms per pass in situ) and a loss where the slots are evenly filled (batch 8: +7 %).
 int dmx_attention_balanced_slots(const AttnArgs& a) {
   if (!g_attn_balanced || !a.v || a.lse || a.Sq % 128 || a.B <= 0) return 0;
@@ -298,7 +298,7 @@ int dmx_attention_balanced_slots(const AttnArgs& a) {
   // (with other streams sharing the CUs - dmx_set_exclusive_device(0): micro-batches, a collective next to the step - the slots of a launch are not all
   // resident and the 8 slots at an XCD boundary would wait for blocks dispatched after them: correct (bounded, others retire), but not a plan to choose)
   if (!dmx_exclusive_device()) return 0;
-  if (nqb <= sk_n_cus() || nqb > 2 * sk_n_cus() || T / ns < 24) return 0;
+  if (nqb > 2 * sk_n_cus() || T / ns < 12) return 0;
   return ns;
 }
 size_t dmx_attention_balanced_part_bytes(const AttnArgs& a) {

@@ -412,8 +412,8 @@ def test_attention_balanced_schedule(cuda, case):
 
 
 def test_attention_balanced_plan(cuda):
-    """the executors' rule (dmx_set_attn_balanced(1)): the balanced schedule where it measured a win (between one and two 128-row blocks per CU with a
-    long key stream: 4096 x 4096 at batch 2 / 3); the headline launch (2.5 blocks per CU: a wash), evenly filled grids, short key streams and the
+    """the executors' rule (dmx_set_attn_balanced(1)): the balanced schedule where it measured a win (at most two 128-row blocks per CU with a
+    long key stream: 4096 x 4096 at batch 1 / 2 / 3); the headline launch (2.5 blocks per CU: a wash), evenly filled grids, short key streams and the
     training forward keep the plain grid"""
     from diffute_amd import _cabi
     lib = _cabi.lib()
@@ -426,7 +426,8 @@ def test_attention_balanced_plan(cuda):
             assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(4, 5, 4096, 4096) == 0
             assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(16, 5, 4096, 4096) == 0
             assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(2, 5, 4096, 577) == 0
-            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(1, 5, 4096, 4096) == 0
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(1, 5, 4096, 4096) > 0
+            assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(1, 10, 1024, 1024) == 0
             assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(2, 5, 9216, 9216) == 0
         lib.dmx_set_attn_balanced(0)
         assert lib.dmx_attention_fwd_v_balanced_workspace_bytes(2, 5, 4096, 4096) == 0
