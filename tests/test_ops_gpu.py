@@ -411,6 +411,39 @@ def test_attention_balanced_schedule(cuda, case):
     assert_close(out, plain.float().cpu(), 4e-3, name + " vs the plain grid")
 
 
+def test_attention_balanced_under_uneven_load(cuda):
+    """The balanced schedule when its 768 slots are NOT all resident: a side stream holds 64 ... 200 CUs in bursts while the 4096 x 4096 batch-1 launch (the
+    shape the executors take it for) runs.  Owners then wait for helper slots that start late; the schedule must neither deadlock (a slot only waits for
+    slots that publish before they wait for anybody; the 8 slots at an XCD boundary wait for blocks dispatched after them, which get their CU when any
+    other block retires) nor change a bit: 12 launches, every one equal to the quiet result, no device error raised."""
+    import time
+    from diffute_amd import ops, _cabi
+    lib = _cabi.lib()
+    B, H, S = 1, 5, 4096
+    C = H * 64
+    g = torch.Generator(device=cuda).manual_seed(5)
+    q = torch.randn(B * S, C, device=cuda, generator=g).to(ops.h16())
+    kv = torch.randn(B * S, 2 * C, device=cuda, generator=g).to(ops.h16())
+    side = torch.cuda.Stream(device=cuda)
+    old = lib.dmx_set_attn_balanced(2)
+    try:
+        ref = ops.attention_v_balanced(q, kv[:, :C], kv[:, C:], B, H, S, S, 0.125)
+        assert ref is not None
+        ref = ref.clone()
+        torch.cuda.synchronize()
+        for it in range(12):
+            with torch.cuda.stream(side):
+                _cabi.check(lib.dmx_test_occupy_cus((64, 128, 200)[it % 3], 30_000 + 20_000 * (it % 4), _cabi.current_stream()), "occupy")    # 0.3 - 0.9 ms bursts
+            if it % 2:
+                time.sleep(0.0003)
+            out = ops.attention_v_balanced(q, kv[:, :C], kv[:, C:], B, H, S, S, 0.125)
+            torch.cuda.synchronize()
+            _cabi.poll_device_error()
+            assert torch.equal(out, ref), f"launch {it}: the balanced schedule changed its result under load"
+    finally:
+        lib.dmx_set_attn_balanced(old)
+
+
 def test_attention_balanced_plan(cuda):
     """the executors' rule (dmx_set_attn_balanced(1)): the balanced schedule where it measured a win (at most two 128-row blocks per CU with a
     long key stream: 4096 x 4096 at batch 1 / 2 / 3); the headline launch (2.5 blocks per CU: a wash), evenly filled grids, short key streams and the
