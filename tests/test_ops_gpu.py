@@ -424,7 +424,7 @@ def test_attention_balanced_under_uneven_load(cuda):
     g = torch.Generator(device=cuda).manual_seed(5)
     q = torch.randn(B * S, C, device=cuda, generator=g).to(ops.h16())
     kv = torch.randn(B * S, 2 * C, device=cuda, generator=g).to(ops.h16())
-    side = torch.cuda.Stream(device=cuda)
+    sides = [torch.cuda.Stream(device=cuda) for _ in range(3)]      # (streams share a few hardware queues: of three, at least two run beside the current one)
     old = lib.dmx_set_attn_balanced(2)
     try:
         ref = ops.attention_v_balanced(q, kv[:, :C], kv[:, C:], B, H, S, S, 0.125)
@@ -432,8 +432,9 @@ def test_attention_balanced_under_uneven_load(cuda):
         ref = ref.clone()
         torch.cuda.synchronize()
         for it in range(12):
-            with torch.cuda.stream(side):
-                _cabi.check(lib.dmx_test_occupy_cus((64, 128, 200)[it % 3], 30_000 + 20_000 * (it % 4), _cabi.current_stream()), "occupy")    # 0.3 - 0.9 ms bursts
+            for si, side in enumerate(sides):
+                with torch.cuda.stream(side):
+                    _cabi.check(lib.dmx_test_occupy_cus((20, 40, 66)[(it + si) % 3], 30_000 + 20_000 * ((it + si) % 4), _cabi.current_stream()), "occupy")    # 0.3 - 0.9 ms bursts
             if it % 2:
                 time.sleep(0.0003)
             out = ops.attention_v_balanced(q, kv[:, :C], kv[:, C:], B, H, S, S, 0.125)
@@ -843,7 +844,7 @@ def test_conv3x3_gn_halo_peers_under_uneven_load(cuda):
     import time
     from diffute_amd import ops, _cabi
     lib = _cabi.lib()
-    side = torch.cuda.Stream(device=cuda)
+    sides = [torch.cuda.Stream(device=cuda) for _ in range(3)]      # (streams share a few hardware queues: of three, at least two run beside the current one)
     for (B, H, W, C, N, split) in ((4, 64, 64, 320, 320, 2), (4, 32, 32, 640, 640, 4)):
         x = bf(seeded((B, C, H, W), 21) * 1.2 + 0.1)
         w = bf(seeded((N, C, 3, 3), 22, 1 / math.sqrt(9 * C))); b = seeded((N,), 23, 0.1)
@@ -859,8 +860,9 @@ def test_conv3x3_gn_halo_peers_under_uneven_load(cuda):
             lib.dmx_set_halo_peers(old_peers)
         torch.cuda.synchronize()
         for it in range(12):
-            with torch.cuda.stream(side):
-                _cabi.check(lib.dmx_test_occupy_cus(16, 100_000 + 40_000 * (it % 3), _cabi.current_stream()), "occupy")      # 1 - 1.8 ms bursts
+            for si, side in enumerate(sides):
+                with torch.cuda.stream(side):
+                    _cabi.check(lib.dmx_test_occupy_cus(6 + si, 100_000 + 40_000 * ((it + si) % 3), _cabi.current_stream()), "occupy")      # 1 - 1.8 ms bursts
             if it % 2:
                 time.sleep(0.0005)
             out, st = ops.conv3x3_gn(X, W_, N, **kw)
@@ -919,19 +921,26 @@ def test_device_error_channel(cuda):
     good = ops.conv3x3_gn(X, W_, N, **kw)
     torch.cuda.synchronize()
     assert lib.dmx_device_error() == 0
-    side = torch.cuda.Stream(device=cuda)
-    hog = torch.cuda.get_device_properties(cuda).multi_processor_count - 1
-    with torch.cuda.stream(side):
-        _cabi.check(lib.dmx_test_occupy_cus(hog, 12_000_000, _cabi.current_stream()), "occupy")       # 120 ms
     import time
-    time.sleep(0.01)                                   # the hog is resident before the conv is launched
-    t0 = time.perf_counter()
-    starved = ops.conv3x3_gn(X, W_, N, **kw)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert dt < 2.0, f"the starved launch took {dt:.2f} s: the wait is not bounded"
-    rc = lib.dmx_device_error()
-    msg = lib.dmx_last_error().decode()
+    hog = torch.cuda.get_device_properties(cuda).multi_processor_count - 1
+    # (the runtime multiplexes streams onto a few hardware queues: a side stream that shares the current stream's queue SERIALISES with it - the conv then
+    # simply runs after the hog, nothing is starved.  Which streams alias depends on how many were created before, so up to four fresh ones are tried.)
+    rc, msg, side = 0, "", None
+    for attempt in range(4):
+        side = torch.cuda.Stream(device=cuda)
+        with torch.cuda.stream(side):
+            _cabi.check(lib.dmx_test_occupy_cus(hog, 12_000_000, _cabi.current_stream()), "occupy")       # 120 ms
+        time.sleep(0.01)                                   # the hog is resident before the conv is launched
+        t0 = time.perf_counter()
+        starved = ops.conv3x3_gn(X, W_, N, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert dt < 2.0, f"the starved launch took {dt:.2f} s: the wait is not bounded"
+        rc = lib.dmx_device_error()
+        msg = lib.dmx_last_error().decode()
+        if rc == -5:
+            break
+        assert torch.equal(starved[0] if isinstance(starved, tuple) else starved, good[0] if isinstance(good, tuple) else good), "a launch that was not starved changed its result"
     assert rc == -5 and "halo conv" in msg and "co-resident" in msg, f"a starved K-split launch must raise the device error (rc {rc}: {msg})"
     # ... and through the ordinary path: raise again, then the NEXT launch of the library reports it as its return code
     with torch.cuda.stream(side):
