@@ -4,7 +4,7 @@
     train         the cfg4 step of tests/test_configs_gpu.py (SD2-inpaint UNet, 8 x 512 px, train_diffute_v1.py:913-925): --steps full B = 8 steps,
                   then the "loss of sample 0 only" step inside the batch and the B = 1 step on sample 0.  After every step: host sync, device-error
                   poll, and a checksum (sum of the int32 bit patterns, sum of squares in double) of the prediction and of EVERY exported gradient
-                  tensor -> JSON.  --occupy N keeps N CUs busy on a side stream while each step runs (dmx_test_occupy_cus).
+                  tensor -> JSON.  --occupy N keeps N CUs busy on three side streams (N / 3 each) while each step runs (dmx_test_occupy_cus).
     denoise-loop  a co-tenant: the headline denoise loop (batch 4, 512 px, --dsteps DDIM steps) repeated until <ctl>.stop exists; the first pass runs
                   BEFORE <ctl>.ready is written (quiet reference), every later pass is classified equal / raised / SILENTLY DIFFERENT.
     tiny-train-loop  a co-tenant like tests/d1_world2_worker.py: tiny UNet, forward + backward with the world-2 gloo all-reduce inside the backward, looped.
@@ -47,7 +47,7 @@ def train(args):
     x = torch.cat([lat, mask, mlat], 1)
     t = torch.tensor([437, 12, 999, 650, 3, 800, 250, 501], device=dev)
     tgt = torch.from_numpy(prng.normal(9, 43, 8 * 4 * 64 * 64).reshape(8, 4, 64, 64)).to(dev)
-    side = torch.cuda.Stream(device=dev)
+    sides = [torch.cuda.Stream(device=dev) for _ in range(3)]       # (streams share a few hardware queues: a hog on ONE side stream may just serialise with the step)
     res = {"mode": "train", "tag": args.tag, "occupy": args.occupy, "steps": [], "env": {k: os.environ[k] for k in os.environ if k.startswith(("AMD_", "HIP_", "HSA_"))}}
 
     def step(kind, xs, ts, cs, tg, sel=None):
@@ -55,8 +55,9 @@ def train(args):
         try:
             unet.zero_grad(set_to_none=True)
             if args.occupy:
-                with torch.cuda.stream(side):
-                    _cabi.check(lib.dmx_test_occupy_cus(args.occupy, 45_000_000, _cabi.current_stream()), "occupy")      # 450 ms: covers the step
+                for si, side in enumerate(sides):
+                    with torch.cuda.stream(side):
+                        _cabi.check(lib.dmx_test_occupy_cus((args.occupy + 2 - si) // 3, 45_000_000, _cabi.current_stream()), "occupy")      # 450 ms: covers the step
                 time.sleep(0.02)
             t0 = time.perf_counter()
             pred = unet(xs, ts, cs).sample

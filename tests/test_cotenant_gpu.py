@@ -72,12 +72,15 @@ def test_train_step_under_cotenant(cuda):
         tally["equal"] += 1
 
     # ---- (b) CUs held by another stream of this process while the step runs
-    side = torch.cuda.Stream(device=cuda)
+    # (HIP multiplexes streams onto a few hardware queues; a side stream that shares the training stream's queue would only SERIALISE with the step.  The hog
+    # is therefore dealt over three fresh streams: at least two of them run beside the step whatever the mapping is.)
+    sides = [torch.cuda.Stream(device=cuda) for _ in range(3)]
     n_cu = torch.cuda.get_device_properties(cuda).multi_processor_count
     for hog in (32, 128, n_cu - 1):
         for kind in ("full", "b1"):
-            with torch.cuda.stream(side):
-                _cabi.check(lib.dmx_test_occupy_cus(hog, 15_000_000, _cabi.current_stream()), "occupy")     # 150 ms
+            for si, side in enumerate(sides):
+                with torch.cuda.stream(side):
+                    _cabi.check(lib.dmx_test_occupy_cus((hog + 2 - si) // 3, 15_000_000, _cabi.current_stream()), "occupy")     # 150 ms
             time.sleep(0.01)
             checked(kind, f"{hog} CUs held by a side stream")
     torch.cuda.synchronize()
