@@ -635,7 +635,9 @@ class UNet2DConditionModel(_HipModel):
         if exchange:
             from .dist import reduce_buckets
             if sync["stream"] is None:
-                sync["stream"] = torch.cuda.Stream(device=dpred.device)
+                # (a HIGH-PRIORITY stream: HIP multiplexes ordinary streams onto a few hardware queues, and an exchange stream that shares the backward's
+                # queue would run behind it instead of beside it; priority streams get their own queue - and the collectives are the latency-critical part)
+                sync["stream"] = torch.cuda.Stream(device=dpred.device, priority=-1)
             side = sync["stream"]
             plan = self._sync_plan(tb)
 
